@@ -1,0 +1,140 @@
+/* raiko_hip.h -- C ABI of libraiko_hip.so, the MI355X (gfx950) STARK proving
+ * backend for raiko's risc0 block-proof path.
+ *
+ * Boundary being replaced (reference = Champii/raiko @ 2024-08-07):
+ *   - plugin level:   `trait Prover { run, cancel }`        lib/src/prover.rs:52-62
+ *                     `Risc0Prover::run`                    provers/risc0/driver/src/lib.rs:56-112
+ *                     `prove_locally` -> `session.prove()`  provers/risc0/driver/src/bonsai.rs:230-272
+ *   - operator level: `risc0_zkp::hal::Hal` of risc0-zkp 1.0.1 (Cargo.lock:7243), the trait
+ *                     risc0's own CUDA/Metal backends implement; that crate is not vendored
+ *                     in the reference, so each entry point cites the trait method by name.
+ *
+ * Rules of the ABI: plain pointers and sizes only; every function returns
+ * RK_OK (0) or a negative rk_status and never aborts; `d_` pointers are device
+ * memory of the ctx's GPU; work is asynchronous on the ctx stream unless the
+ * function returns data to the host (those synchronise the stream).
+ * All field elements are BabyBear Montgomery residues (u32 < p = 15*2^27+1);
+ * extension elements are 4 consecutive u32; digests are 8 consecutive u32.
+ * Matrices are column-major: element (row r, column c) at c*rows + r.
+ */
+#ifndef RAIKO_HIP_H
+#define RAIKO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RK_OK = 0,
+    RK_ERR_INVALID = -1,   /* bad argument (size not a power of two, null pointer, ...) */
+    RK_ERR_HIP = -2,       /* a HIP runtime call failed; see rk_last_error */
+    RK_ERR_NOMEM = -3,
+    RK_ERR_NODEVICE = -4,
+    RK_ERR_CAPACITY = -5,  /* caller-provided output buffer too small */
+    RK_ERR_INTERNAL = -6   /* a prover invariant failed (non-zero remainder in the DEEP division) */
+} rk_status;
+
+typedef struct rk_ctx rk_ctx;
+
+/* ---- library / device management ---- */
+int rk_abi_version(void);
+const char* rk_strerror(int status);
+const char* rk_last_error(rk_ctx* ctx);            /* detail text of the last RK_ERR_HIP */
+int rk_device_count(int* count);
+/* stream = a hipStream_t the caller owns (e.g. torch's current stream) or NULL for a private one */
+int rk_ctx_create(int device, void* stream, rk_ctx** out);
+int rk_ctx_destroy(rk_ctx* ctx);
+int rk_sync(rk_ctx* ctx);
+int rk_alloc(rk_ctx* ctx, size_t bytes, void** d_ptr);
+int rk_free(rk_ctx* ctx, void* d_ptr);
+int rk_h2d(rk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int rk_d2h(rk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* Poseidon2 t=24 constants, Montgomery form: 192 external round constants (8 rounds x 24),
+ * 21 internal round constants, 24 internal-diagonal entries.  Defaults are compiled in. */
+int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t* rc_int, const uint32_t* diag);
+
+/* ---- Hal trait operators (risc0-zkp 1.0.1 hal/mod.rs `trait Hal`) ---- */
+/* Hal::batch_interpolate_ntt: `count` columns of `size` natural-order evaluations ->
+ * bit-reversed coefficients, in place. */
+int rk_batch_interpolate_ntt(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count);
+/* Hal::batch_evaluate_ntt: bit-reversed coefficients -> natural-order evaluations, in place. */
+int rk_batch_evaluate_ntt(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, uint32_t expand_bits);
+/* Hal::zk_shift: io[col][i] *= 3^bitrev(i). */
+int rk_zk_shift(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count);
+/* Hal::batch_expand_into_evaluate_ntt: zero-extend `in_size` bit-reversed coefficients to
+ * in_size << expand_bits and evaluate (natural order out). */
+int rk_batch_expand_into_evaluate_ntt(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_size,
+                                      size_t count, uint32_t expand_bits);
+/* Hal::batch_bit_reverse */
+int rk_batch_bit_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count);
+/* Hal::hash_rows: one Poseidon2 sponge digest per row of a column-major rows x cols matrix. */
+int rk_hash_rows(rk_ctx* ctx, uint32_t* d_out_digests, const uint32_t* d_matrix, size_t rows, size_t cols);
+/* Hal::hash_fold: nodes[out_size + i] = H(nodes[2*(out_size+i)], nodes[2*(out_size+i)+1]), i < out_size. */
+int rk_hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t input_size, size_t output_size);
+/* Hal::batch_evaluate_any: out[e] = sum_k coeffs[which[e]*size + k] * xs[e]^k (host arrays for
+ * which/xs/out: they are transcript-sized). */
+int rk_batch_evaluate_any(rk_ctx* ctx, const uint32_t* d_coeffs, size_t poly_count, size_t size,
+                          const uint32_t* h_which, const uint32_t* h_xs, size_t eval_count, uint32_t* h_out);
+/* Hal::mix_poly_coeffs: out[combos[i]*count + idx] += mix_start * mix^i * in[i*count + idx]. */
+int rk_mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t mix_start[4], const uint32_t mix[4],
+                       const uint32_t* d_in, const uint32_t* h_combos, size_t input_size, size_t count);
+/* Hal::eltwise_* */
+int rk_eltwise_add_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n);
+int rk_eltwise_sum_extelem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in_ext, size_t count, size_t to_add);
+int rk_eltwise_copy_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n);
+int rk_eltwise_zeroize_elem(rk_ctx* ctx, uint32_t* d_io, size_t n);
+/* Hal::fri_fold: arity-16 fold of 4 coefficient planes (bit-reversed order in and out). */
+int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const uint32_t mix[4]);
+/* Hal::gather_sample: dst[g] = src[g*stride + idx], g < size. */
+int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
+
+/* ---- fused building blocks (no single Hal counterpart) ---- */
+/* MerkleTreeProver::new (risc0-zkp prove/merkle.rs): hash_rows + every hash_fold level into
+ * d_nodes (2*rows digests, heap order, root at index 1). */
+int rk_merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols);
+/* synthetic division of one extension polynomial (count coefficients, natural order) by (x - z),
+ * in place (core/poly.rs poly_divide); the remainder f(z) goes to h_rem (4 words, may be NULL). */
+int rk_poly_divide(rk_ctx* ctx, uint32_t* d_polys_ext, size_t count, const uint32_t z[4], uint32_t* h_rem);
+
+/* ---- whole-segment prover (Prover::commit_group/finalize + fri_prove of risc0-zkp 1.0.1) ---- */
+typedef struct {
+    uint32_t group_size[3];        /* columns per register group: 0 accum, 1 code, 2 data */
+    uint32_t n_regs;               /* registers sorted by (group, offset); must cover every column once */
+    const uint32_t* reg_group;
+    const uint32_t* reg_offset;
+    const uint32_t* reg_combo;
+    uint32_t n_combos;
+    const uint32_t* combo_off;     /* n_combos + 1 prefix offsets into combo_backs */
+    const uint32_t* combo_backs;
+} rk_taps;
+
+typedef struct {
+    uint32_t po2;                  /* segment has 2^po2 rows */
+    uint32_t on_device;            /* 1: group[] and check are device pointers, 0: host pointers */
+    rk_taps taps;
+    const uint32_t* group[3];      /* trace evaluations, column-major 2^po2 x group_size[g] */
+    const uint32_t* check;         /* eval_check output: 4 x 4*2^po2 evaluations (CircuitHal::eval_check) */
+    const uint32_t* globals;       /* host, n_globals elements */
+    uint32_t n_globals;
+    uint32_t n_accum_mix;          /* Fiat-Shamir elements drawn before the accum group is committed */
+    uint8_t proof_system_info[16];
+    uint8_t circuit_info[16];
+} rk_segment;
+
+/* Produces the seal (the u32 Fiat-Shamir transcript) of one segment. */
+int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t seal_capacity_words,
+                     size_t* seal_words);
+/* Upper bound on the seal size for a given shape. */
+size_t rk_seal_bound_words(const rk_segment* seg);
+
+/* per-stage device time of the last rk_prove_segment on this ctx, milliseconds (hipEvent) */
+typedef struct { float ntt, hash, deep, fri, query, total; } rk_timing;
+int rk_last_timing(rk_ctx* ctx, rk_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAIKO_HIP_H */

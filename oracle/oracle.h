@@ -1,0 +1,144 @@
+/* TEST INFRASTRUCTURE -- CPU oracle for the segment-proof hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (raiko_amd/, libraiko_hip.so) never does.
+ *
+ * PARITY UNPINNED (byte level).  The path is `session.prove()` called at
+ * /root/reference provers/risc0/driver/src/bonsai.rs:271; the algorithm lives in
+ * the crates.io dependency risc0-zkp 1.0.1 (+ risc0-core 1.0.1,
+ * risc0-circuit-rv32im 1.0.1; reference Cargo.lock:7243,:7171,:7129) whose
+ * source is absent from /root/reference, and the reference holds no golden
+ * vector for it.  Every function below restates the
+ * published algorithm of the named risc0-zkp module and is pinned by
+ * algebraic known-answer tests (tests/test_oracle_*.py): exact big-int field
+ * arithmetic, O(n^2) DFT, iNTT(NTT)=id, Merkle openings that verify, FRI folds
+ * equal to direct evaluation, and a verifier that accepts the produced seal.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include "or_field.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OR_INV_RATE 4
+#define OR_QUERIES 50
+#define OR_FRI_FOLD 16
+#define OR_FRI_FOLD_PO2 4
+#define OR_FRI_MIN_DEGREE 256
+#define OR_DIGEST_WORDS 8
+#define OR_CELLS 24
+#define OR_CELLS_RATE 16
+#define OR_CELLS_OUT 8
+#define OR_EXT 4
+#define OR_CHECK_SIZE 16
+
+/* ---- field helpers exported for ctypes tests ---- */
+uint32_t or_fp_mul(uint32_t a, uint32_t b);
+uint32_t or_fp_add(uint32_t a, uint32_t b);
+uint32_t or_fp_sub(uint32_t a, uint32_t b);
+uint32_t or_fp_inv(uint32_t a);
+uint32_t or_fp_encode(uint32_t canon);
+uint32_t or_fp_decode(uint32_t mont);
+void or_fp4_mul(const uint32_t* a, const uint32_t* b, uint32_t* out);
+void or_fp4_inv(const uint32_t* a, uint32_t* out);
+uint32_t or_rou_fwd(unsigned k); /* Montgomery form of 137^(2^(27-k)) */
+uint32_t or_rou_rev(unsigned k);
+
+/* ---- risc0-zkp core/ntt.rs ---- */
+void or_bit_reverse(fp* io, size_t n);
+void or_interpolate_ntt(fp* io, size_t n);                   /* natural evals -> bit-reversed coeffs */
+void or_evaluate_ntt(fp* io, size_t n, unsigned expand_bits);/* bit-reversed coeffs -> natural evals */
+
+/* ---- risc0-zkp core/hash/poseidon2 ---- */
+void or_poseidon2_mix(fp* cells /*24*/);
+void or_hash_elem_slice(const fp* in, size_t n, size_t stride, uint32_t* digest /*8*/);
+void or_hash_pair(const uint32_t* a, const uint32_t* b, uint32_t* out);
+
+/* ---- risc0-zkp hal/cpu.rs: the Hal trait ---- */
+void or_batch_interpolate_ntt(fp* io, size_t size, size_t count);
+void or_batch_evaluate_ntt(fp* io, size_t size, size_t count, unsigned expand_bits);
+void or_zk_shift(fp* io, size_t size, size_t count);
+void or_batch_expand_into_evaluate_ntt(fp* out, const fp* in, size_t in_size, size_t count, unsigned expand_bits);
+void or_batch_bit_reverse(fp* io, size_t size, size_t count);
+void or_hash_rows(uint32_t* out, const fp* matrix, size_t rows, size_t cols);
+void or_hash_fold(uint32_t* nodes, size_t input_size, size_t output_size);
+void or_batch_evaluate_any(const fp* coeffs, size_t size, const uint32_t* which, const fp4* xs,
+                           size_t eval_count, fp4* out);
+void or_mix_poly_coeffs(fp4* out, const uint32_t* mix_start, const uint32_t* mix, const fp* in,
+                        const uint32_t* combos, size_t input_size, size_t count);
+void or_eltwise_add_elem(fp* out, const fp* a, const fp* b, size_t n);
+void or_eltwise_sum_extelem(fp* out, const fp4* in, size_t count, size_t to_add);
+void or_eltwise_copy_elem(fp* out, const fp* in, size_t n);
+void or_eltwise_zeroize_elem(fp* io, size_t n);
+void or_fri_fold(fp* out, const fp* in, size_t out_count, const uint32_t* mix);
+void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t stride);
+
+/* ---- risc0-zkp core/poly.rs ---- */
+void or_poly_interpolate(fp4* out, const fp4* x, const fp4* fx, size_t n);
+void or_poly_divide(fp4* p, size_t n, const uint32_t* z, uint32_t* remainder);
+void or_poly_eval(const fp4* coeffs, size_t n, const uint32_t* x, uint32_t* out);
+
+/* ---- risc0-zkp prove/merkle.rs ---- */
+typedef struct {
+    size_t rows, cols, queries, layers, top_layer, top_size;
+    uint32_t* nodes;   /* 2*rows digests, heap order, nodes[1] = root */
+    const fp* matrix;  /* column-major rows x cols */
+} or_merkle;
+void or_merkle_build(or_merkle* m, const fp* matrix, size_t rows, size_t cols, size_t queries);
+void or_merkle_free(or_merkle* m);
+
+/* ---- risc0-zkp prove/write_iop.rs + hash/poseidon2/rng.rs ---- */
+typedef struct {
+    uint32_t* proof; size_t len, cap;
+    fp cells[OR_CELLS]; size_t pool_used;
+} or_iop;
+void or_iop_init(or_iop* iop);
+void or_iop_free(or_iop* iop);
+void or_iop_commit(or_iop* iop, const uint32_t* digest);
+void or_iop_write(or_iop* iop, const uint32_t* words, size_t n);
+uint32_t or_iop_random_bits(or_iop* iop, unsigned bits);
+fp or_iop_random_elem(or_iop* iop);
+fp4 or_iop_random_ext(or_iop* iop);
+
+/* ---- tap set (risc0-zkp taps.rs), supplied by the caller ---- */
+typedef struct {
+    uint32_t group_size[3];        /* columns per group: 0 accum, 1 code, 2 data */
+    uint32_t n_regs;               /* sorted by (group, offset) */
+    const uint32_t* reg_group;
+    const uint32_t* reg_offset;
+    const uint32_t* reg_combo;
+    uint32_t n_combos;
+    const uint32_t* combo_off;     /* n_combos+1 prefix offsets into combo_backs */
+    const uint32_t* combo_backs;
+} or_taps;
+
+typedef struct {
+    uint32_t po2;
+    or_taps taps;
+    const fp* group[3];            /* trace evaluations, column-major N x group_size, by group id */
+    const fp* check;               /* stand-in for eval_check output: 4 x 4N evaluations */
+    const fp* globals; uint32_t n_globals;
+    uint32_t n_accum_mix;          /* elements drawn before the accum commit */
+    uint8_t proof_system_info[16];
+    uint8_t circuit_info[16];
+} or_segment;
+
+/* risc0-zkp prove/prover.rs + circuit/rv32im prove/mod.rs (prove_segment):
+ * returns malloc'd seal (u32 transcript). threads>0 sets the OpenMP team size. */
+int or_prove_segment(const or_segment* seg, uint32_t** seal, size_t* seal_words, int threads);
+/* risc0-zkp verify/mod.rs restated for the same flow, minus the circuit's
+ * constraint identity (no rv32im circuit available): 0 = accept. */
+int or_verify_segment(const or_segment* pub_only, const uint32_t* seal, size_t seal_words);
+void or_free(void* p);
+int or_max_threads(void);
+
+/* stage timing of the last or_prove_segment call, seconds */
+typedef struct { double ntt, hash, deep, fri, query, total; } or_timing;
+void or_last_timing(or_timing* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,131 @@
+"""ctypes binding of libraiko_hip.so (the C ABI declared in include/raiko_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load the
+import of anything that computes raises `HipLibraryError`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraiko_hip.so")
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class RkError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"libraiko_hip status {status}: {detail}")
+
+
+u32p = C.POINTER(C.c_uint32)
+
+
+class RkTaps(C.Structure):
+    _fields_ = [
+        ("group_size", C.c_uint32 * 3),
+        ("n_regs", C.c_uint32),
+        ("reg_group", u32p),
+        ("reg_offset", u32p),
+        ("reg_combo", u32p),
+        ("n_combos", C.c_uint32),
+        ("combo_off", u32p),
+        ("combo_backs", u32p),
+    ]
+
+
+class RkSegment(C.Structure):
+    _fields_ = [
+        ("po2", C.c_uint32),
+        ("on_device", C.c_uint32),
+        ("taps", RkTaps),
+        ("group", C.c_void_p * 3),
+        ("check", C.c_void_p),
+        ("globals", u32p),
+        ("n_globals", C.c_uint32),
+        ("n_accum_mix", C.c_uint32),
+        ("proof_system_info", C.c_uint8 * 16),
+        ("circuit_info", C.c_uint8 * 16),
+    ]
+
+
+class RkTiming(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("ntt", "hash", "deep", "fri", "query", "total")]
+
+
+# every symbol include/raiko_hip.h declares: name -> (restype, argtypes)
+_vp, _sz, _u32 = C.c_void_p, C.c_size_t, C.c_uint32
+SYMBOLS = {
+    "rk_abi_version": (C.c_int, []),
+    "rk_strerror": (C.c_char_p, [C.c_int]),
+    "rk_last_error": (C.c_char_p, [_vp]),
+    "rk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rk_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "rk_ctx_destroy": (C.c_int, [_vp]),
+    "rk_sync": (C.c_int, [_vp]),
+    "rk_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "rk_free": (C.c_int, [_vp, _vp]),
+    "rk_h2d": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "rk_d2h": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "rk_set_poseidon2_params": (C.c_int, [_vp, u32p, u32p, u32p]),
+    "rk_batch_interpolate_ntt": (C.c_int, [_vp, _vp, _sz, _sz]),
+    "rk_batch_evaluate_ntt": (C.c_int, [_vp, _vp, _sz, _sz, _u32]),
+    "rk_zk_shift": (C.c_int, [_vp, _vp, _sz, _sz]),
+    "rk_batch_expand_into_evaluate_ntt": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _u32]),
+    "rk_batch_bit_reverse": (C.c_int, [_vp, _vp, _sz, _sz]),
+    "rk_hash_rows": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
+    "rk_hash_fold": (C.c_int, [_vp, _vp, _sz, _sz]),
+    "rk_batch_evaluate_any": (C.c_int, [_vp, _vp, _sz, _sz, u32p, u32p, _sz, u32p]),
+    "rk_mix_poly_coeffs": (C.c_int, [_vp, _vp, u32p, u32p, _vp, u32p, _sz, _sz]),
+    "rk_eltwise_add_elem": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),
+    "rk_eltwise_sum_extelem": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
+    "rk_eltwise_copy_elem": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "rk_eltwise_zeroize_elem": (C.c_int, [_vp, _vp, _sz]),
+    "rk_fri_fold": (C.c_int, [_vp, _vp, _vp, _sz, u32p]),
+    "rk_gather_sample": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz]),
+    "rk_merkle_build": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
+    "rk_poly_divide": (C.c_int, [_vp, _vp, _sz, u32p, u32p]),
+    "rk_prove_segment": (C.c_int, [_vp, C.POINTER(RkSegment), u32p, _sz, C.POINTER(_sz)]),
+    "rk_seal_bound_words": (_sz, [C.POINTER(RkSegment)]),
+    "rk_last_timing": (C.c_int, [_vp, C.POINTER(RkTiming)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach prototypes.  Raises HipLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  raiko_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, status):
+    if status != 0:
+        lib = load()
+        msg = lib.rk_strerror(status).decode()
+        if ctx_handle:
+            detail = lib.rk_last_error(ctx_handle).decode()
+            if detail:
+                msg += " (" + detail + ")"
+        raise RkError(status, msg)

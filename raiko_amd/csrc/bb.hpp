@@ -1,0 +1,149 @@
+// BabyBear field core shared by device kernels and the host-side prover.
+//
+// p = 15*2^27 + 1, elements are Montgomery residues (R = 2^32) in [0, p), the
+// storage format of every buffer crossing the C ABI.  Extension: Fp[x]/(x^4+11).
+// This restates the published field used by `session.prove()` (reference call
+// site: provers/risc0/driver/src/bonsai.rs:271; the implementation is in the
+// un-vendored crate risc0-core 1.0.1, reference Cargo.lock:7171).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RK_HD __host__ __device__ __forceinline__
+#define RK_D __device__ __forceinline__
+#else
+#define RK_HD inline
+#define RK_D inline
+#endif
+
+namespace bb {
+
+constexpr uint32_t P = 2013265921u;
+constexpr uint32_t MPRIME = 0x88000001u;  // p^-1 mod 2^32
+constexpr uint32_t R2 = 1172168163u;      // 2^64 mod p
+constexpr uint32_t ONE = 268435454u;      // 2^32 mod p
+constexpr uint32_t INVALID = 0xffffffffu;
+
+RK_HD uint32_t add(uint32_t a, uint32_t b) {
+    uint32_t r = a + b;  // < 2p < 2^32
+    uint32_t s = r - P;
+    return s < r ? s : r;  // min(r, r-p) in unsigned arithmetic
+}
+RK_HD uint32_t sub(uint32_t a, uint32_t b) {
+    uint32_t r = a - b;
+    uint32_t s = r + P;
+    return s < r ? s : r;  // if a<b, r wrapped and r+p is the small value
+}
+RK_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+RK_HD uint32_t dbl(uint32_t a) { return add(a, a); }
+
+// Montgomery reduction of a 64-bit value t < 2^32 * p: returns t * 2^-32 mod p in [0, p)
+RK_HD uint32_t mont_reduce(uint64_t t) {
+    uint32_t q = (uint32_t)t * (0u - MPRIME);  // q = -t * p^-1 mod 2^32
+    uint64_t u = t + (uint64_t)q * P;          // low 32 bits cancel; u < 2^64
+    uint32_t r = (uint32_t)(u >> 32);          // < 2p
+    uint32_t s = r - P;
+    return s < r ? s : r;
+}
+RK_HD uint32_t mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
+RK_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+RK_HD uint32_t encode(uint32_t canon) { return mul(canon % P, R2); }
+RK_HD uint32_t decode(uint32_t m) { return mont_reduce((uint64_t)m); }
+RK_HD uint32_t pow(uint32_t a, uint64_t e) {
+    uint32_t r = ONE;
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+RK_HD uint32_t inv(uint32_t a) { return pow(a, P - 2); }
+RK_HD uint32_t sbox7(uint32_t x) {
+    uint32_t x2 = mul(x, x);
+    uint32_t x3 = mul(x2, x);
+    uint32_t x6 = mul(x3, x3);
+    return mul(x6, x);
+}
+
+struct Ext {
+    uint32_t c[4];
+};
+RK_HD Ext ext_zero() { return Ext{{0, 0, 0, 0}}; }
+RK_HD Ext ext_one() { return Ext{{ONE, 0, 0, 0}}; }
+RK_HD Ext ext_from(uint32_t a) { return Ext{{a, 0, 0, 0}}; }
+RK_HD Ext add(const Ext& a, const Ext& b) {
+    return Ext{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}};
+}
+RK_HD Ext sub(const Ext& a, const Ext& b) {
+    return Ext{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
+}
+RK_HD Ext scale(const Ext& a, uint32_t s) {
+    return Ext{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}};
+}
+RK_HD bool eq(const Ext& a, const Ext& b) {
+    return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
+}
+// schoolbook product folded through x^4 = -11
+RK_HD Ext mul(const Ext& a, const Ext& b) {
+    constexpr uint32_t NBETA = 1073741848u;  // Montgomery form of p - 11
+    uint32_t h0 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
+    uint32_t h1 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
+    uint32_t h2 = mul(a.c[3], b.c[3]);
+    Ext r;
+    r.c[0] = add(mul(a.c[0], b.c[0]), mul(NBETA, h0));
+    r.c[1] = add(add(mul(a.c[0], b.c[1]), mul(a.c[1], b.c[0])), mul(NBETA, h1));
+    r.c[2] = add(add(add(mul(a.c[0], b.c[2]), mul(a.c[1], b.c[1])), mul(a.c[2], b.c[0])), mul(NBETA, h2));
+    r.c[3] = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
+    return r;
+}
+RK_HD Ext pow(Ext a, uint64_t e) {
+    Ext r = ext_one();
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+// a^-1 via the norm to the quadratic subfield Fp[x^2]: for a = a0 + a1 x with
+// a0 = (c0 + c2 y), a1 = (c1 + c3 y), y = x^2, y^2 = -11:
+//   a * (a0 - a1 x) = a0^2 - a1^2 y =: n = n0 + n1 y in Fp[y]
+//   n * (n0 - n1 y) = n0^2 + 11 n1^2 in Fp
+RK_HD Ext inv(const Ext& a) {
+    const uint32_t B11 = encode(11);
+    // a0^2 = (c0^2 - 11 c2^2) + 2 c0 c2 y ; a1^2 y = (c1 + c3 y)^2 y = (c1^2 - 11 c3^2) y + 2 c1 c3 y^2
+    uint32_t a0sq0 = sub(mul(a.c[0], a.c[0]), mul(B11, mul(a.c[2], a.c[2])));
+    uint32_t a0sq1 = dbl(mul(a.c[0], a.c[2]));
+    uint32_t a1sq0 = sub(mul(a.c[1], a.c[1]), mul(B11, mul(a.c[3], a.c[3])));
+    uint32_t a1sq1 = dbl(mul(a.c[1], a.c[3]));
+    // n = a0^2 - y*a1^2 = (a0sq0 + 11*a1sq1) + (a0sq1 - a1sq0) y
+    uint32_t n0 = add(a0sq0, mul(B11, a1sq1));
+    uint32_t n1 = sub(a0sq1, a1sq0);
+    uint32_t d = add(mul(n0, n0), mul(B11, mul(n1, n1)));
+    uint32_t di = inv(d);
+    // n^-1 = (n0 - n1 y) / d ; a^-1 = (a0 - a1 x) * n^-1
+    uint32_t m0 = mul(n0, di), m1 = neg(mul(n1, di));
+    // (a0 - a1 x) as Ext: (c0, -c1, c2, -c3); times (m0 + m1 y) = (m0, 0, m1, 0)
+    Ext conj{{a.c[0], neg(a.c[1]), a.c[2], neg(a.c[3])}};
+    Ext m{{m0, 0, m1, 0}};
+    return mul(conj, m);
+}
+
+RK_HD uint32_t bitrev(uint32_t x, unsigned bits) {
+    if (bits == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x) >> (32 - bits);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+    x = (x >> 16) | (x << 16);
+    return x >> (32 - bits);
+#endif
+}
+
+}  // namespace bb

@@ -1,0 +1,212 @@
+// Context, device memory and table management + the plain C entry points for them.
+#include "internal.hpp"
+#include "poseidon2_consts.inc"
+
+#include <cstring>
+
+namespace rk {
+
+int post_launch(rk_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+        return RK_ERR_HIP;
+    }
+    return RK_OK;
+}
+
+int dev_alloc(rk_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->free_list.find(bytes);
+    if (it != ctx->free_list.end()) {
+        *out = it->second;
+        ctx->free_list.erase(it);
+        ctx->live[*out] = bytes;
+        return RK_OK;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
+        ctx->free_list.clear();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+            return RK_ERR_NOMEM;
+        }
+    }
+    ctx->live[p] = bytes;
+    *out = p;
+    return RK_OK;
+}
+int dev_free(rk_ctx* ctx, void* p) {
+    if (!p) return RK_OK;
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) return RK_ERR_INVALID;
+    ctx->free_list.emplace(it->second, p);
+    ctx->live.erase(it);
+    return RK_OK;
+}
+int scratch(rk_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->scratch_bytes) {
+        // stream-ordered users of the old buffer must finish before it is released
+        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) RK_HIP_TRY(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        size_t nb = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+        RK_HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, nb));
+        ctx->scratch_bytes = nb;
+    }
+    *out = ctx->d_scratch;
+    return RK_OK;
+}
+
+static int build_tables(rk_ctx* ctx) {
+    const ntt::TableLayout l = ntt::table_layout();
+    std::vector<uint32_t> h(l.total);
+    ntt::fill_tables(h.data());
+    RK_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tables, l.total * sizeof(uint32_t)));
+    RK_HIP_TRY(ctx, hipMemcpy(ctx->d_tables, h.data(), l.total * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->tb = ntt::tables_at(ctx->d_tables);
+    return RK_OK;
+}
+
+}  // namespace rk
+
+extern "C" {
+
+int rk_abi_version(void) { return 1; }
+
+const char* rk_strerror(int s) {
+    switch (s) {
+        case RK_OK: return "ok";
+        case RK_ERR_INVALID: return "invalid argument";
+        case RK_ERR_HIP: return "HIP runtime error";
+        case RK_ERR_NOMEM: return "out of device memory";
+        case RK_ERR_NODEVICE: return "no usable GPU";
+        case RK_ERR_CAPACITY: return "output buffer too small";
+        case RK_ERR_INTERNAL: return "prover invariant violated";
+        default: return "unknown status";
+    }
+}
+const char* rk_last_error(rk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int rk_device_count(int* count) {
+    if (!count) return RK_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return RK_ERR_NODEVICE;
+    }
+    *count = n;
+    return RK_OK;
+}
+
+int rk_ctx_create(int device, void* stream, rk_ctx** out) {
+    if (!out) return RK_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RK_ERR_NODEVICE;
+    if (device < 0 || device >= n) return RK_ERR_INVALID;
+    rk_ctx* ctx = new rk_ctx();
+    ctx->device = device;
+    int st = RK_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { st = RK_ERR_NODEVICE; break; }
+        if (stream) {
+            ctx->stream = (hipStream_t)stream;
+        } else {
+            if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = RK_ERR_HIP; break; }
+            ctx->own_stream = true;
+        }
+        st = rk::build_tables(ctx);
+        if (st != RK_OK) break;
+        std::memcpy(ctx->h_p2.rc_ext, P2_RC_EXT_MONT, sizeof ctx->h_p2.rc_ext);
+        std::memcpy(ctx->h_p2.rc_int, P2_RC_INT_MONT, sizeof ctx->h_p2.rc_int);
+        std::memcpy(ctx->h_p2.diag, P2_INT_DIAG_MONT, sizeof ctx->h_p2.diag);
+        if (hipMalloc((void**)&ctx->d_p2, sizeof(p2::Consts)) != hipSuccess) { st = RK_ERR_NOMEM; break; }
+        if (hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice) != hipSuccess) {
+            st = RK_ERR_HIP;
+            break;
+        }
+    } while (0);
+    if (st != RK_OK) {
+        rk_ctx_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return RK_OK;
+}
+
+int rk_ctx_destroy(rk_ctx* ctx) {
+    if (!ctx) return RK_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
+    for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_p2) (void)hipFree(ctx->d_p2);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RK_OK;
+}
+
+int rk_sync(rk_ctx* ctx) {
+    if (!ctx) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+int rk_alloc(rk_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::dev_alloc(ctx, bytes, d_ptr);
+}
+int rk_free(rk_ctx* ctx, void* d_ptr) {
+    if (!ctx) return RK_ERR_INVALID;
+    // the block may still be in use by queued work on the stream
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return rk::dev_free(ctx, d_ptr);
+}
+int rk_h2d(rk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (!d_dst && bytes) || (!h_src && bytes)) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+int rk_d2h(rk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (!h_dst && bytes) || (!d_src && bytes)) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RK_HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+
+int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t* rc_int, const uint32_t* diag) {
+    if (!ctx || !rc_ext || !rc_int || !diag) return RK_ERR_INVALID;
+    for (size_t i = 0; i < sizeof ctx->h_p2.rc_ext / 4; i++)
+        if (rc_ext[i] >= bb::P) return RK_ERR_INVALID;
+    for (int i = 0; i < p2::ROUNDS_PARTIAL; i++)
+        if (rc_int[i] >= bb::P) return RK_ERR_INVALID;
+    for (int i = 0; i < p2::CELLS; i++)
+        if (diag[i] >= bb::P) return RK_ERR_INVALID;
+    std::memcpy(ctx->h_p2.rc_ext, rc_ext, sizeof ctx->h_p2.rc_ext);
+    std::memcpy(ctx->h_p2.rc_int, rc_int, sizeof ctx->h_p2.rc_int);
+    std::memcpy(ctx->h_p2.diag, diag, sizeof ctx->h_p2.diag);
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RK_HIP_TRY(ctx, hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice));
+    return RK_OK;
+}
+
+int rk_last_timing(rk_ctx* ctx, rk_timing* out) {
+    if (!ctx || !out) return RK_ERR_INVALID;
+    *out = ctx->timing;
+    return RK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Internal declarations shared by the translation units of libraiko_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/raiko_hip.h"
+#include "bb.hpp"
+#include "ntt_core.hpp"
+#include "poseidon2_core.hpp"
+
+struct rk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+
+    // twiddle / power tables (one device allocation)
+    uint32_t* d_tables = nullptr;
+    ntt::Tables tb{};
+
+    // Poseidon2 constants: host copy for the transcript, device copy for kernels
+    p2::Consts h_p2{};
+    p2::Consts* d_p2 = nullptr;
+
+    // caching allocator (exact-size free lists) so steady-state proving never calls hipMalloc
+    std::multimap<size_t, void*> free_list;
+    std::unordered_map<void*, size_t> live;
+
+    // small staging area for per-call parameter uploads
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    rk_timing timing{};
+};
+
+#define RK_HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);              \
+            return RK_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+#define RK_TRY(expr)                \
+    do {                            \
+        int _s = (expr);            \
+        if (_s != RK_OK) return _s; \
+    } while (0)
+
+static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static inline unsigned log2u(size_t n) {
+    unsigned k = 0;
+    while (((size_t)1 << k) < n) k++;
+    return k;
+}
+
+namespace rk {
+
+// memory (context.hip)
+int dev_alloc(rk_ctx* ctx, size_t bytes, void** out);
+int dev_free(rk_ctx* ctx, void* p);
+int scratch(rk_ctx* ctx, size_t bytes, void** out);  // valid until the next scratch() call
+int post_launch(rk_ctx* ctx, const char* what);
+
+// NTT (kernels_ntt.hip)
+int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fuse_zk_shift);
+int ntt_forward(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_size, size_t count,
+                unsigned expand_bits);
+int zk_shift(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count);
+int bit_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count);
+
+// hashing (kernels_hash.hip)
+int hash_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_matrix, size_t rows, size_t cols);
+int hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t output_size);
+int merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols);
+
+// polynomial / elementwise (kernels_poly.hip)
+int eltwise_add(rk_ctx* ctx, uint32_t* d_out, const uint32_t* a, const uint32_t* b, size_t n);
+int eltwise_sum_ext(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add);
+int eltwise_zeroize(rk_ctx* ctx, uint32_t* d_io, size_t n);
+int fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const bb::Ext& mix);
+int gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
+// rows: d_dst[q*cols + c] = d_matrix[c*rows + h_idx[q]]
+int gather_rows(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_matrix, size_t rows, size_t cols,
+                const uint32_t* d_idx, size_t n_idx);
+// digests: d_dst[i] = d_nodes[d_idx[i]]
+int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const uint32_t* d_idx, size_t n_idx);
+int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n);
+// d_out_ext[e] = sum_k coeffs[which[e]*size + k] * pw[pw_sel[e]*size + k]
+int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t size, const uint32_t* d_which,
+             const uint32_t* d_pw_ext, const uint32_t* d_pw_sel, size_t eval_count);
+int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, const bb::Ext& mix,
+                    const uint32_t* d_in, const uint32_t* h_combos, size_t input_size, size_t count);
+int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& z, bb::Ext* h_rem);
+// d_ext[idx[i]] -= delta[i]
+int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n);
+
+}  // namespace rk

@@ -1,0 +1,104 @@
+// Poseidon2 row hashing and Merkle folds (Hal::hash_rows / Hal::hash_fold and
+// MerkleTreeProver::new of risc0-zkp 1.0.1).  Integer-ALU-bound: one lane owns one
+// sponge (24 state words in VGPRs), consecutive lanes own consecutive rows so every
+// column load is a coalesced 256-byte wave access of the column-major matrix.
+#include "internal.hpp"
+
+namespace {
+
+constexpr int HASH_BLOCK = 256;
+
+__global__ __launch_bounds__(HASH_BLOCK) void hash_rows_kernel(uint32_t* __restrict__ out,
+                                                               const uint32_t* __restrict__ matrix, size_t rows,
+                                                               size_t cols, const p2::Consts* __restrict__ kc) {
+    size_t row = (size_t)blockIdx.x * HASH_BLOCK + threadIdx.x;
+    if (row >= rows) return;
+    const p2::Consts& k = *kc;
+    uint32_t s[p2::CELLS];
+#pragma unroll
+    for (int i = 0; i < p2::CELLS; i++) s[i] = 0;
+    size_t full = cols / p2::RATE;
+    const uint32_t* src = matrix + row;
+    for (size_t b = 0; b < full; b++) {
+#pragma unroll
+        for (int i = 0; i < p2::RATE; i++) s[i] = src[(b * p2::RATE + i) * rows];
+        p2::permute(s, k);
+    }
+    size_t rem = cols - full * p2::RATE;
+    if (rem != 0 || cols == 0) {
+#pragma unroll
+        for (int i = 0; i < p2::RATE; i++) s[i] = (size_t)i < rem ? src[(full * p2::RATE + i) * rows] : 0u;
+        p2::permute(s, k);
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + row * p2::OUT);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// nodes[out_size + i] = H(nodes[2*(out_size+i)] || nodes[2*(out_size+i)+1])
+__global__ __launch_bounds__(HASH_BLOCK) void hash_fold_kernel(uint32_t* __restrict__ nodes, size_t out_size,
+                                                               const p2::Consts* __restrict__ kc) {
+    size_t i = (size_t)blockIdx.x * HASH_BLOCK + threadIdx.x;
+    if (i >= out_size) return;
+    const p2::Consts& k = *kc;
+    size_t idx = out_size + i;
+    const uint4* in = reinterpret_cast<const uint4*>(nodes + 2 * idx * p2::OUT);
+    uint4 a = in[0], b = in[1], c = in[2], d = in[3];
+    uint32_t s[p2::CELLS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w,
+                             d.x, d.y, d.z, d.w, 0,   0,   0,   0,   0,   0,   0,   0};
+    p2::permute(s, k);
+    uint4* o = reinterpret_cast<uint4*>(nodes + idx * p2::OUT);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+}  // namespace
+
+namespace rk {
+
+int hash_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_matrix, size_t rows, size_t cols) {
+    if (rows == 0) return RK_ERR_INVALID;
+    size_t blocks = (rows + HASH_BLOCK - 1) / HASH_BLOCK;
+    if (blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_out, d_matrix, rows,
+                       cols, ctx->d_p2);
+    return post_launch(ctx, "hash_rows_kernel");
+}
+
+int hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t output_size) {
+    if (output_size == 0) return RK_ERR_INVALID;
+    size_t blocks = (output_size + HASH_BLOCK - 1) / HASH_BLOCK;
+    if (blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    hipLaunchKernelGGL(hash_fold_kernel, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_nodes, output_size,
+                       ctx->d_p2);
+    return post_launch(ctx, "hash_fold_kernel");
+}
+
+int merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols) {
+    if (!is_pow2(rows)) return RK_ERR_INVALID;
+    RK_TRY(hash_rows(ctx, d_nodes + rows * p2::OUT, d_matrix, rows, cols));
+    for (size_t layer = rows / 2; layer >= 1; layer /= 2) RK_TRY(hash_fold(ctx, d_nodes, layer));
+    return RK_OK;
+}
+
+}  // namespace rk
+
+extern "C" {
+
+int rk_hash_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_matrix, size_t rows, size_t cols) {
+    if (!ctx || !d_out || (!d_matrix && cols)) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::hash_rows(ctx, d_out, d_matrix, rows, cols);
+}
+int rk_hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t input_size, size_t output_size) {
+    if (!ctx || !d_nodes || input_size != 2 * output_size) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::hash_fold(ctx, d_nodes, output_size);
+}
+int rk_merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols) {
+    if (!ctx || !d_nodes || !d_matrix) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::merkle_build(ctx, d_nodes, d_matrix, rows, cols);
+}
+
+}  // extern "C"

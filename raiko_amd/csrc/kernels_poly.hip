@@ -1,0 +1,498 @@
+// Polynomial / element-wise operators of the Hal trait (risc0-zkp 1.0.1 hal/mod.rs):
+// eltwise_*, fri_fold, gather_sample, batch_evaluate_any, mix_poly_coeffs, plus the
+// device form of core/poly.rs poly_divide.  All are HBM-bound streaming kernels:
+// one lane per coefficient index, consecutive lanes on consecutive addresses.
+#include "internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+using bb::Ext;
+constexpr int TPB = 256;
+
+inline unsigned grid_for(size_t n, unsigned cap = 16384) {
+    size_t b = (n + TPB - 1) / TPB;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+__device__ __forceinline__ Ext load_ext(const uint32_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return Ext{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void store_ext(uint32_t* p, const Ext& e) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]);
+}
+
+__global__ void add_kernel(uint32_t* out, const uint32_t* a, const uint32_t* b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) out[i] = bb::add(a[i], b[i]);
+}
+__global__ void zeroize_kernel(uint32_t* io, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st)
+        if (io[i] == bb::INVALID) io[i] = 0;
+}
+__global__ void sum_ext_kernel(uint32_t* out, const uint32_t* in, size_t count, size_t to_add) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += st) {
+        Ext tot = bb::ext_zero();
+        for (size_t j = 0; j < to_add; j++) tot = bb::add(tot, load_ext(in + (j * count + i) * 4));
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[(size_t)k * count + i] = tot.c[k];
+    }
+}
+
+struct FoldPows {
+    Ext p[16];
+};
+__global__ void fri_fold_kernel(uint32_t* out, const uint32_t* in, size_t count, FoldPows pw) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; idx < count; idx += st) {
+        Ext tot = bb::ext_zero();
+#pragma unroll
+        for (unsigned i = 0; i < 16; i++) {
+            unsigned rev_i = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+            size_t ri = (size_t)rev_i * count + idx;
+            Ext f{{in[ri], in[count * 16 + ri], in[count * 32 + ri], in[count * 48 + ri]}};
+            tot = bb::add(tot, bb::mul(pw.p[i], f));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[(size_t)k * count + idx] = tot.c[k];
+    }
+}
+
+__global__ void gather_sample_kernel(uint32_t* dst, const uint32_t* src, size_t idx, size_t size, size_t stride) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; g < size; g += st) dst[g] = src[g * stride + idx];
+}
+__global__ void gather_rows_kernel(uint32_t* dst, const uint32_t* matrix, size_t rows, size_t cols,
+                                   const uint32_t* idx) {
+    size_t q = blockIdx.y;
+    size_t r = idx[q];
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (size_t)gridDim.x * blockDim.x)
+        dst[q * cols + c] = matrix[c * rows + r];
+}
+__global__ void gather_digests_kernel(uint32_t* dst, const uint32_t* nodes, const uint32_t* idx, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 8) return;
+    dst[i] = nodes[(size_t)idx[i >> 3] * 8 + (i & 7)];
+}
+
+// pw[k] = x^k: each lane seeds x^(lane_start) by square-and-multiply, then walks CH powers
+constexpr int PW_CH = 32;
+__global__ void ext_powers_kernel(uint32_t* pw, Ext x, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t start = t * PW_CH;
+    if (start >= n) return;
+    Ext cur = bb::pow(x, (uint64_t)start);
+    size_t end = start + PW_CH < n ? start + PW_CH : n;
+    for (size_t k = start; k < end; k++) {
+        store_ext(pw + k * 4, cur);
+        cur = bb::mul(cur, x);
+    }
+}
+
+// partial[e][blk] = sum over this block's slice of coeffs[which[e]][k] * pw[sel[e]][k]
+constexpr int DOT_BLOCKS = 64;
+__global__ __launch_bounds__(TPB) void eval_dot_kernel(uint32_t* partial, const uint32_t* coeffs, size_t size,
+                                                       const uint32_t* which, const uint32_t* pw,
+                                                       const uint32_t* sel) {
+    __shared__ uint32_t red[TPB * 4];
+    size_t e = blockIdx.y;
+    const uint32_t* c = coeffs + (size_t)which[e] * size;
+    const uint32_t* p = pw + (size_t)sel[e] * size * 4;
+    Ext acc = bb::ext_zero();
+    for (size_t k = (size_t)blockIdx.x * TPB + threadIdx.x; k < size; k += (size_t)DOT_BLOCKS * TPB)
+        acc = bb::add(acc, bb::scale(load_ext(p + k * 4), c[k]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) red[threadIdx.x * 4 + j] = acc.c[j];
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                red[threadIdx.x * 4 + j] = bb::add(red[threadIdx.x * 4 + j], red[(threadIdx.x + s) * 4 + j]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[(e * DOT_BLOCKS + blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x];
+}
+__global__ void eval_reduce_kernel(uint32_t* out, const uint32_t* partial, size_t n_eval) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_eval * 4) return;
+    size_t e = i >> 2, j = i & 3;
+    uint32_t acc = 0;
+    for (int b = 0; b < DOT_BLOCKS; b++) acc = bb::add(acc, partial[(e * DOT_BLOCKS + b) * 4 + j]);
+    out[i] = acc;
+}
+
+// one grid.y slot per distinct combo: out[combo][idx] += sum_t pows[t] * in[cols[t]][idx]
+__global__ void mix_kernel(uint32_t* out, const uint32_t* in, size_t count, const uint32_t* slot_combo,
+                           const uint32_t* slot_off, const uint32_t* cols, const uint32_t* pows) {
+    unsigned slot = blockIdx.y;
+    size_t combo = slot_combo[slot];
+    unsigned t0 = slot_off[slot], t1 = slot_off[slot + 1];
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; idx < count; idx += st) {
+        uint32_t* o = out + (combo * count + idx) * 4;
+        Ext acc = load_ext(o);
+        for (unsigned t = t0; t < t1; t++) {
+            Ext pw = load_ext(pows + (size_t)t * 4);
+            acc = bb::add(acc, bb::scale(pw, in[(size_t)cols[t] * count + idx]));
+        }
+        store_ext(o, acc);
+    }
+}
+
+// ---- synthetic division by (x - z): q[i-1] = c[i] + z*q[i], chunked Horner ----
+constexpr int DIV_CH = 256;
+// tops[b] = sum_{k in chunk b} c[k] z^(k - start_b)
+__global__ void div_tops_kernel(uint32_t* tops, const uint32_t* poly, size_t count, Ext z) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t start = b * DIV_CH;
+    if (start >= count) return;
+    size_t end = start + DIV_CH < count ? start + DIV_CH : count;
+    Ext s = bb::ext_zero();
+    for (size_t k = end; k-- > start;) s = bb::add(bb::mul(s, z), load_ext(poly + k * 4));
+    store_ext(tops + b * 4, s);
+}
+// carry[b] = value of the running Horner state entering chunk b from above:
+// carry[b] = T[b+1], T[b] = tops[b] + zL * T[b+1], T[nchunks] = 0.  Single block, two-level.
+__global__ __launch_bounds__(TPB) void div_carry_kernel(uint32_t* carry, const uint32_t* tops, size_t nchunks, Ext zL,
+                                                        uint32_t* rem_out) {
+    __shared__ uint32_t seg_top[TPB * 4];
+    __shared__ uint32_t seg_in[TPB * 4];
+    size_t per = (nchunks + TPB - 1) / TPB;
+    size_t s0 = threadIdx.x * per, s1 = s0 + per < nchunks ? s0 + per : nchunks;
+    // local pass: value at the segment's first chunk assuming zero carry-in, and zL^(segment length)
+    Ext acc = bb::ext_zero();
+    if (s0 < nchunks)
+        for (size_t b = s1; b-- > s0;) acc = bb::add(bb::mul(acc, zL), load_ext(tops + b * 4));
+#pragma unroll
+    for (int j = 0; j < 4; j++) seg_top[threadIdx.x * 4 + j] = acc.c[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Ext zseg = bb::pow(zL, (uint64_t)per);
+        Ext run = bb::ext_zero();  // T at the start of segment t+1
+        for (int t = TPB - 1; t >= 0; t--) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) seg_in[t * 4 + j] = run.c[j];
+            size_t a0 = (size_t)t * per;
+            if (a0 >= nchunks) continue;
+            size_t a1 = a0 + per < nchunks ? a0 + per : nchunks;
+            Ext zs = (a1 - a0 == per) ? zseg : bb::pow(zL, (uint64_t)(a1 - a0));
+            Ext top{{seg_top[t * 4], seg_top[t * 4 + 1], seg_top[t * 4 + 2], seg_top[t * 4 + 3]}};
+            run = bb::add(top, bb::mul(zs, run));
+        }
+        // run == T[0] == sum_k c[k] z^k == remainder of the division
+        store_ext(rem_out, run);
+    }
+    __syncthreads();
+    if (s0 < nchunks) {
+        Ext run{{seg_in[threadIdx.x * 4], seg_in[threadIdx.x * 4 + 1], seg_in[threadIdx.x * 4 + 2],
+                 seg_in[threadIdx.x * 4 + 3]}};
+        for (size_t b = s1; b-- > s0;) {
+            store_ext(carry + b * 4, run);
+            run = bb::add(load_ext(tops + b * 4), bb::mul(zL, run));
+        }
+    }
+}
+// within chunk b: cur = carry[b]; for k from top: next = z*cur + c[k]; c[k] = cur; cur = next
+__global__ void div_apply_kernel(uint32_t* poly, const uint32_t* carry, size_t count, Ext z) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t start = b * DIV_CH;
+    if (start >= count) return;
+    size_t end = start + DIV_CH < count ? start + DIV_CH : count;
+    Ext cur = load_ext(carry + b * 4);
+    for (size_t k = end; k-- > start;) {
+        Ext next = bb::add(bb::mul(z, cur), load_ext(poly + k * 4));
+        store_ext(poly + k * 4, cur);
+        cur = next;
+    }
+}
+
+__global__ void ext_sub_at_kernel(uint32_t* data, const uint32_t* idx, const uint32_t* delta, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* p = data + (size_t)idx[i] * 4;
+    store_ext(p, bb::sub(load_ext(p), load_ext(delta + i * 4)));
+}
+
+}  // namespace
+
+namespace rk {
+
+int eltwise_add(rk_ctx* ctx, uint32_t* d_out, const uint32_t* a, const uint32_t* b, size_t n) {
+    if (n == 0) return RK_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(TPB), 0, ctx->stream, d_out, a, b, n);
+    return post_launch(ctx, "add_kernel");
+}
+int eltwise_zeroize(rk_ctx* ctx, uint32_t* d_io, size_t n) {
+    if (n == 0) return RK_OK;
+    hipLaunchKernelGGL(zeroize_kernel, dim3(grid_for(n)), dim3(TPB), 0, ctx->stream, d_io, n);
+    return post_launch(ctx, "zeroize_kernel");
+}
+int eltwise_sum_ext(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add) {
+    if (count == 0) return RK_OK;
+    hipLaunchKernelGGL(sum_ext_kernel, dim3(grid_for(count)), dim3(TPB), 0, ctx->stream, d_out, d_in, count, to_add);
+    return post_launch(ctx, "sum_ext_kernel");
+}
+int fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const bb::Ext& mix) {
+    if (out_count == 0) return RK_ERR_INVALID;
+    FoldPows pw;
+    pw.p[0] = bb::ext_one();
+    for (int i = 1; i < 16; i++) pw.p[i] = bb::mul(pw.p[i - 1], mix);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(out_count)), dim3(TPB), 0, ctx->stream, d_out, d_in, out_count, pw);
+    return post_launch(ctx, "fri_fold_kernel");
+}
+int gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {
+    if (size == 0) return RK_OK;
+    hipLaunchKernelGGL(gather_sample_kernel, dim3(grid_for(size)), dim3(TPB), 0, ctx->stream, d_dst, d_src, idx, size,
+                       stride);
+    return post_launch(ctx, "gather_sample_kernel");
+}
+int gather_rows(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_matrix, size_t rows, size_t cols,
+                const uint32_t* d_idx, size_t n_idx) {
+    if (n_idx == 0 || cols == 0) return RK_OK;
+    if (n_idx > 65535) return RK_ERR_INVALID;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(cols, 64), (unsigned)n_idx), dim3(TPB), 0, ctx->stream, d_dst,
+                       d_matrix, rows, cols, d_idx);
+    return post_launch(ctx, "gather_rows_kernel");
+}
+int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const uint32_t* d_idx, size_t n_idx) {
+    if (n_idx == 0) return RK_OK;
+    size_t n = n_idx * 8;
+    hipLaunchKernelGGL(gather_digests_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_dst,
+                       d_nodes, d_idx, n_idx);
+    return post_launch(ctx, "gather_digests_kernel");
+}
+int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n) {
+    if (n == 0) return RK_OK;
+    size_t lanes = (n + PW_CH - 1) / PW_CH;
+    hipLaunchKernelGGL(ext_powers_kernel, dim3((unsigned)((lanes + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_pw_ext,
+                       x, n);
+    return post_launch(ctx, "ext_powers_kernel");
+}
+int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t size, const uint32_t* d_which,
+             const uint32_t* d_pw_ext, const uint32_t* d_pw_sel, size_t eval_count) {
+    if (eval_count == 0) return RK_OK;
+    if (eval_count > 65535) return RK_ERR_INVALID;
+    void* partial = nullptr;
+    RK_TRY(dev_alloc(ctx, eval_count * DOT_BLOCKS * 16, &partial));
+    hipLaunchKernelGGL(eval_dot_kernel, dim3(DOT_BLOCKS, (unsigned)eval_count), dim3(TPB), 0, ctx->stream,
+                       (uint32_t*)partial, d_coeffs, size, d_which, d_pw_ext, d_pw_sel);
+    int st = post_launch(ctx, "eval_dot_kernel");
+    if (st == RK_OK) {
+        hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)((eval_count * 4 + TPB - 1) / TPB)), dim3(TPB), 0,
+                           ctx->stream, d_out_ext, (const uint32_t*)partial, eval_count);
+        st = post_launch(ctx, "eval_reduce_kernel");
+    }
+    // stream-ordered reuse: the block returns to this ctx's pool and any later user runs on the same stream
+    dev_free(ctx, partial);
+    return st;
+}
+
+int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, const bb::Ext& mix,
+                    const uint32_t* d_in, const uint32_t* h_combos, size_t input_size, size_t count) {
+    if (input_size == 0 || count == 0) return RK_OK;
+    // bucket the input columns by destination combo; each bucket is one grid.y slot
+    std::vector<uint32_t> order(input_size);
+    for (size_t i = 0; i < input_size; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_combos[a] < h_combos[b]; });
+    std::vector<bb::Ext> pw(input_size);
+    bb::Ext cur = mix_start;
+    for (size_t i = 0; i < input_size; i++) {
+        pw[i] = cur;
+        cur = bb::mul(cur, mix);
+    }
+    std::vector<uint32_t> slot_combo, slot_off, cols(input_size), pows(input_size * 4);
+    for (size_t t = 0; t < input_size; t++) {
+        uint32_t i = order[t];
+        if (t == 0 || h_combos[i] != h_combos[order[t - 1]]) {
+            slot_combo.push_back(h_combos[i]);
+            slot_off.push_back((uint32_t)t);
+        }
+        cols[t] = i;
+        std::memcpy(&pows[t * 4], pw[i].c, 16);
+    }
+    slot_off.push_back((uint32_t)input_size);
+    size_t n_slots = slot_combo.size();
+    // pack: [slot_combo | slot_off | cols | pows(16B aligned)]
+    size_t o_combo = 0, o_off = o_combo + n_slots, o_cols = o_off + n_slots + 1;
+    size_t o_pows = (o_cols + input_size + 3) & ~(size_t)3;
+    size_t words = o_pows + input_size * 4;
+    std::vector<uint32_t> pack(words, 0);
+    std::memcpy(&pack[o_combo], slot_combo.data(), n_slots * 4);
+    std::memcpy(&pack[o_off], slot_off.data(), (n_slots + 1) * 4);
+    std::memcpy(&pack[o_cols], cols.data(), input_size * 4);
+    std::memcpy(&pack[o_pows], pows.data(), input_size * 16);
+    void* d = nullptr;
+    RK_TRY(scratch(ctx, words * 4, &d));
+    // the previous user of the scratch area may still be running: pageable H2D on the same stream is ordered
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack is a stack-lifetime host buffer
+    const uint32_t* dp = (const uint32_t*)d;
+    hipLaunchKernelGGL(mix_kernel, dim3(grid_for(count, 4096), (unsigned)n_slots), dim3(TPB), 0, ctx->stream, d_out_ext,
+                       d_in, count, dp + o_combo, dp + o_off, dp + o_cols, dp + o_pows);
+    return post_launch(ctx, "mix_kernel");
+}
+
+int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& z, bb::Ext* h_rem) {
+    if (count == 0) return RK_ERR_INVALID;
+    size_t nchunks = (count + DIV_CH - 1) / DIV_CH;
+    void* buf = nullptr;
+    RK_TRY(dev_alloc(ctx, (2 * nchunks + 1) * 16, &buf));
+    uint32_t* tops = (uint32_t*)buf;
+    uint32_t* carry = tops + nchunks * 4;
+    uint32_t* rem = carry + nchunks * 4;
+    bb::Ext zL = bb::pow(z, (uint64_t)DIV_CH);
+    unsigned blocks = (unsigned)((nchunks + TPB - 1) / TPB);
+    hipLaunchKernelGGL(div_tops_kernel, dim3(blocks), dim3(TPB), 0, ctx->stream, tops, d_poly_ext, count, z);
+    int st = post_launch(ctx, "div_tops_kernel");
+    if (st == RK_OK) {
+        hipLaunchKernelGGL(div_carry_kernel, dim3(1), dim3(TPB), 0, ctx->stream, carry, tops, nchunks, zL, rem);
+        st = post_launch(ctx, "div_carry_kernel");
+    }
+    if (st == RK_OK) {
+        hipLaunchKernelGGL(div_apply_kernel, dim3(blocks), dim3(TPB), 0, ctx->stream, d_poly_ext, carry, count, z);
+        st = post_launch(ctx, "div_apply_kernel");
+    }
+    if (st == RK_OK && h_rem) {
+        hipError_t e = hipMemcpyAsync(h_rem, rem, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("poly_divide d2h: ") + hipGetErrorString(e);
+            st = RK_ERR_HIP;
+        }
+    }
+    dev_free(ctx, buf);
+    return st;
+}
+
+int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n) {
+    if (n == 0) return RK_OK;
+    size_t o_delta = (n + 3) & ~(size_t)3;
+    std::vector<uint32_t> pack(o_delta + n * 4);
+    std::memcpy(pack.data(), h_idx, n * 4);
+    std::memcpy(&pack[o_delta], h_delta, n * 16);
+    void* d = nullptr;
+    RK_TRY(scratch(ctx, pack.size() * 4, &d));
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t* dp = (const uint32_t*)d;
+    hipLaunchKernelGGL(ext_sub_at_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_ext, dp,
+                       dp + o_delta, n);
+    return post_launch(ctx, "ext_sub_at_kernel");
+}
+
+}  // namespace rk
+
+extern "C" {
+
+int rk_eltwise_add_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n) {
+    if (!ctx || (n && (!d_out || !d_a || !d_b))) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::eltwise_add(ctx, d_out, d_a, d_b, n);
+}
+int rk_eltwise_sum_extelem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in_ext, size_t count, size_t to_add) {
+    if (!ctx || (count && (!d_out || !d_in_ext))) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::eltwise_sum_ext(ctx, d_out, d_in_ext, count, to_add);
+}
+int rk_eltwise_copy_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n) {
+    if (!ctx || (n && (!d_out || !d_in))) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n)
+        RK_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return RK_OK;
+}
+int rk_eltwise_zeroize_elem(rk_ctx* ctx, uint32_t* d_io, size_t n) {
+    if (!ctx || (n && !d_io)) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::eltwise_zeroize(ctx, d_io, n);
+}
+int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const uint32_t mix[4]) {
+    if (!ctx || !d_out || !d_in || !mix) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bb::Ext m{{mix[0], mix[1], mix[2], mix[3]}};
+    return rk::fri_fold(ctx, d_out, d_in, out_count, m);
+}
+int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {
+    if (!ctx || (size && (!d_dst || !d_src))) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::gather_sample(ctx, d_dst, d_src, idx, size, stride);
+}
+
+int rk_batch_evaluate_any(rk_ctx* ctx, const uint32_t* d_coeffs, size_t poly_count, size_t size,
+                          const uint32_t* h_which, const uint32_t* h_xs, size_t eval_count, uint32_t* h_out) {
+    if (!ctx || !d_coeffs || !is_pow2(size)) return RK_ERR_INVALID;
+    if (eval_count == 0) return RK_OK;
+    if (!h_which || !h_xs || !h_out) return RK_ERR_INVALID;
+    for (size_t e = 0; e < eval_count; e++)
+        if (h_which[e] >= poly_count) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // distinct evaluation points share one device table of powers
+    std::vector<bb::Ext> pts;
+    std::vector<uint32_t> sel(eval_count);
+    for (size_t e = 0; e < eval_count; e++) {
+        bb::Ext x{{h_xs[e * 4], h_xs[e * 4 + 1], h_xs[e * 4 + 2], h_xs[e * 4 + 3]}};
+        size_t j = 0;
+        for (; j < pts.size(); j++)
+            if (bb::eq(pts[j], x)) break;
+        if (j == pts.size()) pts.push_back(x);
+        sel[e] = (uint32_t)j;
+    }
+    void *d_pw = nullptr, *d_small = nullptr;
+    RK_TRY(rk::dev_alloc(ctx, pts.size() * size * 16, &d_pw));
+    int st = rk::dev_alloc(ctx, eval_count * (4 + 4 + 16) + 32, &d_small);
+    if (st != RK_OK) {
+        rk::dev_free(ctx, d_pw);
+        return st;
+    }
+    uint32_t* d_which = (uint32_t*)d_small;
+    uint32_t* d_sel = d_which + eval_count;
+    uint32_t* d_out = d_sel + eval_count;
+    // keep d_out 16-byte aligned
+    if (((uintptr_t)d_out & 15) != 0) d_out += (16 - ((uintptr_t)d_out & 15)) / 4;
+    do {
+        hipError_t e1 = hipMemcpyAsync(d_which, h_which, eval_count * 4, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e2 = hipMemcpyAsync(d_sel, sel.data(), eval_count * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e1 != hipSuccess || e2 != hipSuccess) { st = RK_ERR_HIP; ctx->last_error = "evaluate_any h2d"; break; }
+        for (size_t j = 0; j < pts.size() && st == RK_OK; j++)
+            st = rk::ext_powers(ctx, (uint32_t*)d_pw + j * size * 4, pts[j], size);
+        if (st != RK_OK) break;
+        st = rk::eval_dot(ctx, d_out, d_coeffs, size, d_which, (const uint32_t*)d_pw, d_sel, eval_count);
+        if (st != RK_OK) break;
+        hipError_t e3 = hipMemcpyAsync(h_out, d_out, eval_count * 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
+        if (e3 != hipSuccess) { st = RK_ERR_HIP; ctx->last_error = "evaluate_any d2h"; }
+    } while (0);
+    if (st != RK_OK) (void)hipStreamSynchronize(ctx->stream);
+    rk::dev_free(ctx, d_small);
+    rk::dev_free(ctx, d_pw);
+    return st;
+}
+
+int rk_mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t mix_start[4], const uint32_t mix[4],
+                       const uint32_t* d_in, const uint32_t* h_combos, size_t input_size, size_t count) {
+    if (!ctx || !d_out_ext || !d_in || !h_combos || !mix_start || !mix) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bb::Ext ms{{mix_start[0], mix_start[1], mix_start[2], mix_start[3]}};
+    bb::Ext mx{{mix[0], mix[1], mix[2], mix[3]}};
+    return rk::mix_poly_coeffs(ctx, d_out_ext, ms, mx, d_in, h_combos, input_size, count);
+}
+
+int rk_poly_divide(rk_ctx* ctx, uint32_t* d_polys_ext, size_t count, const uint32_t z[4], uint32_t* h_rem) {
+    if (!ctx || !d_polys_ext || !z || count == 0) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bb::Ext zz{{z[0], z[1], z[2], z[3]}};
+    bb::Ext rem;
+    RK_TRY(rk::poly_divide(ctx, d_polys_ext, count, zz, &rem));
+    if (h_rem) std::memcpy(h_rem, rem.c, 16);
+    return RK_OK;
+}
+
+}  // extern "C"

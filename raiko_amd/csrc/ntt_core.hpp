@@ -1,0 +1,268 @@
+// Tiled radix-2 NTT passes for BabyBear columns (gfx950: one workgroup stages a
+// 2^g x T tile of one column in LDS, runs g butterfly stages there, and applies
+// the four-step twiddle on the way in/out, so each pass reads and writes every
+// element exactly once from HBM).
+//
+// Conventions follow the published risc0 NTT (risc0-zkp core/ntt.rs, behind the
+// call at reference provers/risc0/driver/src/bonsai.rs:271):
+//   interpolate: natural-order evaluations -> bit-reversed coefficients,
+//                decimation in frequency with inverse roots, scaled by 1/n;
+//   evaluate:    bit-reversed coefficients -> natural-order evaluations,
+//                decimation in time with forward roots; the lowest expand_bits
+//                stages of a zero-padded input are a broadcast.
+//
+// The phase functions are RK_HD so tests can run them lane by lane on the CPU
+// (tests/emul/emul.cpp) -- the GPU kernel in kernels_ntt.hip is the same code
+// with __syncthreads() between phases.
+#pragma once
+#include "bb.hpp"
+
+namespace ntt {
+
+constexpr unsigned KS = 14;       // log2 of the in-LDS twiddle table order
+constexpr unsigned LAMBDA = 24;   // log2 of the largest supported transform
+constexpr unsigned TW_SPLIT = 12; // two-level table split for order-2^LAMBDA roots
+constexpr unsigned MAX_TILE_LOG = 14;  // 2^14 elements = 64 KiB of LDS
+
+struct Tables {
+    // [0] = forward roots, [1] = inverse roots
+    const uint32_t* small[2];  // w_{2^KS}^{+-j}, j < 2^(KS-1)
+    const uint32_t* hi[2];     // W^{+-(a << TW_SPLIT)}, W = w_{2^LAMBDA}, a < 2^(LAMBDA-TW_SPLIT)
+    const uint32_t* lo[2];     // W^{+-b}, b < 2^TW_SPLIT
+    const uint32_t* pow3_hi;   // 3^(a << TW_SPLIT)
+    const uint32_t* pow3_lo;   // 3^b
+};
+
+struct PassArgs {
+    uint32_t* dst;
+    const uint32_t* src;   // == dst except for the expanding first forward pass
+    size_t n;              // elements per column in dst
+    size_t n_src;          // elements per column in src
+    unsigned mu;           // log2 sub-problem size
+    unsigned g;            // stages in this pass
+    unsigned logT;         // log2 tile width (adjacent sub-problem positions)
+    unsigned expand_bits;  // forward first pass only
+    uint32_t scale;        // reverse last pass: Montgomery form of 1/n, else 0 (= skip)
+    unsigned zk_bits;      // reverse last pass fused zk-shift: log2 n, else 0 (= skip)
+};
+
+RK_HD uint32_t root_pow(const Tables& t, int dir, uint32_t e24) {
+    // W^(+-e24), e24 < 2^LAMBDA
+    uint32_t h = t.hi[dir][e24 >> TW_SPLIT];
+    uint32_t l = t.lo[dir][e24 & ((1u << TW_SPLIT) - 1)];
+    return bb::mul(h, l);
+}
+RK_HD uint32_t pow3(const Tables& t, uint32_t e) {
+    return bb::mul(t.pow3_hi[e >> TW_SPLIT], t.pow3_lo[e & ((1u << TW_SPLIT) - 1)]);
+}
+
+struct Tile {
+    size_t base;     // element offset of (hi=0, lo=0) inside dst
+    size_t src_base; // element offset inside src (expand pass)
+    uint32_t lo0;    // first sub-problem position covered by the tile
+    size_t S;        // stride between consecutive hi
+};
+// blocks are numbered column-major: block = col * blocks_per_col + b
+RK_HD Tile tile_of(const PassArgs& a, size_t block) {
+    size_t tile_elems = (size_t)1 << (a.g + a.logT);
+    size_t per_col = a.n >> (a.g + a.logT);
+    size_t col = block / per_col, b = block % per_col;
+    size_t S = ((size_t)1 << a.mu) >> a.g;
+    size_t tiles_per_sub = S >> a.logT;
+    size_t sp = b / tiles_per_sub, ti = b % tiles_per_sub;
+    Tile t;
+    t.S = S;
+    t.lo0 = (uint32_t)(ti << a.logT);
+    t.base = col * a.n + (sp << a.mu) + t.lo0;
+    t.src_base = col * a.n_src + ((b * tile_elems) >> a.expand_bits);
+    return t;
+}
+
+// ---------------------------------------------------------------- reverse (DIF)
+RK_HD void rev_load(const PassArgs& a, const Tile& t, uint32_t* lds, unsigned tid, unsigned nthr) {
+    unsigned elems = 1u << (a.g + a.logT), tmask = (1u << a.logT) - 1;
+    for (unsigned e = tid; e < elems; e += nthr) {
+        unsigned hi = e >> a.logT, lo = e & tmask;
+        lds[e] = a.src[t.base + (size_t)hi * t.S + lo];
+    }
+}
+RK_HD void rev_stage(const PassArgs& a, const Tables& tb, uint32_t* lds, unsigned tid, unsigned nthr, unsigned s) {
+    unsigned nb = 1u << (a.g - 1 + a.logT), tmask = (1u << a.logT) - 1;
+    unsigned hlog = a.g - 1 - s, half = 1u << hlog;
+    for (unsigned b = tid; b < nb; b += nthr) {
+        unsigned lo = b & tmask, hb = b >> a.logT;
+        unsigned j = hb & (half - 1), blk = hb >> hlog;
+        unsigned i0 = (((blk << (hlog + 1)) + j) << a.logT) + lo;
+        unsigned i1 = i0 + (half << a.logT);
+        uint32_t x = lds[i0], y = lds[i1];
+        lds[i0] = bb::add(x, y);
+        lds[i1] = bb::mul(bb::sub(x, y), tb.small[1][j << (s + KS - a.g)]);
+    }
+}
+RK_HD void rev_store(const PassArgs& a, const Tables& tb, const Tile& t, const uint32_t* lds, unsigned tid,
+                     unsigned nthr) {
+    unsigned elems = 1u << (a.g + a.logT), tmask = (1u << a.logT) - 1;
+    bool tw = t.S > 1;
+    for (unsigned e = tid; e < elems; e += nthr) {
+        unsigned p1 = e >> a.logT, lo = e & tmask;
+        uint32_t v = lds[e];
+        if (tw) {
+            uint32_t k1 = bb::bitrev(p1, a.g);
+            uint32_t ex = ((t.lo0 + lo) * k1) << (LAMBDA - a.mu);
+            v = bb::mul(v, root_pow(tb, 1, ex));
+        }
+        size_t pos = t.base + (size_t)p1 * t.S + lo;
+        if (a.scale) {
+            uint32_t f = a.scale;
+            if (a.zk_bits) {
+                uint32_t within = (uint32_t)(pos & (a.n - 1));
+                f = bb::mul(f, pow3(tb, bb::bitrev(within, a.zk_bits)));
+            }
+            v = bb::mul(v, f);
+        }
+        a.dst[pos] = v;
+    }
+}
+
+// ---------------------------------------------------------------- forward (DIT)
+RK_HD void fwd_load(const PassArgs& a, const Tables& tb, const Tile& t, uint32_t* lds, unsigned tid, unsigned nthr) {
+    unsigned elems = 1u << (a.g + a.logT), tmask = (1u << a.logT) - 1;
+    bool tw = t.S > 1;
+    for (unsigned e = tid; e < elems; e += nthr) {
+        unsigned hi = e >> a.logT, lo = e & tmask;
+        uint32_t v;
+        if (a.expand_bits) {
+            v = a.src[t.src_base + (e >> a.expand_bits)];  // T == 1, S == 1 here
+        } else {
+            v = a.src[t.base + (size_t)hi * t.S + lo];
+            if (tw) {
+                uint32_t r = bb::bitrev(hi, a.g);
+                uint32_t ex = (r * (t.lo0 + lo)) << (LAMBDA - a.mu);
+                v = bb::mul(v, root_pow(tb, 0, ex));
+            }
+        }
+        lds[e] = v;
+    }
+}
+RK_HD void fwd_stage(const PassArgs& a, const Tables& tb, uint32_t* lds, unsigned tid, unsigned nthr, unsigned tt) {
+    unsigned nb = 1u << (a.g - 1 + a.logT), tmask = (1u << a.logT) - 1;
+    unsigned half = 1u << tt;
+    for (unsigned b = tid; b < nb; b += nthr) {
+        unsigned lo = b & tmask, hb = b >> a.logT;
+        unsigned j = hb & (half - 1), blk = hb >> tt;
+        unsigned i0 = (((blk << (tt + 1)) + j) << a.logT) + lo;
+        unsigned i1 = i0 + (half << a.logT);
+        uint32_t x = lds[i0];
+        uint32_t y = bb::mul(lds[i1], tb.small[0][j << (KS - 1 - tt)]);
+        lds[i0] = bb::add(x, y);
+        lds[i1] = bb::sub(x, y);
+    }
+}
+RK_HD void fwd_store(const PassArgs& a, const Tile& t, const uint32_t* lds, unsigned tid, unsigned nthr) {
+    unsigned elems = 1u << (a.g + a.logT), tmask = (1u << a.logT) - 1;
+    for (unsigned e = tid; e < elems; e += nthr) {
+        unsigned hi = e >> a.logT, lo = e & tmask;
+        a.dst[t.base + (size_t)hi * t.S + lo] = lds[e];
+    }
+}
+
+// ---------------------------------------------------------------- pass planning
+struct Plan {
+    unsigned npass;
+    unsigned g[4], logT[4], mu[4];
+};
+// split k stages into passes, outermost (largest sub-problem) first; the host
+// runs them in this order for the reverse transform and in the opposite order
+// for the forward one.
+inline Plan make_plan(unsigned k, unsigned max_tile_log = MAX_TILE_LOG) {
+    Plan p{};
+    if (k == 0) return p;
+    unsigned rem = k, mu = k;
+    // contiguous innermost pass takes as many stages as fit in one tile
+    unsigned inner = k < max_tile_log ? k : max_tile_log;
+    rem -= inner;
+    // strided passes of at most 8 stages each (tile width >= 64 elements)
+    unsigned outer[3], no = 0;
+    while (rem > 0) {
+        unsigned npieces = (rem + 7) / 8;
+        unsigned gg = (rem + npieces - 1) / npieces;
+        outer[no++] = gg;
+        rem -= gg;
+    }
+    for (unsigned i = 0; i < no; i++) {
+        p.g[p.npass] = outer[i];
+        p.mu[p.npass] = mu;
+        unsigned s_log = mu - outer[i];
+        unsigned t = max_tile_log - outer[i];
+        p.logT[p.npass] = t < s_log ? t : s_log;
+        p.npass++;
+        mu -= outer[i];
+    }
+    p.g[p.npass] = inner;
+    p.mu[p.npass] = mu;
+    p.logT[p.npass] = 0;
+    p.npass++;
+    return p;
+}
+
+// Host-side generation of every table behind `Tables` (one flat array + offsets).
+struct TableLayout {
+    size_t small[2], hi[2], lo[2], pow3_hi, pow3_lo, total;
+};
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline TableLayout table_layout() {
+    const size_t n_small = (size_t)1 << (KS - 1);
+    const size_t n_hi = (size_t)1 << (LAMBDA - TW_SPLIT);
+    const size_t n_lo = (size_t)1 << TW_SPLIT;
+    TableLayout l{};
+    size_t off = 0;
+    for (int d = 0; d < 2; d++) { l.small[d] = off; off += n_small; }
+    for (int d = 0; d < 2; d++) { l.hi[d] = off; off += n_hi; l.lo[d] = off; off += n_lo; }
+    l.pow3_hi = off; off += n_hi;
+    l.pow3_lo = off; off += n_lo;
+    l.total = off;
+    return l;
+}
+inline void fill_pow(uint32_t* v, size_t n, uint32_t base) {
+    uint32_t cur = bb::ONE;
+    for (size_t i = 0; i < n; i++) {
+        v[i] = cur;
+        cur = bb::mul(cur, base);
+    }
+}
+// h must hold table_layout().total words
+inline void fill_tables(uint32_t* h) {
+    const TableLayout l = table_layout();
+    const size_t n_small = (size_t)1 << (KS - 1);
+    const size_t n_hi = (size_t)1 << (LAMBDA - TW_SPLIT);
+    const size_t n_lo = (size_t)1 << TW_SPLIT;
+    // 137 generates the 2^27 subgroup of BabyBear
+    uint32_t W = bb::pow(bb::encode(137), (uint64_t)1 << (27 - LAMBDA));
+    uint32_t Winv = bb::inv(W);
+    uint32_t ws = bb::pow(W, (uint64_t)1 << (LAMBDA - KS));
+    fill_pow(h + l.small[0], n_small, ws);
+    fill_pow(h + l.small[1], n_small, bb::inv(ws));
+    for (int d = 0; d < 2; d++) {
+        uint32_t g = d == 0 ? W : Winv;
+        fill_pow(h + l.hi[d], n_hi, bb::pow(g, (uint64_t)1 << TW_SPLIT));
+        fill_pow(h + l.lo[d], n_lo, g);
+    }
+    uint32_t three = bb::encode(3);
+    fill_pow(h + l.pow3_hi, n_hi, bb::pow(three, (uint64_t)1 << TW_SPLIT));
+    fill_pow(h + l.pow3_lo, n_lo, three);
+}
+inline Tables tables_at(const uint32_t* base) {
+    const TableLayout l = table_layout();
+    Tables t{};
+    for (int d = 0; d < 2; d++) {
+        t.small[d] = base + l.small[d];
+        t.hi[d] = base + l.hi[d];
+        t.lo[d] = base + l.lo[d];
+    }
+    t.pow3_hi = base + l.pow3_hi;
+    t.pow3_lo = base + l.pow3_lo;
+    return t;
+}
+#endif
+
+}  // namespace ntt

@@ -1,0 +1,69 @@
+// Poseidon2 over BabyBear, width 24, rate 16, x^7, R_F = 8, R_P = 21 -- the
+// permutation of risc0's default "poseidon2" hash suite (risc0-zkp
+// core/hash/poseidon2, un-vendored; reached from the reference through
+// `session.prove()` at provers/risc0/driver/src/bonsai.rs:271).  Constants come
+// from tools/gen_poseidon2_consts.py (Grain LFSR + published diagonal).
+//
+// Host and device share this code: the device keeps the 24-word state in VGPRs
+// (all indices are compile-time after unrolling) and reads round constants
+// through wave-uniform scalar loads from __constant__ memory.
+#pragma once
+#include "bb.hpp"
+
+namespace p2 {
+
+constexpr int CELLS = 24;
+constexpr int RATE = 16;
+constexpr int OUT = 8;
+constexpr int ROUNDS_HALF_FULL = 4;
+constexpr int ROUNDS_PARTIAL = 21;
+
+struct Consts {
+    uint32_t rc_ext[2 * ROUNDS_HALF_FULL * CELLS];  // Montgomery form
+    uint32_t rc_int[ROUNDS_PARTIAL];
+    uint32_t diag[CELLS];
+};
+
+// circ(2*M4, M4, ..., M4) with M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
+RK_HD void m_ext(uint32_t* s) {
+    uint32_t t[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < CELLS; i += 4) {
+        uint32_t a = s[i], b = s[i + 1], c = s[i + 2], d = s[i + 3];
+        uint32_t t0 = bb::add(a, b), t1 = bb::add(c, d);
+        uint32_t t2 = bb::add(bb::dbl(b), t1), t3 = bb::add(bb::dbl(d), t0);
+        uint32_t t4 = bb::add(bb::dbl(bb::dbl(t1)), t3), t5 = bb::add(bb::dbl(bb::dbl(t0)), t2);
+        uint32_t t6 = bb::add(t3, t5), t7 = bb::add(t2, t4);
+        s[i] = t6; s[i + 1] = t5; s[i + 2] = t7; s[i + 3] = t4;
+        t[0] = bb::add(t[0], t6); t[1] = bb::add(t[1], t5);
+        t[2] = bb::add(t[2], t7); t[3] = bb::add(t[3], t4);
+    }
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) s[i] = bb::add(s[i], t[i & 3]);
+}
+RK_HD void m_int(uint32_t* s, const Consts& k) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) sum = bb::add(sum, s[i]);
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) s[i] = bb::add(sum, bb::mul(s[i], k.diag[i]));
+}
+RK_HD void full_round(uint32_t* s, const Consts& k, int r) {
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) s[i] = bb::sbox7(bb::add(s[i], k.rc_ext[r * CELLS + i]));
+    m_ext(s);
+}
+RK_HD void permute(uint32_t* s, const Consts& k) {
+    m_ext(s);
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS_HALF_FULL; r++) full_round(s, k, r);
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS_PARTIAL; r++) {
+        s[0] = bb::sbox7(bb::add(s[0], k.rc_int[r]));
+        m_int(s, k);
+    }
+#pragma unroll 1
+    for (int r = ROUNDS_HALF_FULL; r < 2 * ROUNDS_HALF_FULL; r++) full_round(s, k, r);
+}
+
+}  // namespace p2

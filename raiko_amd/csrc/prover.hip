@@ -1,0 +1,587 @@
+// Whole-segment STARK prover on one MI355X: the host-side C++ mirror of
+// risc0-zkp 1.0.1 prove/{prover,poly_group,merkle,write_iop,fri}.rs and the
+// prove_segment driver of risc0-circuit-rv32im 1.0.1 -- the work behind
+// `session.prove()` at reference provers/risc0/driver/src/bonsai.rs:271.
+//
+// Everything sized O(trace) stays in HBM for the whole proof; the host only
+// sees transcript-sized data (Merkle caps, tap openings, the final FRI
+// polynomial, query openings).  The Fiat-Shamir transcript forces a handful
+// of stream synchronisations per segment (one per commitment).
+//
+// Circuit-specific steps (witness generation, accum construction, eval_check)
+// are inputs here: rk_segment carries their outputs.
+#include "internal.hpp"
+
+#include <cstring>
+#include <memory>
+
+namespace {
+
+using bb::Ext;
+
+// ---------------------------------------------------------------- transcript
+// WriteIOP + Poseidon2Rng (risc0-zkp prove/write_iop.rs, core/hash/poseidon2/rng.rs)
+struct Transcript {
+    const p2::Consts* k;
+    std::vector<uint32_t> proof;
+    uint32_t cells[p2::CELLS];
+    unsigned pool_used = 0;
+    explicit Transcript(const p2::Consts* kc) : k(kc) { std::memset(cells, 0, sizeof cells); }
+    void write(const uint32_t* w, size_t n) { proof.insert(proof.end(), w, w + n); }
+    void commit(const uint32_t* digest) {
+        if (pool_used != 0) {
+            p2::permute(cells, *k);
+            pool_used = 0;
+        }
+        for (int i = 0; i < p2::OUT; i++) cells[i] = bb::add(cells[i], digest[i]);
+        p2::permute(cells, *k);
+    }
+    uint32_t random_elem() {
+        if (pool_used == p2::RATE) {
+            p2::permute(cells, *k);
+            pool_used = 0;
+        }
+        return cells[pool_used++];
+    }
+    Ext random_ext() {
+        Ext r;
+        for (int i = 0; i < 4; i++) r.c[i] = random_elem();
+        return r;
+    }
+    uint32_t random_bits(unsigned bits) {
+        uint32_t v = bb::decode(random_elem());
+        for (int i = 0; i < 3; i++) v ^= bb::decode(random_elem());
+        return v & (uint32_t)(((uint64_t)1 << bits) - 1);
+    }
+};
+
+// host sponge over a contiguous element slice (Poseidon2HashFn::hash_elem_slice)
+void hash_elems(const p2::Consts& k, const uint32_t* in, size_t n, uint32_t* digest) {
+    uint32_t s[p2::CELLS];
+    std::memset(s, 0, sizeof s);
+    size_t unmixed = 0;
+    for (size_t i = 0; i < n; i++) {
+        s[unmixed++] = in[i];
+        if (unmixed == p2::RATE) {
+            p2::permute(s, k);
+            unmixed = 0;
+        }
+    }
+    if (unmixed != 0 || n == 0) {
+        for (size_t i = unmixed; i < p2::RATE; i++) s[i] = 0;
+        p2::permute(s, k);
+    }
+    std::memcpy(digest, s, p2::OUT * 4);
+}
+
+// ---------------------------------------------------------------- device helpers
+struct DevBuf {
+    rk_ctx* ctx = nullptr;
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    int alloc(rk_ctx* c, size_t bytes) {
+        release();
+        ctx = c;
+        return rk::dev_alloc(c, bytes, &p);
+    }
+    void release() {
+        if (p) rk::dev_free(ctx, p);
+        p = nullptr;
+    }
+    uint32_t* u32() const { return (uint32_t*)p; }
+};
+
+int d2h_sync(rk_ctx* ctx, void* h, const void* d, size_t bytes) {
+    RK_HIP_TRY(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+int h2d_sync(rk_ctx* ctx, void* d, const void* h, size_t bytes) {
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------- Merkle prover
+struct MerkleDev {
+    size_t rows = 0, cols = 0, layers = 0, top_layer = 0, top_size = 1;
+    DevBuf nodes;
+    const uint32_t* matrix = nullptr;  // device, column-major rows x cols
+    std::vector<uint32_t> top;         // host copy of nodes[1 .. 2*top_size)
+
+    int build(rk_ctx* ctx, const uint32_t* d_matrix, size_t r, size_t c, size_t queries) {
+        rows = r;
+        cols = c;
+        matrix = d_matrix;
+        layers = log2u(r);
+        top_layer = 0;
+        for (size_t i = 1; i < layers; i++) {
+            if (((size_t)1 << i) > queries) break;
+            top_layer = i;
+        }
+        top_size = (size_t)1 << top_layer;
+        RK_TRY(nodes.alloc(ctx, 2 * rows * p2::OUT * 4));
+        return rk::merkle_build(ctx, nodes.u32(), d_matrix, rows, cols);
+    }
+    // MerkleTreeProver::commit: send the top layer, absorb the root
+    int commit(rk_ctx* ctx, Transcript& iop) {
+        top.assign(2 * top_size * p2::OUT, 0);
+        // nodes[1 .. 2*top_size) in one copy (index 0 unused)
+        RK_TRY(d2h_sync(ctx, top.data() + p2::OUT, nodes.u32() + p2::OUT, (2 * top_size - 1) * p2::OUT * 4));
+        iop.write(top.data() + top_size * p2::OUT, top_size * p2::OUT);
+        iop.commit(top.data() + p2::OUT);
+        return RK_OK;
+    }
+    size_t path_len() const { return layers - top_layer; }
+};
+
+// Openings of one tree at n query positions, fetched with two gathers and one D2H each.
+struct Openings {
+    std::vector<uint32_t> rows;   // n x cols
+    std::vector<uint32_t> paths;  // n x path_len x 8
+};
+int open_many(rk_ctx* ctx, const MerkleDev& m, const std::vector<uint32_t>& pos, Openings& out) {
+    size_t n = pos.size(), pl = m.path_len();
+    std::vector<uint32_t> node_idx(n * pl);
+    for (size_t q = 0; q < n; q++) {
+        size_t idx = pos[q] + m.rows, j = 0;
+        while (idx >= 2 * m.top_size) {
+            size_t low = idx & 1;
+            idx >>= 1;
+            node_idx[q * pl + j++] = (uint32_t)(2 * idx + (1 - low));
+        }
+    }
+    DevBuf d_idx, d_rows, d_paths;
+    RK_TRY(d_idx.alloc(ctx, (n + n * pl) * 4));
+    RK_TRY(d_rows.alloc(ctx, n * m.cols * 4));
+    RK_TRY(d_paths.alloc(ctx, n * pl * p2::OUT * 4 + 16));
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d_idx.u32(), pos.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (pl)
+        RK_HIP_TRY(ctx, hipMemcpyAsync(d_idx.u32() + n, node_idx.data(), n * pl * 4, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors are about to go out of scope
+    RK_TRY(rk::gather_rows(ctx, d_rows.u32(), m.matrix, m.rows, m.cols, d_idx.u32(), n));
+    RK_TRY(rk::gather_digests(ctx, d_paths.u32(), m.nodes.u32(), d_idx.u32() + n, n * pl));
+    out.rows.resize(n * m.cols);
+    out.paths.resize(n * pl * p2::OUT);
+    RK_HIP_TRY(ctx, hipMemcpyAsync(out.rows.data(), d_rows.u32(), n * m.cols * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pl)
+        RK_HIP_TRY(ctx, hipMemcpyAsync(out.paths.data(), d_paths.u32(), n * pl * p2::OUT * 4, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+void write_opening(Transcript& iop, const MerkleDev& m, const Openings& o, size_t q) {
+    iop.write(o.rows.data() + q * m.cols, m.cols);
+    size_t pl = m.path_len();
+    iop.write(o.paths.data() + q * pl * p2::OUT, pl * p2::OUT);
+}
+
+// ---------------------------------------------------------------- PolyGroup
+struct PolyGroup {
+    DevBuf coeffs;     // count x size, natural order once built
+    DevBuf evaluated;  // count x size*4
+    size_t count = 0, size = 0;
+    MerkleDev merkle;
+    // coeffs must hold interpolated, zk-shifted, bit-reversed coefficients
+    int build(rk_ctx* ctx, size_t cnt, size_t sz) {
+        count = cnt;
+        size = sz;
+        size_t domain = sz * 4;
+        RK_TRY(evaluated.alloc(ctx, cnt * domain * 4));
+        RK_TRY(rk::ntt_forward(ctx, evaluated.u32(), coeffs.u32(), sz, cnt, 2));
+        RK_TRY(rk::bit_reverse(ctx, coeffs.u32(), sz, cnt));
+        return RK_OK;
+    }
+};
+
+struct Stopwatch {
+    rk_ctx* ctx;
+    hipEvent_t ev[2];
+    bool ok = false;
+    explicit Stopwatch(rk_ctx* c) : ctx(c) {
+        ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+    }
+    ~Stopwatch() {
+        if (ok) {
+            (void)hipEventDestroy(ev[0]);
+            (void)hipEventDestroy(ev[1]);
+        }
+    }
+    void start() {
+        if (ok) (void)hipEventRecord(ev[0], ctx->stream);
+    }
+    // accumulates elapsed device time since start() into *acc (synchronises the stream)
+    void stop(float* acc) {
+        if (!ok) return;
+        (void)hipEventRecord(ev[1], ctx->stream);
+        (void)hipEventSynchronize(ev[1]);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) *acc += ms;
+    }
+};
+
+int check_taps(const rk_taps& t) {
+    if (!t.reg_group || !t.reg_offset || !t.reg_combo || !t.combo_off || !t.combo_backs) return RK_ERR_INVALID;
+    if ((size_t)t.group_size[0] + t.group_size[1] + t.group_size[2] != t.n_regs) return RK_ERR_INVALID;
+    uint32_t r = 0;
+    for (uint32_t g = 0; g < 3; g++)
+        for (uint32_t o = 0; o < t.group_size[g]; o++, r++) {
+            if (t.reg_group[r] != g || t.reg_offset[r] != o) return RK_ERR_INVALID;
+            if (t.reg_combo[r] >= t.n_combos) return RK_ERR_INVALID;
+        }
+    if (t.combo_off[0] != 0) return RK_ERR_INVALID;
+    for (uint32_t c = 0; c < t.n_combos; c++)
+        if (t.combo_off[c + 1] <= t.combo_off[c]) return RK_ERR_INVALID;
+    return RK_OK;
+}
+
+// core/poly.rs poly_interpolate for the handful of taps of one register
+void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n) {
+    std::vector<Ext> num(n + 1);
+    for (size_t i = 0; i < n; i++) out[i] = bb::ext_zero();
+    for (size_t i = 0; i < n; i++) {
+        size_t deg = 0;
+        Ext denom = bb::ext_one();
+        num[0] = bb::ext_one();
+        for (size_t j = 0; j < n; j++) {
+            if (j == i) continue;
+            num[deg + 1] = num[deg];
+            for (size_t k = deg; k > 0; k--) num[k] = bb::sub(num[k - 1], bb::mul(num[k], x[j]));
+            num[0] = bb::sub(bb::ext_zero(), bb::mul(num[0], x[j]));
+            deg++;
+            denom = bb::mul(denom, bb::sub(x[i], x[j]));
+        }
+        Ext sc = bb::mul(fx[i], bb::inv(denom));
+        for (size_t k = 0; k < n; k++) out[k] = bb::add(out[k], bb::mul(num[k], sc));
+    }
+}
+
+int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& seal) {
+    const rk_taps& taps = seg->taps;
+    RK_TRY(check_taps(taps));
+    if (seg->po2 < 1 || seg->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
+    for (int g = 0; g < 3; g++)
+        if (!seg->group[g] || taps.group_size[g] == 0) return RK_ERR_INVALID;
+    if (!seg->check || (seg->n_globals && !seg->globals)) return RK_ERR_INVALID;
+
+    const size_t N = (size_t)1 << seg->po2, D = N * 4;
+    const size_t QUERIES = 50, FRI_FOLD = 16, FRI_MIN_DEGREE = 256, CHECK_SIZE = 16;
+    const p2::Consts& kc = ctx->h_p2;
+    Transcript iop(&kc);
+    uint32_t digest[8];
+    ctx->timing = rk_timing{};
+    Stopwatch total_sw(ctx), sw(ctx);
+    total_sw.start();
+
+    {
+        uint32_t e[16];
+        for (int i = 0; i < 16; i++) e[i] = bb::encode(seg->proof_system_info[i]);
+        hash_elems(kc, e, 16, digest);
+        iop.commit(digest);
+        for (int i = 0; i < 16; i++) e[i] = bb::encode(seg->circuit_info[i]);
+        hash_elems(kc, e, 16, digest);
+        iop.commit(digest);
+        std::vector<uint32_t> vec(seg->globals, seg->globals + seg->n_globals);
+        vec.push_back(bb::encode(seg->po2));
+        hash_elems(kc, vec.data(), vec.size(), digest);
+        iop.commit(digest);
+        iop.write(seg->globals, seg->n_globals);
+        iop.write(&seg->po2, 1);
+    }
+
+    auto load_trace = [&](DevBuf& dst, const uint32_t* src, size_t words) -> int {
+        RK_TRY(dst.alloc(ctx, words * 4));
+        RK_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, words * 4,
+                                       seg->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        if (!seg->on_device) RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RK_OK;
+    };
+    // Prover::commit_group
+    auto commit_group = [&](PolyGroup& pg, const uint32_t* trace, size_t count) -> int {
+        RK_TRY(load_trace(pg.coeffs, trace, count * N));
+        sw.start();
+        RK_TRY(rk::ntt_reverse(ctx, pg.coeffs.u32(), N, count, /*fuse_zk_shift=*/true));
+        RK_TRY(pg.build(ctx, count, N));
+        sw.stop(&ctx->timing.ntt);
+        sw.start();
+        RK_TRY(pg.merkle.build(ctx, pg.evaluated.u32(), D, count, QUERIES));
+        sw.stop(&ctx->timing.hash);
+        return pg.merkle.commit(ctx, iop);
+    };
+
+    PolyGroup groups[3], check;
+    RK_TRY(commit_group(groups[1], seg->group[1], taps.group_size[1]));  // code
+    RK_TRY(commit_group(groups[2], seg->group[2], taps.group_size[2]));  // data
+    for (uint32_t i = 0; i < seg->n_accum_mix; i++) (void)iop.random_elem();
+    RK_TRY(commit_group(groups[0], seg->group[0], taps.group_size[0]));  // accum
+
+    // Prover::finalize
+    (void)iop.random_ext();  // poly_mix: consumed by CircuitHal::eval_check, whose output is seg->check
+    RK_TRY(load_trace(check.coeffs, seg->check, 4 * D));
+    sw.start();
+    RK_TRY(rk::ntt_reverse(ctx, check.coeffs.u32(), D, 4, false));
+    RK_TRY(rk::zk_shift(ctx, check.coeffs.u32(), N, CHECK_SIZE));
+    RK_TRY(check.build(ctx, CHECK_SIZE, N));
+    sw.stop(&ctx->timing.ntt);
+    sw.start();
+    RK_TRY(check.merkle.build(ctx, check.evaluated.u32(), D, CHECK_SIZE, QUERIES));
+    sw.stop(&ctx->timing.hash);
+    RK_TRY(check.merkle.commit(ctx, iop));
+
+    sw.start();
+    Ext z = iop.random_ext();
+    uint32_t w27 = bb::encode(137);
+    uint32_t back_one = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - seg->po2)));
+    Ext z_pow = bb::pow(z, 4);
+
+    // tap openings: every register at z * back_one^back for each of its backs
+    size_t tot_taps = 0;
+    for (uint32_t r = 0; r < taps.n_regs; r++)
+        tot_taps += taps.combo_off[taps.reg_combo[r] + 1] - taps.combo_off[taps.reg_combo[r]];
+    uint32_t max_back = 0;
+    for (uint32_t b = 0; b < taps.combo_off[taps.n_combos]; b++)
+        if (taps.combo_backs[b] > max_back) max_back = taps.combo_backs[b];
+    if (max_back > 64) return RK_ERR_INVALID;
+    // device power tables: slot b = (z*back_one^b)^k, slot max_back+1 = (z^4)^k
+    size_t n_pts = (size_t)max_back + 2;
+    std::vector<Ext> pts(n_pts);
+    for (uint32_t b = 0; b <= max_back; b++) pts[b] = bb::scale(z, bb::pow(back_one, b));
+    pts[max_back + 1] = z_pow;
+    std::vector<Ext> all_xs(tot_taps), coeff_u(tot_taps + CHECK_SIZE);
+    {
+        DevBuf d_pw, d_small;
+        RK_TRY(d_pw.alloc(ctx, n_pts * N * 16));
+        for (size_t j = 0; j < n_pts; j++) RK_TRY(rk::ext_powers(ctx, d_pw.u32() + j * N * 4, pts[j], N));
+        size_t max_evals = tot_taps > CHECK_SIZE ? tot_taps : CHECK_SIZE;
+        RK_TRY(d_small.alloc(ctx, max_evals * (4 + 4 + 16) + 32));
+        std::vector<Ext> eval_u(tot_taps + CHECK_SIZE);
+        std::vector<uint32_t> which, sel;
+        size_t pos = 0;
+        uint32_t reg = 0;
+        auto run_evals = [&](const PolyGroup& pg, size_t out_pos) -> int {
+            size_t n = which.size();
+            if (n == 0) return RK_OK;
+            uint32_t* d_which = d_small.u32();
+            uint32_t* d_sel = d_which + n;
+            uint32_t* d_out = d_sel + n;
+            if (((uintptr_t)d_out & 15) != 0) d_out += (16 - ((uintptr_t)d_out & 15)) / 4;
+            RK_HIP_TRY(ctx, hipMemcpyAsync(d_which, which.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+            RK_HIP_TRY(ctx, hipMemcpyAsync(d_sel, sel.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+            RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            RK_TRY(rk::eval_dot(ctx, d_out, pg.coeffs.u32(), N, d_which, d_pw.u32(), d_sel, n));
+            return d2h_sync(ctx, &eval_u[out_pos], d_out, n * 16);
+        };
+        for (uint32_t gid = 0; gid < 3; gid++) {
+            which.clear();
+            sel.clear();
+            size_t start = pos;
+            for (; reg < taps.n_regs && taps.reg_group[reg] == gid; reg++) {
+                uint32_t cb = taps.reg_combo[reg];
+                for (uint32_t b = taps.combo_off[cb]; b < taps.combo_off[cb + 1]; b++) {
+                    which.push_back(taps.reg_offset[reg]);
+                    sel.push_back(taps.combo_backs[b]);
+                    all_xs[pos++] = pts[taps.combo_backs[b]];
+                }
+            }
+            RK_TRY(run_evals(groups[gid], start));
+        }
+        // registers -> coefficients of their interpolating polynomials
+        size_t p = 0;
+        for (uint32_t r = 0; r < taps.n_regs; r++) {
+            uint32_t cb = taps.reg_combo[r];
+            size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
+            poly_interpolate(&coeff_u[p], &all_xs[p], &eval_u[p], sz);
+            p += sz;
+        }
+        which.clear();
+        sel.clear();
+        for (uint32_t i = 0; i < CHECK_SIZE; i++) {
+            which.push_back(i);
+            sel.push_back(max_back + 1);
+        }
+        RK_TRY(run_evals(check, tot_taps));
+        for (uint32_t i = 0; i < CHECK_SIZE; i++) coeff_u[tot_taps + i] = eval_u[tot_taps + i];
+    }
+    iop.write((const uint32_t*)coeff_u.data(), coeff_u.size() * 4);
+    hash_elems(kc, (const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
+    iop.commit(digest);
+
+    // DEEP: mix all columns into one polynomial per combo, remove the openings, divide
+    Ext mix = iop.random_ext();
+    const size_t combo_count = taps.n_combos;
+    DevBuf combos;
+    RK_TRY(combos.alloc(ctx, (combo_count + 1) * N * 16));
+    RK_HIP_TRY(ctx, hipMemsetAsync(combos.p, 0, (combo_count + 1) * N * 16, ctx->stream));
+    {
+        Ext cur_mix = bb::ext_one();
+        uint32_t reg = 0;
+        std::vector<uint32_t> which;
+        for (uint32_t gid = 0; gid < 3; gid++) {
+            uint32_t gs = taps.group_size[gid];
+            which.assign(gs, 0);
+            for (uint32_t i = 0; i < gs; i++, reg++) which[i] = taps.reg_combo[reg];
+            RK_TRY(rk::mix_poly_coeffs(ctx, combos.u32(), cur_mix, mix, groups[gid].coeffs.u32(), which.data(), gs, N));
+            cur_mix = bb::mul(cur_mix, bb::pow(mix, gs));
+        }
+        which.assign(CHECK_SIZE, (uint32_t)combo_count);
+        RK_TRY(rk::mix_poly_coeffs(ctx, combos.u32(), cur_mix, mix, check.coeffs.u32(), which.data(), CHECK_SIZE, N));
+    }
+    {
+        // combos[size*combo + i] -= cur * coeff_u[...]: accumulate per touched coefficient on the host
+        std::vector<Ext> delta((combo_count + 1) * (max_back + 2), bb::ext_zero());
+        std::vector<uint32_t> delta_idx;
+        size_t stride = (size_t)max_back + 2;
+        Ext cur = bb::ext_one();
+        size_t cur_pos = 0;
+        for (uint32_t r = 0; r < taps.n_regs; r++) {
+            uint32_t cb = taps.reg_combo[r];
+            size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
+            if (sz > stride || sz > N) return RK_ERR_INVALID;
+            for (size_t i = 0; i < sz; i++)
+                delta[cb * stride + i] = bb::add(delta[cb * stride + i], bb::mul(cur, coeff_u[cur_pos + i]));
+            cur = bb::mul(cur, mix);
+            cur_pos += sz;
+        }
+        for (uint32_t i = 0; i < CHECK_SIZE; i++) {
+            delta[combo_count * stride] = bb::add(delta[combo_count * stride], bb::mul(cur, coeff_u[cur_pos++]));
+            cur = bb::mul(cur, mix);
+        }
+        std::vector<Ext> dl;
+        for (size_t c = 0; c <= combo_count; c++) {
+            size_t sz = c < combo_count ? taps.combo_off[c + 1] - taps.combo_off[c] : 1;
+            for (size_t i = 0; i < sz; i++) {
+                delta_idx.push_back((uint32_t)(c * N + i));
+                dl.push_back(delta[c * stride + i]);
+            }
+        }
+        RK_TRY(rk::ext_sub_at(ctx, combos.u32(), delta_idx.data(), dl.data(), dl.size()));
+        for (size_t c = 0; c < combo_count; c++)
+            for (uint32_t b = taps.combo_off[c]; b < taps.combo_off[c + 1]; b++) {
+                Ext rem;
+                RK_TRY(rk::poly_divide(ctx, combos.u32() + c * N * 4, N, pts[taps.combo_backs[b]], &rem));
+                if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+            }
+        Ext rem;
+        RK_TRY(rk::poly_divide(ctx, combos.u32() + combo_count * N * 4, N, z_pow, &rem));
+        if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+    }
+    DevBuf final_poly;
+    RK_TRY(final_poly.alloc(ctx, N * 16));
+    RK_TRY(rk::eltwise_sum_ext(ctx, final_poly.u32(), combos.u32(), N, combo_count + 1));
+    RK_TRY(rk::bit_reverse(ctx, final_poly.u32(), N, 4));
+    combos.release();
+    sw.stop(&ctx->timing.deep);
+
+    // ---- fri_prove ----
+    sw.start();
+    struct Round {
+        size_t domain;
+        DevBuf coeffs, evaluated;
+        size_t coeffs_words;
+        MerkleDev merkle;
+    };
+    std::vector<std::unique_ptr<Round>> rounds;
+    const uint32_t* cur_coeffs = final_poly.u32();
+    size_t cur_words = N * 4;
+    const size_t orig_domain = D;
+    while (cur_words / 4 > FRI_MIN_DEGREE) {
+        std::unique_ptr<Round> r(new Round());
+        size_t size = cur_words / 4, domain = size * 4;
+        r->domain = domain;
+        RK_TRY(r->evaluated.alloc(ctx, domain * 16));
+        RK_TRY(rk::ntt_forward(ctx, r->evaluated.u32(), cur_coeffs, size, 4, 2));
+        RK_TRY(r->merkle.build(ctx, r->evaluated.u32(), domain / FRI_FOLD, FRI_FOLD * 4, QUERIES));
+        RK_TRY(r->merkle.commit(ctx, iop));
+        Ext fold_mix = iop.random_ext();
+        r->coeffs_words = size / FRI_FOLD * 4;
+        RK_TRY(r->coeffs.alloc(ctx, r->coeffs_words * 4));
+        RK_TRY(rk::fri_fold(ctx, r->coeffs.u32(), cur_coeffs, size / FRI_FOLD, fold_mix));
+        cur_coeffs = r->coeffs.u32();
+        cur_words = r->coeffs_words;
+        rounds.push_back(std::move(r));
+    }
+    {
+        DevBuf fin;
+        RK_TRY(fin.alloc(ctx, cur_words * 4));
+        RK_HIP_TRY(ctx, hipMemcpyAsync(fin.p, cur_coeffs, cur_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        RK_TRY(rk::bit_reverse(ctx, fin.u32(), cur_words / 4, 4));
+        std::vector<uint32_t> h(cur_words);
+        RK_TRY(d2h_sync(ctx, h.data(), fin.p, cur_words * 4));
+        iop.write(h.data(), h.size());
+        hash_elems(kc, h.data(), h.size(), digest);
+        iop.commit(digest);
+    }
+    sw.stop(&ctx->timing.fri);
+
+    // ---- queries: positions depend only on the sponge, so all openings are gathered in bulk ----
+    sw.start();
+    std::vector<uint32_t> pos0(QUERIES);
+    for (size_t q = 0; q < QUERIES; q++) pos0[q] = iop.random_bits(log2u(orig_domain)) % (uint32_t)orig_domain;
+    Openings og[3], ocheck;
+    for (int g = 0; g < 3; g++) RK_TRY(open_many(ctx, groups[g].merkle, pos0, og[g]));
+    RK_TRY(open_many(ctx, check.merkle, pos0, ocheck));
+    std::vector<Openings> oround(rounds.size());
+    {
+        std::vector<uint32_t> pos = pos0;
+        for (size_t k = 0; k < rounds.size(); k++) {
+            for (size_t q = 0; q < QUERIES; q++) pos[q] %= (uint32_t)(rounds[k]->domain / FRI_FOLD);
+            RK_TRY(open_many(ctx, rounds[k]->merkle, pos, oround[k]));
+        }
+    }
+    for (size_t q = 0; q < QUERIES; q++) {
+        for (int g = 0; g < 3; g++) write_opening(iop, groups[g].merkle, og[g], q);
+        write_opening(iop, check.merkle, ocheck, q);
+        for (size_t k = 0; k < rounds.size(); k++) write_opening(iop, rounds[k]->merkle, oround[k], q);
+    }
+    sw.stop(&ctx->timing.query);
+    total_sw.stop(&ctx->timing.total);
+    seal.swap(iop.proof);
+    return RK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk_seal_bound_words(const rk_segment* seg) {
+    if (!seg || seg->po2 > 24) return 0;
+    const rk_taps& t = seg->taps;
+    size_t N = (size_t)1 << seg->po2, D = 4 * N;
+    size_t layers = log2u(D);
+    size_t words = seg->n_globals + 1;
+    size_t tot_taps = 0;
+    if (t.reg_combo && t.combo_off)
+        for (uint32_t r = 0; r < t.n_regs; r++) tot_taps += t.combo_off[t.reg_combo[r] + 1] - t.combo_off[t.reg_combo[r]];
+    size_t w_all = (size_t)t.group_size[0] + t.group_size[1] + t.group_size[2] + 16;
+    words += 4 * 32 * 8;                      // top layers of the four trace trees
+    words += (tot_taps + 16) * 4;             // coeff_u
+    words += 50 * (w_all + 4 * layers * 8);   // trace openings
+    size_t size = N;
+    while (size > 256) {
+        size_t domain = size * 4;
+        words += 32 * 8 + 50 * (64 + log2u(domain / 16) * 8);
+        size /= 16;
+    }
+    words += size * 4;
+    return words + 64;
+}
+
+int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t cap, size_t* seal_words) {
+    if (!ctx || !seg || !seal_words) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> seal;
+    int st = prove_segment(ctx, seg, seal);
+    if (st != RK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return st;
+    }
+    *seal_words = seal.size();
+    if (!h_seal || seal.size() > cap) return RK_ERR_CAPACITY;
+    std::memcpy(h_seal, seal.data(), seal.size() * 4);
+    return RK_OK;
+}
+
+}  // extern "C"

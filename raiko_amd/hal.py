@@ -1,0 +1,240 @@
+"""`HipHal`: the MI355X implementation of risc0's `Hal` operator set, over the C ABI.
+
+Method names and argument meaning follow `risc0_zkp::hal::Hal` (risc0-zkp 1.0.1, the
+trait behind `session.prove()` at reference provers/risc0/driver/src/bonsai.rs:271) so
+parity tests read like risc0's own HAL tests.  Buffers are device memory; elements are
+BabyBear Montgomery residues (uint32).  No CPU fallback exists: construction fails if
+libraiko_hip.so or a GPU is missing.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .segment import Segment, TapSet
+
+
+def _u32p(a: np.ndarray):
+    return a.ctypes.data_as(_lib.u32p)
+
+
+class DeviceBuffer:
+    """`Hal::Buffer<u32>`: a device allocation owned by a HipHal context."""
+
+    def __init__(self, hal: "HipHal", words: int):
+        self.hal = hal
+        self.words = int(words)
+        ptr = C.c_void_p()
+        _lib.check(hal._ctx, hal._lib.rk_alloc(hal._ctx, self.words * 4, C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def size(self) -> int:
+        return self.words
+
+    def copy_from(self, host: np.ndarray) -> "DeviceBuffer":
+        host = np.ascontiguousarray(host, dtype=np.uint32).reshape(-1)
+        assert host.size == self.words, (host.size, self.words)
+        _lib.check(self.hal._ctx, self.hal._lib.rk_h2d(self.hal._ctx, self.ptr, host.ctypes.data, host.nbytes))
+        return self
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.words, dtype=np.uint32)
+        _lib.check(self.hal._ctx, self.hal._lib.rk_d2h(self.hal._ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.hal._ctx:
+            self.hal._lib.rk_free(self.hal._ctx, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(buf) -> int:
+    """Accept a DeviceBuffer, a torch CUDA tensor (uint32/int32) or a raw device address."""
+    if isinstance(buf, DeviceBuffer):
+        return buf.ptr
+    if hasattr(buf, "data_ptr"):
+        return buf.data_ptr()
+    return int(buf)
+
+
+class HipHal:
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _lib.load()
+        self._ctx = None
+        n = C.c_int(0)
+        st = self._lib.rk_device_count(C.byref(n))
+        if st != 0 or n.value <= 0:
+            raise _lib.HipLibraryError("no AMD GPU visible to HIP: raiko_amd has no CPU fallback")
+        ctx = C.c_void_p()
+        _lib.check(None, self._lib.rk_ctx_create(device, stream, C.byref(ctx)))
+        self._ctx = ctx.value
+        self.device = device
+
+    def close(self):
+        if self._ctx:
+            self._lib.rk_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        _lib.check(self._ctx, st)
+
+    # ---- buffers ----
+    def alloc_elem(self, words: int) -> DeviceBuffer:
+        return DeviceBuffer(self, words)
+
+    def copy_from_elem(self, host: np.ndarray) -> DeviceBuffer:
+        host = np.ascontiguousarray(host, dtype=np.uint32)
+        return DeviceBuffer(self, host.size).copy_from(host)
+
+    def sync(self):
+        self._ck(self._lib.rk_sync(self._ctx))
+
+    # ---- Hal operators ----
+    def batch_interpolate_ntt(self, io, count: int, size: Optional[int] = None):
+        size = size if size is not None else io.size() // count
+        self._ck(self._lib.rk_batch_interpolate_ntt(self._ctx, _ptr(io), size, count))
+
+    def batch_evaluate_ntt(self, io, count: int, expand_bits: int = 0, size: Optional[int] = None):
+        size = size if size is not None else io.size() // count
+        self._ck(self._lib.rk_batch_evaluate_ntt(self._ctx, _ptr(io), size, count, expand_bits))
+
+    def zk_shift(self, io, count: int, size: Optional[int] = None):
+        size = size if size is not None else io.size() // count
+        self._ck(self._lib.rk_zk_shift(self._ctx, _ptr(io), size, count))
+
+    def batch_expand_into_evaluate_ntt(self, out, inp, count: int, expand_bits: int, in_size: Optional[int] = None):
+        in_size = in_size if in_size is not None else inp.size() // count
+        self._ck(self._lib.rk_batch_expand_into_evaluate_ntt(self._ctx, _ptr(out), _ptr(inp), in_size, count, expand_bits))
+
+    def batch_bit_reverse(self, io, count: int, size: Optional[int] = None):
+        size = size if size is not None else io.size() // count
+        self._ck(self._lib.rk_batch_bit_reverse(self._ctx, _ptr(io), size, count))
+
+    def hash_rows(self, out, matrix, rows: int, cols: int):
+        self._ck(self._lib.rk_hash_rows(self._ctx, _ptr(out), _ptr(matrix), rows, cols))
+
+    def hash_fold(self, io, input_size: int, output_size: int):
+        self._ck(self._lib.rk_hash_fold(self._ctx, _ptr(io), input_size, output_size))
+
+    def merkle_build(self, nodes, matrix, rows: int, cols: int):
+        self._ck(self._lib.rk_merkle_build(self._ctx, _ptr(nodes), _ptr(matrix), rows, cols))
+
+    def batch_evaluate_any(self, coeffs, poly_count: int, size: int, which: Sequence[int], xs: np.ndarray) -> np.ndarray:
+        which = np.ascontiguousarray(which, dtype=np.uint32)
+        xs = np.ascontiguousarray(xs, dtype=np.uint32).reshape(-1, 4)
+        assert xs.shape[0] == which.size
+        out = np.zeros((which.size, 4), dtype=np.uint32)
+        self._ck(self._lib.rk_batch_evaluate_any(self._ctx, _ptr(coeffs), poly_count, size, _u32p(which), _u32p(xs),
+                                                 which.size, _u32p(out)))
+        return out
+
+    def mix_poly_coeffs(self, out, mix_start, mix, inp, combos: Sequence[int], input_size: int, count: int):
+        ms = np.ascontiguousarray(mix_start, dtype=np.uint32)
+        mx = np.ascontiguousarray(mix, dtype=np.uint32)
+        cb = np.ascontiguousarray(combos, dtype=np.uint32)
+        assert cb.size == input_size
+        self._ck(self._lib.rk_mix_poly_coeffs(self._ctx, _ptr(out), _u32p(ms), _u32p(mx), _ptr(inp), _u32p(cb),
+                                              input_size, count))
+
+    def eltwise_add_elem(self, out, a, b, n: int):
+        self._ck(self._lib.rk_eltwise_add_elem(self._ctx, _ptr(out), _ptr(a), _ptr(b), n))
+
+    def eltwise_sum_extelem(self, out, inp, count: int, to_add: int):
+        self._ck(self._lib.rk_eltwise_sum_extelem(self._ctx, _ptr(out), _ptr(inp), count, to_add))
+
+    def eltwise_copy_elem(self, out, inp, n: int):
+        self._ck(self._lib.rk_eltwise_copy_elem(self._ctx, _ptr(out), _ptr(inp), n))
+
+    def eltwise_zeroize_elem(self, io, n: int):
+        self._ck(self._lib.rk_eltwise_zeroize_elem(self._ctx, _ptr(io), n))
+
+    def fri_fold(self, out, inp, out_count: int, mix):
+        mx = np.ascontiguousarray(mix, dtype=np.uint32)
+        self._ck(self._lib.rk_fri_fold(self._ctx, _ptr(out), _ptr(inp), out_count, _u32p(mx)))
+
+    def gather_sample(self, dst, src, idx: int, size: int, stride: int):
+        self._ck(self._lib.rk_gather_sample(self._ctx, _ptr(dst), _ptr(src), idx, size, stride))
+
+    def poly_divide(self, poly, count: int, z) -> np.ndarray:
+        zz = np.ascontiguousarray(z, dtype=np.uint32)
+        rem = np.zeros(4, dtype=np.uint32)
+        self._ck(self._lib.rk_poly_divide(self._ctx, _ptr(poly), count, _u32p(zz), _u32p(rem)))
+        return rem
+
+    # ---- whole segment ----
+    def prove_segment(self, seg: Segment, device_inputs=None) -> np.ndarray:
+        """Seal (uint32 transcript) of one segment.  `device_inputs` = (groups[3], check) of device
+        buffers / tensors to prove from HBM-resident inputs; otherwise the host arrays are uploaded."""
+        c_seg, keep = make_c_segment(seg, device_inputs)
+        cap = int(self._lib.rk_seal_bound_words(C.byref(c_seg)))
+        seal = np.empty(cap, dtype=np.uint32)
+        words = C.c_size_t(0)
+        self._ck(self._lib.rk_prove_segment(self._ctx, C.byref(c_seg), _u32p(seal), cap, C.byref(words)))
+        del keep
+        return seal[:words.value].copy()
+
+    def last_timing(self) -> dict:
+        t = _lib.RkTiming()
+        self._ck(self._lib.rk_last_timing(self._ctx, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in t._fields_}
+
+
+def fill_c_taps(c_taps, taps: TapSet, keep: list):
+    arrs = {}
+    for name in ("reg_group", "reg_offset", "reg_combo", "combo_off", "combo_backs"):
+        a = np.ascontiguousarray(getattr(taps, name), dtype=np.uint32)
+        keep.append(a)
+        arrs[name] = a
+        setattr(c_taps, name, _u32p(a))
+    for g in range(3):
+        c_taps.group_size[g] = int(taps.group_size[g])
+    c_taps.n_regs = taps.n_regs
+    c_taps.n_combos = taps.n_combos
+
+
+def make_c_segment(seg: Segment, device_inputs=None):
+    keep = []
+    c = _lib.RkSegment()
+    c.po2 = seg.po2
+    fill_c_taps(c.taps, seg.taps, keep)
+    if device_inputs is not None:
+        groups, check = device_inputs
+        c.on_device = 1
+        for g in range(3):
+            c.group[g] = _ptr(groups[g])
+        c.check = _ptr(check)
+        keep.append(device_inputs)
+    else:
+        c.on_device = 0
+        for g in range(3):
+            a = np.ascontiguousarray(seg.groups[g], dtype=np.uint32)
+            assert a.shape == (seg.taps.group_size[g], seg.rows)
+            keep.append(a)
+            c.group[g] = a.ctypes.data
+        chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
+        assert chk.shape == (4, 4 * seg.rows)
+        keep.append(chk)
+        c.check = chk.ctypes.data
+    gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)
+    keep.append(gl)
+    c.globals = _u32p(gl)
+    c.n_globals = gl.size
+    c.n_accum_mix = seg.n_accum_mix
+    assert len(seg.proof_system_info) == 16 and len(seg.circuit_info) == 16
+    for i in range(16):
+        c.proof_system_info[i] = seg.proof_system_info[i]
+        c.circuit_info[i] = seg.circuit_info[i]
+    return c, keep

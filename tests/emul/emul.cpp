@@ -1,0 +1,121 @@
+// TEST INFRASTRUCTURE: runs the product's host/device-shared code (bb.hpp,
+// ntt_core.hpp, poseidon2_core.hpp) on the CPU, one emulated lane at a time, so
+// the tile/index/twiddle logic of the HIP kernels can be checked against the
+// oracle without a GPU.  The GPU kernels are these same phase functions with
+// __syncthreads() between phases (raiko_amd/csrc/kernels_ntt.hip).
+#include <cstring>
+#include <vector>
+
+#include "bb.hpp"
+#include "ntt_core.hpp"
+#include "poseidon2_core.hpp"
+#include "poseidon2_consts.inc"
+
+namespace {
+std::vector<uint32_t> g_tables;
+ntt::Tables g_tb;
+void ensure_tables() {
+    if (!g_tables.empty()) return;
+    g_tables.resize(ntt::table_layout().total);
+    ntt::fill_tables(g_tables.data());
+    g_tb = ntt::tables_at(g_tables.data());
+}
+p2::Consts consts() {
+    p2::Consts k;
+    std::memcpy(k.rc_ext, P2_RC_EXT_MONT, sizeof k.rc_ext);
+    std::memcpy(k.rc_int, P2_RC_INT_MONT, sizeof k.rc_int);
+    std::memcpy(k.diag, P2_INT_DIAG_MONT, sizeof k.diag);
+    return k;
+}
+template <bool FWD>
+void run_pass(const ntt::PassArgs& a, size_t count, unsigned nthr) {
+    size_t tile = (size_t)1 << (a.g + a.logT);
+    size_t blocks = count * (a.n >> (a.g + a.logT));
+    std::vector<uint32_t> lds(tile);
+    for (size_t blk = 0; blk < blocks; blk++) {
+        ntt::Tile t = ntt::tile_of(a, blk);
+        if (FWD) {
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::fwd_load(a, g_tb, t, lds.data(), tid, nthr);
+            for (unsigned s = a.expand_bits; s < a.g; s++)
+                for (unsigned tid = 0; tid < nthr; tid++) ntt::fwd_stage(a, g_tb, lds.data(), tid, nthr, s);
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::fwd_store(a, t, lds.data(), tid, nthr);
+        } else {
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::rev_load(a, t, lds.data(), tid, nthr);
+            for (unsigned s = 0; s < a.g; s++)
+                for (unsigned tid = 0; tid < nthr; tid++) ntt::rev_stage(a, g_tb, lds.data(), tid, nthr, s);
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::rev_store(a, g_tb, t, lds.data(), tid, nthr);
+        }
+    }
+}
+unsigned log2u(size_t n) {
+    unsigned k = 0;
+    while (((size_t)1 << k) < n) k++;
+    return k;
+}
+}  // namespace
+
+extern "C" {
+
+// mirrors rk::ntt_reverse (kernels_ntt.hip)
+int emul_ntt_reverse(uint32_t* io, size_t size, size_t count, int fuse_zk, unsigned max_tile_log, unsigned nthr) {
+    ensure_tables();
+    unsigned k = log2u(size);
+    if (k == 0) return 0;
+    uint32_t scale = bb::inv(bb::encode((uint32_t)size));
+    ntt::Plan plan = ntt::make_plan(k, max_tile_log);
+    for (unsigned p = 0; p < plan.npass; p++) {
+        ntt::PassArgs a{};
+        a.dst = io; a.src = io; a.n = size; a.n_src = size;
+        a.mu = plan.mu[p]; a.g = plan.g[p]; a.logT = plan.logT[p];
+        bool last = p + 1 == plan.npass;
+        a.scale = last ? scale : 0;
+        a.zk_bits = (last && fuse_zk) ? k : 0;
+        run_pass<false>(a, count, nthr);
+    }
+    return (int)plan.npass;
+}
+// mirrors rk::ntt_forward
+int emul_ntt_forward(uint32_t* out, const uint32_t* in, size_t in_size, size_t count, unsigned expand_bits,
+                     unsigned max_tile_log, unsigned nthr) {
+    ensure_tables();
+    size_t size = in_size << expand_bits;
+    unsigned k = log2u(size);
+    if (k == 0) { std::memcpy(out, in, count * 4); return 0; }
+    if (expand_bits == 0 && out != in) { std::memcpy(out, in, count * size * 4); in = out; }
+    ntt::Plan plan = ntt::make_plan(k, max_tile_log);
+    for (unsigned pi = plan.npass; pi-- > 0;) {
+        ntt::PassArgs a{};
+        bool first = pi + 1 == plan.npass;
+        a.dst = out; a.src = first ? in : out; a.n = size; a.n_src = first ? in_size : size;
+        a.mu = plan.mu[pi]; a.g = plan.g[pi]; a.logT = plan.logT[pi];
+        a.expand_bits = first ? expand_bits : 0;
+        if (first && expand_bits > a.g) return -1;
+        run_pass<true>(a, count, nthr);
+    }
+    return (int)plan.npass;
+}
+void emul_poseidon2_permute(uint32_t* cells) {
+    p2::Consts k = consts();
+    p2::permute(cells, k);
+}
+uint32_t emul_mul(uint32_t a, uint32_t b) { return bb::mul(a, b); }
+uint32_t emul_add(uint32_t a, uint32_t b) { return bb::add(a, b); }
+uint32_t emul_sub(uint32_t a, uint32_t b) { return bb::sub(a, b); }
+uint32_t emul_inv(uint32_t a) { return bb::inv(a); }
+uint32_t emul_encode(uint32_t a) { return bb::encode(a); }
+uint32_t emul_decode(uint32_t a) { return bb::decode(a); }
+void emul_ext_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) {
+    bb::Ext x, y;
+    std::memcpy(x.c, a, 16); std::memcpy(y.c, b, 16);
+    bb::Ext r = bb::mul(x, y);
+    std::memcpy(o, r.c, 16);
+}
+void emul_ext_inv(const uint32_t* a, uint32_t* o) {
+    bb::Ext x;
+    std::memcpy(x.c, a, 16);
+    bb::Ext r = bb::inv(x);
+    std::memcpy(o, r.c, 16);
+}
+uint32_t emul_pow3(uint32_t e) { ensure_tables(); return ntt::pow3(g_tb, e); }
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+"""TEST INFRASTRUCTURE: ctypes binding of the CPU oracle (oracle/_build/liboracle.so) and of the
+CPU lane-emulation of the product's shared kernel code (tests/emul/_build/libemul.so).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+EMUL_DIR = os.path.join(ROOT, "tests", "emul")
+EMUL_SO = os.path.join(EMUL_DIR, "_build", "libemul.so")
+
+P = 2013265921
+u32p = C.POINTER(C.c_uint32)
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h", ".inc"))]
+    if not force and os.path.exists(ORACLE_SO) and all(os.path.getmtime(ORACLE_SO) >= os.path.getmtime(s) for s in srcs):
+        return ORACLE_SO
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    return ORACLE_SO
+
+
+def build_emul(force=False):
+    csrc = os.path.join(ROOT, "raiko_amd", "csrc")
+    srcs = [os.path.join(EMUL_DIR, "emul.cpp")] + [os.path.join(csrc, f) for f in
+                                                   ("bb.hpp", "ntt_core.hpp", "poseidon2_core.hpp", "poseidon2_consts.inc")]
+    if not force and os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs):
+        return EMUL_SO
+    os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", csrc, "-o", EMUL_SO, srcs[0]],
+                   check=True, capture_output=True)
+    return EMUL_SO
+
+
+class OrTaps(C.Structure):
+    _fields_ = [("group_size", C.c_uint32 * 3), ("n_regs", C.c_uint32), ("reg_group", u32p), ("reg_offset", u32p),
+                ("reg_combo", u32p), ("n_combos", C.c_uint32), ("combo_off", u32p), ("combo_backs", u32p)]
+
+
+class OrSegment(C.Structure):
+    _fields_ = [("po2", C.c_uint32), ("taps", OrTaps), ("group", C.c_void_p * 3), ("check", C.c_void_p),
+                ("globals", u32p), ("n_globals", C.c_uint32), ("n_accum_mix", C.c_uint32),
+                ("proof_system_info", C.c_uint8 * 16), ("circuit_info", C.c_uint8 * 16)]
+
+
+class OrTiming(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ntt", "hash", "deep", "fri", "query", "total")]
+
+
+_oracle = None
+_emul = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(build_oracle())
+        sz, u32, vp = C.c_size_t, C.c_uint32, C.c_void_p
+        sig = {
+            "or_fp_mul": (u32, [u32, u32]), "or_fp_add": (u32, [u32, u32]), "or_fp_sub": (u32, [u32, u32]),
+            "or_fp_inv": (u32, [u32]), "or_fp_encode": (u32, [u32]), "or_fp_decode": (u32, [u32]),
+            "or_fp4_mul": (None, [u32p, u32p, u32p]), "or_fp4_inv": (None, [u32p, u32p]),
+            "or_rou_fwd": (u32, [C.c_uint]), "or_rou_rev": (u32, [C.c_uint]),
+            "or_bit_reverse": (None, [vp, sz]), "or_interpolate_ntt": (None, [vp, sz]),
+            "or_evaluate_ntt": (None, [vp, sz, C.c_uint]),
+            "or_poseidon2_mix": (None, [vp]), "or_hash_elem_slice": (None, [vp, sz, sz, vp]),
+            "or_hash_pair": (None, [vp, vp, vp]),
+            "or_batch_interpolate_ntt": (None, [vp, sz, sz]), "or_batch_evaluate_ntt": (None, [vp, sz, sz, C.c_uint]),
+            "or_zk_shift": (None, [vp, sz, sz]),
+            "or_batch_expand_into_evaluate_ntt": (None, [vp, vp, sz, sz, C.c_uint]),
+            "or_batch_bit_reverse": (None, [vp, sz, sz]), "or_hash_rows": (None, [vp, vp, sz, sz]),
+            "or_hash_fold": (None, [vp, sz, sz]),
+            "or_batch_evaluate_any": (None, [vp, sz, vp, vp, sz, vp]),
+            "or_mix_poly_coeffs": (None, [vp, vp, vp, vp, vp, sz, sz]),
+            "or_eltwise_add_elem": (None, [vp, vp, vp, sz]), "or_eltwise_sum_extelem": (None, [vp, vp, sz, sz]),
+            "or_eltwise_copy_elem": (None, [vp, vp, sz]), "or_eltwise_zeroize_elem": (None, [vp, sz]),
+            "or_fri_fold": (None, [vp, vp, sz, vp]), "or_gather_sample": (None, [vp, vp, sz, sz, sz]),
+            "or_poly_interpolate": (None, [vp, vp, vp, sz]), "or_poly_divide": (None, [vp, sz, vp, vp]),
+            "or_poly_eval": (None, [vp, sz, vp, vp]),
+            "or_prove_segment": (C.c_int, [C.POINTER(OrSegment), C.POINTER(u32p), C.POINTER(sz), C.c_int]),
+            "or_verify_segment": (C.c_int, [C.POINTER(OrSegment), u32p, sz]),
+            "or_free": (None, [vp]), "or_max_threads": (C.c_int, []),
+            "or_last_timing": (None, [C.POINTER(OrTiming)]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _oracle = lib
+    return _oracle
+
+
+def emul():
+    global _emul
+    if _emul is None:
+        lib = C.CDLL(build_emul())
+        sz, u32, vp = C.c_size_t, C.c_uint32, C.c_void_p
+        lib.emul_ntt_reverse.restype = C.c_int
+        lib.emul_ntt_reverse.argtypes = [vp, sz, sz, C.c_int, C.c_uint, C.c_uint]
+        lib.emul_ntt_forward.restype = C.c_int
+        lib.emul_ntt_forward.argtypes = [vp, vp, sz, sz, C.c_uint, C.c_uint, C.c_uint]
+        lib.emul_poseidon2_permute.restype = None
+        lib.emul_poseidon2_permute.argtypes = [vp]
+        for n in ("emul_mul", "emul_add", "emul_sub"):
+            getattr(lib, n).restype = u32
+            getattr(lib, n).argtypes = [u32, u32]
+        for n in ("emul_inv", "emul_encode", "emul_decode", "emul_pow3"):
+            getattr(lib, n).restype = u32
+            getattr(lib, n).argtypes = [u32]
+        lib.emul_ext_mul.restype = None
+        lib.emul_ext_mul.argtypes = [vp, vp, vp]
+        lib.emul_ext_inv.restype = None
+        lib.emul_ext_inv.argtypes = [vp, vp]
+        _emul = lib
+    return _emul
+
+
+# ---- numpy helpers (exact integer arithmetic, independent of both C implementations) ----
+R = 1 << 32
+
+
+def to_mont(x):
+    """canonical -> Montgomery, exact via Python ints / uint64"""
+    a = np.asarray(x, dtype=np.uint64)
+    return ((a % P) * ((R % P)) % P).astype(np.uint32)
+
+
+def from_mont(x):
+    a = np.asarray(x, dtype=np.uint64)
+    rinv = pow(R, -1, P)
+    return (a * rinv % P).astype(np.uint32)
+
+
+def rand_elems(rng, shape):
+    return rng.integers(0, P, size=shape, dtype=np.uint32)
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data
+
+
+def make_or_segment(seg):
+    """raiko_amd.segment.Segment -> (OrSegment, keepalive list)"""
+    keep = []
+    c = OrSegment()
+    c.po2 = seg.po2
+    t = seg.taps
+    for name in ("reg_group", "reg_offset", "reg_combo", "combo_off", "combo_backs"):
+        a = np.ascontiguousarray(getattr(t, name), dtype=np.uint32)
+        keep.append(a)
+        setattr(c.taps, name, a.ctypes.data_as(u32p))
+    for g in range(3):
+        c.taps.group_size[g] = int(t.group_size[g])
+        a = np.ascontiguousarray(seg.groups[g], dtype=np.uint32)
+        keep.append(a)
+        c.group[g] = a.ctypes.data
+    c.taps.n_regs = t.n_regs
+    c.taps.n_combos = t.n_combos
+    chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
+    keep.append(chk)
+    c.check = chk.ctypes.data
+    gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)
+    keep.append(gl)
+    c.globals = gl.ctypes.data_as(u32p)
+    c.n_globals = gl.size
+    c.n_accum_mix = seg.n_accum_mix
+    for i in range(16):
+        c.proof_system_info[i] = seg.proof_system_info[i]
+        c.circuit_info[i] = seg.circuit_info[i]
+    return c, keep
+
+
+def oracle_prove(seg, threads=0):
+    lib = oracle()
+    c, keep = make_or_segment(seg)
+    seal = u32p()
+    n = C.c_size_t(0)
+    rc = lib.or_prove_segment(C.byref(c), C.byref(seal), C.byref(n), threads)
+    if rc != 0:
+        raise RuntimeError(f"or_prove_segment failed: {rc}")
+    out = np.ctypeslib.as_array(seal, shape=(n.value,)).copy()
+    lib.or_free(seal)
+    del keep
+    return out
+
+
+def oracle_verify(seg, seal) -> int:
+    lib = oracle()
+    c, keep = make_or_segment(seg)
+    s = np.ascontiguousarray(seal, dtype=np.uint32)
+    rc = lib.or_verify_segment(C.byref(c), s.ctypes.data_as(u32p), s.size)
+    del keep
+    return rc
+
+
+def oracle_timing() -> dict:
+    t = OrTiming()
+    oracle().or_last_timing(C.byref(t))
+    return {n: getattr(t, n) for n, _ in t._fields_}
