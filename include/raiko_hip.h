@@ -134,6 +134,23 @@ size_t rk_seal_bound_words(const rk_segment* seg);
 typedef struct { float ntt, hash, deep, fri, query, total; } rk_timing;
 int rk_last_timing(rk_ctx* ctx, rk_timing* out);
 
+/* ---- per-kernel-class timing (for bench.py's roofline object) ----
+ * When enabled every launch of a class is bracketed by a hipEvent pair on the ctx stream;
+ * rk_kernel_stats synchronises the stream and returns launches, total device milliseconds and
+ * total ALGORITHMIC bytes (what the launch must read + write once) since the last reset. */
+typedef enum {
+    RK_KCLASS_HASH_ROWS = 0,   /* hash_rows_kernel */
+    RK_KCLASS_HASH_FOLD = 1,   /* hash_fold_kernel */
+    RK_KCLASS_NTT_PASS = 2,    /* ntt_pass_kernel<fwd|rev> */
+    RK_KCLASS_BIT_REVERSE = 3, /* bit_reverse_kernel */
+    RK_KCLASS_POLY = 4,        /* mix / eval / divide / fold / sum kernels */
+    RK_KCLASS_COUNT = 5
+} rk_kclass;
+typedef struct { uint64_t launches; double ms; double bytes; } rk_kernel_stat;
+int rk_set_kernel_timing(rk_ctx* ctx, int enabled);   /* also resets the counters */
+int rk_kernel_stats(rk_ctx* ctx, int kclass, rk_kernel_stat* out);
+const char* rk_kernel_class_name(int kclass);
+
 #ifdef __cplusplus
 }
 #endif

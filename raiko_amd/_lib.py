@@ -51,6 +51,13 @@ class RkSegment(C.Structure):
     ]
 
 
+class RkKernelStat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double)]
+
+
+KCLASS_COUNT = 5
+
+
 class RkTiming(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ntt", "hash", "deep", "fri", "query", "total")]
 
@@ -90,6 +97,9 @@ SYMBOLS = {
     "rk_prove_segment": (C.c_int, [_vp, C.POINTER(RkSegment), u32p, _sz, C.POINTER(_sz)]),
     "rk_seal_bound_words": (_sz, [C.POINTER(RkSegment)]),
     "rk_last_timing": (C.c_int, [_vp, C.POINTER(RkTiming)]),
+    "rk_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
+    "rk_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(RkKernelStat)]),
+    "rk_kernel_class_name": (C.c_char_p, [C.c_int]),
 }
 
 _lib = None

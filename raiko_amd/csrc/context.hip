@@ -63,6 +63,40 @@ int scratch(rk_ctx* ctx, size_t bytes, void** out) {
     return RK_OK;
 }
 
+KTimer::KTimer(rk_ctx* c, int cls, double bytes) : ctx(c), idx(-1) {
+    if (!c->ktime_on) return;
+    if (c->krec_used == c->krecs.size()) {
+        rk_ctx::KRec r{};
+        if (hipEventCreate(&r.a) != hipSuccess) return;
+        if (hipEventCreate(&r.b) != hipSuccess) {
+            (void)hipEventDestroy(r.a);
+            return;
+        }
+        c->krecs.push_back(r);
+    }
+    idx = (int)c->krec_used++;
+    c->krecs[idx].cls = cls;
+    c->krecs[idx].bytes = bytes;
+    (void)hipEventRecord(c->krecs[idx].a, c->stream);
+}
+KTimer::~KTimer() {
+    if (idx >= 0) (void)hipEventRecord(ctx->krecs[idx].b, ctx->stream);
+}
+
+// fold finished event pairs into the per-class totals (stream must be idle)
+static void ktime_collect(rk_ctx* ctx) {
+    for (size_t i = 0; i < ctx->krec_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->krecs[i].a, ctx->krecs[i].b) == hipSuccess) {
+            int c = ctx->krecs[i].cls;
+            ctx->k_ms[c] += ms;
+            ctx->k_bytes[c] += ctx->krecs[i].bytes;
+            ctx->k_launches[c] += 1;
+        }
+    }
+    ctx->krec_used = 0;
+}
+
 static int build_tables(rk_ctx* ctx) {
     const ntt::TableLayout l = ntt::table_layout();
     std::vector<uint32_t> h(l.total);
@@ -146,6 +180,10 @@ int rk_ctx_destroy(rk_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    for (auto& r : ctx->krecs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_p2) (void)hipFree(ctx->d_p2);
@@ -201,6 +239,40 @@ int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t*
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     RK_HIP_TRY(ctx, hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice));
     return RK_OK;
+}
+
+int rk_set_kernel_timing(rk_ctx* ctx, int enabled) {
+    if (!ctx) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->krec_used = 0;
+    for (int c = 0; c < RK_KCLASS_COUNT; c++) {
+        ctx->k_ms[c] = 0;
+        ctx->k_bytes[c] = 0;
+        ctx->k_launches[c] = 0;
+    }
+    ctx->ktime_on = enabled != 0;
+    return RK_OK;
+}
+int rk_kernel_stats(rk_ctx* ctx, int kclass, rk_kernel_stat* out) {
+    if (!ctx || !out || kclass < 0 || kclass >= RK_KCLASS_COUNT) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rk::ktime_collect(ctx);
+    out->launches = ctx->k_launches[kclass];
+    out->ms = ctx->k_ms[kclass];
+    out->bytes = ctx->k_bytes[kclass];
+    return RK_OK;
+}
+const char* rk_kernel_class_name(int kclass) {
+    switch (kclass) {
+        case RK_KCLASS_HASH_ROWS: return "hash_rows_kernel";
+        case RK_KCLASS_HASH_FOLD: return "hash_fold_kernel";
+        case RK_KCLASS_NTT_PASS: return "ntt_pass_kernel";
+        case RK_KCLASS_BIT_REVERSE: return "bit_reverse_kernel";
+        case RK_KCLASS_POLY: return "poly kernels (mix/eval/divide/fold/sum)";
+        default: return "?";
+    }
 }
 
 int rk_last_timing(rk_ctx* ctx, rk_timing* out) {

@@ -35,6 +35,19 @@ struct rk_ctx {
     size_t scratch_bytes = 0;
 
     rk_timing timing{};
+
+    // optional per-kernel-class timing (hipEvent pairs on the ctx stream, resolved lazily)
+    bool ktime_on = false;
+    struct KRec {
+        hipEvent_t a, b;
+        int cls;
+        double bytes;
+    };
+    std::vector<KRec> krecs;
+    size_t krec_used = 0;
+    double k_ms[RK_KCLASS_COUNT] = {0};
+    double k_bytes[RK_KCLASS_COUNT] = {0};
+    uint64_t k_launches[RK_KCLASS_COUNT] = {0};
 };
 
 #define RK_HIP_TRY(ctx, expr)                                                                   \
@@ -59,6 +72,14 @@ static inline unsigned log2u(size_t n) {
 }
 
 namespace rk {
+
+// per-kernel-class timing (context.hip): bracket a launch; no-ops unless enabled
+struct KTimer {
+    rk_ctx* ctx;
+    int idx;
+    KTimer(rk_ctx* c, int cls, double algorithmic_bytes);
+    ~KTimer();
+};
 
 // memory (context.hip)
 int dev_alloc(rk_ctx* ctx, size_t bytes, void** out);

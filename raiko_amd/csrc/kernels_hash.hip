@@ -60,6 +60,7 @@ int hash_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_matrix, size_t row
     if (rows == 0) return RK_ERR_INVALID;
     size_t blocks = (rows + HASH_BLOCK - 1) / HASH_BLOCK;
     if (blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    KTimer kt(ctx, RK_KCLASS_HASH_ROWS, (double)rows * cols * 4 + (double)rows * 32);
     hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_out, d_matrix, rows,
                        cols, ctx->d_p2);
     return post_launch(ctx, "hash_rows_kernel");
@@ -69,6 +70,7 @@ int hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t output_size) {
     if (output_size == 0) return RK_ERR_INVALID;
     size_t blocks = (output_size + HASH_BLOCK - 1) / HASH_BLOCK;
     if (blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)output_size * 96);
     hipLaunchKernelGGL(hash_fold_kernel, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_nodes, output_size,
                        ctx->d_p2);
     return post_launch(ctx, "hash_fold_kernel");

@@ -62,6 +62,7 @@ int launch_pass(rk_ctx* ctx, const ntt::PassArgs& a, size_t count) {
     unsigned threads = tile / 2 >= 1024 ? 1024 : (unsigned)(tile / 2);
     if (threads < 64) threads = 64;
     size_t lds_bytes = tile * sizeof(uint32_t);
+    rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)count * 4 * ((a.expand_bits ? a.n_src : a.n) + a.n));
     hipLaunchKernelGGL(ntt_pass_kernel<FWD>, dim3((unsigned)blocks), dim3(threads), lds_bytes, ctx->stream, a, ctx->tb);
     return rk::post_launch(ctx, FWD ? "ntt_pass_kernel<fwd>" : "ntt_pass_kernel<rev>");
 }
@@ -137,6 +138,7 @@ int zk_shift(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count) {
     if (!is_pow2(size) || size > ((size_t)1 << ntt::LAMBDA) || count == 0) return RK_ERR_INVALID;
     size_t total = size * count;
     unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)total * 8);
     hipLaunchKernelGGL(zk_shift_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_io, total, size, log2u(size), ctx->tb);
     return post_launch(ctx, "zk_shift_kernel");
 }
@@ -146,6 +148,7 @@ int bit_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count) {
     if (size <= 2) return RK_OK;
     size_t total = size * count;
     unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    KTimer kt(ctx, RK_KCLASS_BIT_REVERSE, (double)total * 8);
     hipLaunchKernelGGL(bit_reverse_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_io, total, size, log2u(size));
     return post_launch(ctx, "bit_reverse_kernel");
 }

@@ -237,6 +237,7 @@ int eltwise_zeroize(rk_ctx* ctx, uint32_t* d_io, size_t n) {
 }
 int eltwise_sum_ext(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add) {
     if (count == 0) return RK_OK;
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)count * (to_add + 1) * 16);
     hipLaunchKernelGGL(sum_ext_kernel, dim3(grid_for(count)), dim3(TPB), 0, ctx->stream, d_out, d_in, count, to_add);
     return post_launch(ctx, "sum_ext_kernel");
 }
@@ -245,6 +246,7 @@ int fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_coun
     FoldPows pw;
     pw.p[0] = bb::ext_one();
     for (int i = 1; i < 16; i++) pw.p[i] = bb::mul(pw.p[i - 1], mix);
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)out_count * 17 * 16);
     hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(out_count)), dim3(TPB), 0, ctx->stream, d_out, d_in, out_count, pw);
     return post_launch(ctx, "fri_fold_kernel");
 }
@@ -272,6 +274,7 @@ int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const 
 int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n) {
     if (n == 0) return RK_OK;
     size_t lanes = (n + PW_CH - 1) / PW_CH;
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)n * 16);
     hipLaunchKernelGGL(ext_powers_kernel, dim3((unsigned)((lanes + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_pw_ext,
                        x, n);
     return post_launch(ctx, "ext_powers_kernel");
@@ -282,6 +285,7 @@ int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t 
     if (eval_count > 65535) return RK_ERR_INVALID;
     void* partial = nullptr;
     RK_TRY(dev_alloc(ctx, eval_count * DOT_BLOCKS * 16, &partial));
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)eval_count * size * 20);
     hipLaunchKernelGGL(eval_dot_kernel, dim3(DOT_BLOCKS, (unsigned)eval_count), dim3(TPB), 0, ctx->stream,
                        (uint32_t*)partial, d_coeffs, size, d_which, d_pw_ext, d_pw_sel);
     int st = post_launch(ctx, "eval_dot_kernel");
@@ -335,6 +339,7 @@ int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, 
     RK_HIP_TRY(ctx, hipMemcpyAsync(d, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack is a stack-lifetime host buffer
     const uint32_t* dp = (const uint32_t*)d;
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)count * (input_size * 4 + n_slots * 32));
     hipLaunchKernelGGL(mix_kernel, dim3(grid_for(count, 4096), (unsigned)n_slots), dim3(TPB), 0, ctx->stream, d_out_ext,
                        d_in, count, dp + o_combo, dp + o_off, dp + o_cols, dp + o_pows);
     return post_launch(ctx, "mix_kernel");
@@ -350,6 +355,7 @@ int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& 
     uint32_t* rem = carry + nchunks * 4;
     bb::Ext zL = bb::pow(z, (uint64_t)DIV_CH);
     unsigned blocks = (unsigned)((nchunks + TPB - 1) / TPB);
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)count * 48);
     hipLaunchKernelGGL(div_tops_kernel, dim3(blocks), dim3(TPB), 0, ctx->stream, tops, d_poly_ext, count, z);
     int st = post_launch(ctx, "div_tops_kernel");
     if (st == RK_OK) {

@@ -209,7 +209,6 @@ inline Plan make_plan(unsigned k, unsigned max_tile_log = MAX_TILE_LOG) {
 struct TableLayout {
     size_t small[2], hi[2], lo[2], pow3_hi, pow3_lo, total;
 };
-#if !defined(__HIP_DEVICE_COMPILE__)
 inline TableLayout table_layout() {
     const size_t n_small = (size_t)1 << (KS - 1);
     const size_t n_hi = (size_t)1 << (LAMBDA - TW_SPLIT);
@@ -263,6 +262,5 @@ inline Tables tables_at(const uint32_t* base) {
     t.pow3_lo = base + l.pow3_lo;
     return t;
 }
-#endif
 
 }  // namespace ntt

@@ -186,6 +186,19 @@ class HipHal:
         del keep
         return seal[:words.value].copy()
 
+    def set_kernel_timing(self, enabled: bool):
+        self._ck(self._lib.rk_set_kernel_timing(self._ctx, 1 if enabled else 0))
+
+    def kernel_stats(self) -> dict:
+        """{kernel class name: {launches, ms, bytes}} since set_kernel_timing(True)"""
+        out = {}
+        for k in range(_lib.KCLASS_COUNT):
+            st = _lib.RkKernelStat()
+            self._ck(self._lib.rk_kernel_stats(self._ctx, k, C.byref(st)))
+            out[self._lib.rk_kernel_class_name(k).decode()] = {
+                "launches": int(st.launches), "ms": float(st.ms), "bytes": float(st.bytes)}
+        return out
+
     def last_timing(self) -> dict:
         t = _lib.RkTiming()
         self._ck(self._lib.rk_last_timing(self._ctx, C.byref(t)))
