@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/raiko_hip.h declares
+(no compute calls: there is no GPU here), and refuses to pretend otherwise."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "raiko_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from raiko_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "library does not export " + n
+        assert n in _lib.SYMBOLS, "no ctypes prototype for " + n
+    assert sorted(_lib.SYMBOLS) == names
+    assert lib.rk_abi_version() == 1
+    assert lib.rk_strerror(-1) == b"invalid argument"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from raiko_amd import _lib
+    from raiko_amd.hal import HipHal
+    lib = _lib.load()
+    n = C.c_int(-1)
+    st = lib.rk_device_count(C.byref(n))
+    if st == 0 and n.value > 0:
+        pytest.skip("a GPU is visible: this check is for CPU-only boxes")
+    with pytest.raises(_lib.HipLibraryError):
+        HipHal(0)
+    ctx = C.c_void_p()
+    assert lib.rk_ctx_create(0, None, C.byref(ctx)) == -4  # RK_ERR_NODEVICE
+    assert not ctx.value
+
+
+def test_product_never_imports_the_oracle():
+    """the product package must not reference oracle/ or the tests' oracle binding"""
+    pkg = os.path.join(ROOT, "raiko_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("(oracle/", "(x/"), f

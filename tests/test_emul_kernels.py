@@ -1,0 +1,87 @@
+"""The product's host/device-shared kernel code (raiko_amd/csrc/{bb,ntt_core,poseidon2_core}.hpp)
+run lane by lane on the CPU and compared with the oracle.  This exercises the exact tile / index /
+twiddle logic the HIP kernels execute (same phase functions, barriers replaced by phase order)."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+
+P = o.P
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 9, 11, 13])
+@pytest.mark.parametrize("max_tile_log,nthr", [(2, 4), (3, 2), (5, 8), (14, 64)])
+def test_ntt_passes_match_oracle(orc, emu, k, max_tile_log, nthr):
+    rng = np.random.default_rng(1000 * k + max_tile_log)
+    n, cnt = 1 << k, 3
+    x = o.rand_elems(rng, (cnt, n))
+    want = x.copy()
+    orc.or_batch_interpolate_ntt(want.ctypes.data, n, cnt)
+    got = x.copy()
+    npass = emu.emul_ntt_reverse(got.ctypes.data, n, cnt, 0, max_tile_log, nthr)
+    assert npass >= 1 and np.array_equal(got, want)
+    if k > max_tile_log:
+        assert npass >= 2  # the multi-pass (four-step twiddle) path is what is being tested
+    # fused zk-shift
+    want_zk = want.copy()
+    orc.or_zk_shift(want_zk.ctypes.data, n, cnt)
+    got_zk = x.copy()
+    emu.emul_ntt_reverse(got_zk.ctypes.data, n, cnt, 1, max_tile_log, nthr)
+    assert np.array_equal(got_zk, want_zk)
+    # expanding forward transform (LDE) and plain forward transform
+    want_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(want_e.ctypes.data, want_zk.ctypes.data, n, cnt, 2)
+    got_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
+    assert emu.emul_ntt_forward(got_e.ctypes.data, got_zk.ctypes.data, n, cnt, 2, max(max_tile_log, 2), nthr) >= 1
+    assert np.array_equal(got_e, want_e)
+    back = want.copy()
+    emu.emul_ntt_forward(back.ctypes.data, back.ctypes.data, n, cnt, 0, max_tile_log, nthr)
+    assert np.array_equal(back, x)
+
+
+def test_three_pass_plan(orc, emu):
+    """sizes that need two strided passes + the contiguous one"""
+    rng = np.random.default_rng(77)
+    k, mtl = 14, 3  # 11 outer stages -> two strided passes of <= 8 stages
+    n = 1 << k
+    x = o.rand_elems(rng, (1, n))
+    want = x.copy()
+    orc.or_batch_interpolate_ntt(want.ctypes.data, n, 1)
+    got = x.copy()
+    assert emu.emul_ntt_reverse(got.ctypes.data, n, 1, 0, mtl, 16) == 3
+    assert np.array_equal(got, want)
+    out_w = np.zeros((1, 4 * n), dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(out_w.ctypes.data, want.ctypes.data, n, 1, 2)
+    out_g = np.zeros((1, 4 * n), dtype=np.uint32)
+    emu.emul_ntt_forward(out_g.ctypes.data, got.ctypes.data, n, 1, 2, mtl, 16)
+    assert np.array_equal(out_g, out_w)
+
+
+def test_field_and_poseidon2_host_code(orc, emu):
+    rng = np.random.default_rng(5)
+    for a, b in rng.integers(0, P, (500, 2)):
+        a, b = int(a), int(b)
+        assert emu.emul_mul(a, b) == orc.or_fp_mul(a, b)
+        assert emu.emul_add(a, b) == orc.or_fp_add(a, b)
+        assert emu.emul_sub(a, b) == orc.or_fp_sub(a, b)
+    for a in [0, 1, P - 1] + [int(v) for v in rng.integers(0, P, 50)]:
+        assert emu.emul_encode(a) == orc.or_fp_encode(a)
+        assert emu.emul_decode(a) == orc.or_fp_decode(a)
+        if a:
+            assert emu.emul_inv(a) == orc.or_fp_inv(a)
+    for e in [0, 1, 5, 4095, 4096, 4097, (1 << 20) - 1, (1 << 24) - 1]:
+        assert orc.or_fp_decode(emu.emul_pow3(e)) == pow(3, e, P)
+    for _ in range(20):
+        st = o.rand_elems(rng, (24,))
+        s1, s2 = st.copy(), st.copy()
+        orc.or_poseidon2_mix(s1.ctypes.data)
+        emu.emul_poseidon2_permute(s2.ctypes.data)
+        assert np.array_equal(s1, s2)
+        a, b = o.rand_elems(rng, (4,)), o.rand_elems(rng, (4,))
+        r1, r2 = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+        orc.or_fp4_mul(a.ctypes.data_as(o.u32p), b.ctypes.data_as(o.u32p), r1.ctypes.data_as(o.u32p))
+        emu.emul_ext_mul(a.ctypes.data, b.ctypes.data, r2.ctypes.data)
+        assert np.array_equal(r1, r2)
+        orc.or_fp4_inv(a.ctypes.data_as(o.u32p), r1.ctypes.data_as(o.u32p))
+        emu.emul_ext_inv(a.ctypes.data, r2.ctypes.data)
+        assert np.array_equal(r1, r2)
