@@ -1,0 +1,249 @@
+"""`HipProver`: the host-side mirror of raiko's `Prover` plugin interface for the HIP backend.
+
+Reference interface (Champii/raiko @ 2024-08-07):
+  * `trait Prover { async fn run(input, output, config, store) -> ProverResult<Proof>;
+                    async fn cancel(proof_key, read) -> ProverResult<()> }`   lib/src/prover.rs:52-62
+  * `Proof { proof, quote, kzg_proof }`                                       lib/src/prover.rs:29-38
+  * `ProverError::{GuestError, FileIo, Param, StoreError}`                    lib/src/prover.rs:7-23
+  * `Risc0Param { bonsai, snark, profile, execution_po2 }` read from
+    `config["risc0"]`                                                         provers/risc0/driver/src/lib.rs:27-34,63
+  * `Risc0Prover::run` / `maybe_prove` / `prove_locally`                      provers/risc0/driver/src/lib.rs:56-112,
+                                                                              bonsai.rs:89-181, bonsai.rs:230-272
+
+The reference toolchain (Rust) is absent from this image, so the host side above the C ABI is
+Python here; INTEGRATION.md shows the Rust `provers/hip` crate a maintainer would add.  What is
+NOT here because its source is not in the reference tree: the RV32IM executor, witness
+generation and the rv32im constraint evaluator -- a `Session` therefore arrives already executed
+(segments + journal), the point where `session.prove()` (bonsai.rs:271) starts.
+
+Differences from the reference driver, on purpose:
+  * errors are returned as `ProverError`, never panics (the reference `unwrap()`s at
+    lib.rs:63,71,84 and bonsai.rs:266-271, leaving the task row at WorkInProgress);
+  * the receipt cache lives in a per-process directory instead of the shared, wiped
+    `/tmp/risc0-cache` (bonsai.rs:261-265 is a latent race under `concurrency_limit` = 16).
+"""
+import hashlib
+import json
+import os
+import struct
+import tempfile
+import threading
+from dataclasses import dataclass, field
+from typing import Any, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .segment import Segment
+
+RISC0_PROVER_CODE = 3  # provers/risc0/driver/src/lib.rs:53; `hip` answers to proof_type "risc0"
+
+
+class ProverError(Exception):
+    """lib/src/prover.rs:7-23"""
+
+    kind = "GuestError"
+
+    def __str__(self):
+        return "ProverError::%s `%s`" % (self.kind, self.args[0] if self.args else "")
+
+
+class GuestError(ProverError):
+    kind = "GuestError"
+
+
+class FileIo(ProverError):
+    kind = "FileIo"
+
+
+class Param(ProverError):
+    kind = "Param"
+
+
+class StoreError(ProverError):
+    kind = "StoreError"
+
+    def __str__(self):
+        return "Store error `%s`" % (self.args[0] if self.args else "")
+
+
+@dataclass
+class Proof:
+    """The response body of a proof request (lib/src/prover.rs:29-38)."""
+
+    proof: Optional[str] = None
+    quote: Optional[str] = None
+    kzg_proof: Optional[str] = None
+
+    def to_json(self) -> dict:
+        return {"proof": self.proof, "quote": self.quote, "kzg_proof": self.kzg_proof}
+
+
+@dataclass
+class Risc0Param:
+    bonsai: bool
+    snark: bool
+    profile: bool
+    execution_po2: int
+
+    @staticmethod
+    def deserialize(value: Any) -> "Risc0Param":
+        if not isinstance(value, dict):
+            raise Param("risc0 options must be an object")
+        try:
+            out = Risc0Param(bonsai=value["bonsai"], snark=value["snark"], profile=value["profile"],
+                             execution_po2=value["execution_po2"])
+        except KeyError as e:
+            raise Param("missing field `%s`" % e.args[0])
+        for name in ("bonsai", "snark", "profile"):
+            if not isinstance(getattr(out, name), bool):
+                raise Param("invalid type for `%s`: expected a boolean" % name)
+        if isinstance(out.execution_po2, bool) or not isinstance(out.execution_po2, int) or out.execution_po2 < 0:
+            raise Param("invalid type for `execution_po2`: expected u32")
+        return out
+
+
+@dataclass
+class Session:
+    """What `ExecutorImpl::run()` returns (bonsai.rs:267-269): the executed segments and the journal."""
+
+    segments: List[Segment]
+    journal: bytes
+    image_id: bytes = b"\0" * 32
+
+    @property
+    def total_cycles(self) -> int:
+        return sum(s.cycles for s in self.segments)
+
+
+@dataclass
+class Receipt:
+    """Composite receipt: one seal per segment + the journal (risc0 `ReceiptKind::Composite`)."""
+
+    seals: List[np.ndarray]
+    journal: bytes
+    po2: List[int] = field(default_factory=list)
+
+    MAGIC = b"RKHIPZKP1"
+
+    def to_bytes(self) -> bytes:
+        hdr = json.dumps({"journal": self.journal.hex(), "po2": self.po2, "words": [int(s.size) for s in self.seals]}).encode()
+        body = b"".join(np.ascontiguousarray(s, dtype="<u4").tobytes() for s in self.seals)
+        return self.MAGIC + struct.pack("<I", len(hdr)) + hdr + body
+
+    @staticmethod
+    def from_bytes(b: bytes) -> "Receipt":
+        if not b.startswith(Receipt.MAGIC):
+            raise FileIo("not a raiko-hip receipt")
+        o = len(Receipt.MAGIC)
+        (n,) = struct.unpack_from("<I", b, o)
+        hdr = json.loads(b[o + 4:o + 4 + n])
+        o += 4 + n
+        seals = []
+        for w in hdr["words"]:
+            seals.append(np.frombuffer(b, dtype="<u4", count=w, offset=o).copy())
+            o += 4 * w
+        return Receipt(seals=seals, journal=bytes.fromhex(hdr["journal"]), po2=hdr["po2"])
+
+
+_CACHE_DIR = None
+_DEVICE_LOCK = threading.Lock()  # `run` may be entered from up to concurrency_limit threads (host/src/lib.rs:38-41)
+_HAL = {}
+
+
+def _cache_dir() -> str:
+    global _CACHE_DIR
+    if _CACHE_DIR is None:
+        _CACHE_DIR = tempfile.mkdtemp(prefix="raiko-hip-cache-")
+    return _CACHE_DIR
+
+
+def zkp_cache_path(label: str) -> str:
+    """bonsai.rs:304-310, with a private directory"""
+    return os.path.join(_cache_dir(), label + ".zkp")
+
+
+def save_receipt(label: str, receipt: Receipt) -> None:
+    try:
+        with open(zkp_cache_path(label), "wb") as f:
+            f.write(receipt.to_bytes())
+    except OSError as e:
+        raise FileIo(str(e))
+
+
+def load_receipt(label: str) -> Optional[Receipt]:
+    try:
+        with open(zkp_cache_path(label), "rb") as f:
+            return Receipt.from_bytes(f.read())
+    except OSError:
+        return None
+
+
+def _hal(device: int):
+    from .hal import HipHal  # raises HipLibraryError when the library / GPU is missing: no fallback
+    if device not in _HAL:
+        _HAL[device] = HipHal(device)
+    return _HAL[device]
+
+
+def prove_locally(segment_limit_po2: int, session: Session, device: int = 0) -> Receipt:
+    """bonsai.rs:230-272 from the point the executor has produced the session: prove every
+    segment (this rank's shard when torch.distributed is initialised) and assemble the receipt."""
+    from . import dist as rdist
+    for s in session.segments:
+        if s.po2 > segment_limit_po2:
+            raise GuestError("segment of 2^%d cycles exceeds segment_limit_po2 = %d" % (s.po2, segment_limit_po2))
+    rank, world = 0, 1
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            rank, world = tdist.get_rank(), tdist.get_world_size()
+    except ImportError:
+        pass
+    mine = rdist.shard_indices(len(session.segments), rank, world)
+    with _DEVICE_LOCK:
+        hal = _hal(device)
+        try:
+            local = [hal.prove_segment(session.segments[i]) for i in mine]
+        except Exception as e:  # RkError etc.: surface as GuestError like `From<String>` (prover.rs:19-23)
+            raise GuestError(str(e))
+    seals = rdist.gather_seals(local, len(session.segments)) if world > 1 else local
+    if seals is None:  # non-root rank of a sharded proof
+        seals = []
+    return Receipt(seals=list(seals), journal=session.journal, po2=[s.po2 for s in session.segments])
+
+
+class HipProver:
+    """Unit struct with associated functions, like `Risc0Prover` (lib.rs:51)."""
+
+    @staticmethod
+    def run(input: Any, output: Any, config: Any, store: Any = None) -> Proof:
+        """`input` must expose `.session` (a `Session`) and `.chain_spec.chain_id`; `output.hash` is the
+        32-byte expected journal; `config` is the whole request JSON (core/src/lib.rs:107)."""
+        if not isinstance(config, dict) or "risc0" not in config:
+            raise Param("missing `risc0` options in the proof request")
+        param = Risc0Param.deserialize(config["risc0"])
+        if param.bonsai:
+            raise GuestError("the hip backend proves locally; bonsai = true is not available")
+        if param.snark:
+            raise GuestError("No STARK->SNARK (Groth16) stage in the hip backend")
+        session = getattr(input, "session", None)
+        if not isinstance(session, Session):
+            raise GuestError("input carries no executed session (the RV32IM executor is outside this backend)")
+        expected = bytes(output.hash)
+        label = session.image_id.hex() + "-" + hashlib.sha3_256(expected).hexdigest()
+        receipt = load_receipt(label)
+        if receipt is None:
+            receipt = prove_locally(param.execution_po2, session, device=int(config.get("hip", {}).get("device", 0)))
+            if receipt.seals:
+                save_receipt(label, receipt)
+        # bonsai.rs:157-162: a journal mismatch is logged, not fatal
+        HipProver.last_journal_matches = receipt.journal == expected
+        return Proof(proof=receipt.journal.hex(), quote=None, kzg_proof=None)
+
+    last_journal_matches = None
+
+    @staticmethod
+    def cancel(proof_key: Tuple[int, bytes, int], read: Any) -> None:
+        """A local proof cannot be interrupted (same as the SGX backend's no-op,
+        provers/sgx/prover/src/lib.rs:151-153); nothing is stored under the key."""
+        return None
