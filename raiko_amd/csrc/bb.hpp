@@ -68,6 +68,46 @@ RK_HD uint32_t sbox7(uint32_t x) {
     return mul(x6, x);
 }
 
+// Signed Montgomery product: for |a|, |b| <= p returns r == a*b*2^-32 (mod p) with
+// |r| < 0.97 p, so chains of products need no conditional subtraction in between:
+//   t = a*b (signed 64-bit), q = lo32(t) * p^-1 as int32, r = hi32(t) - hi32(q*p)
+// (t - q*p is divisible by 2^32, |q*p| / 2^32 <= p/2, |t| / 2^32 <= 0.469 p).
+// gfx950: 2 x v_mul_lo_u32 + 2 x v_mul_hi_i32 (half rate) + v_sub; cheaper than the
+// v_mad_u64_u32 form (quarter rate) -- profiles/r01_ubench_intmul.txt.
+RK_HD int32_t mulhi_s32(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mulhi(a, b);
+#else
+    return (int32_t)(((int64_t)a * (int64_t)b) >> 32);
+#endif
+}
+RK_HD int32_t smul(int32_t a, int32_t b) {
+    uint32_t lo = (uint32_t)a * (uint32_t)b;
+    int32_t q = (int32_t)(lo * MPRIME);
+    return mulhi_s32(a, b) - mulhi_s32(q, (int32_t)P);
+}
+// product with a constant c whose companion c_q = c * p^-1 mod 2^32 is precomputed:
+// q = a * c_q needs no dependence on the low product (3 multiplies instead of 4)
+RK_HD int32_t smul_const(int32_t a, int32_t c, uint32_t c_q) {
+    int32_t q = (int32_t)((uint32_t)a * c_q);
+    return mulhi_s32(a, c) - mulhi_s32(q, (int32_t)P);
+}
+// signed-lazy value in (-p, p) -> canonical [0, p)
+RK_HD uint32_t canon(int32_t r) {
+    uint32_t u = (uint32_t)r, v = u + P;
+    return v < u ? v : u;  // negative values wrap to small after +p
+}
+// (x + rc)^7 for canonical x; rc_minus_p = rc - p (two's complement), so x + rc_minus_p is a
+// representative of x + rc in [-p, p): the addition needs no reduction and the whole power
+// chain runs on signed-lazy values; one conditional +p at the end restores [0, p).
+RK_HD uint32_t sbox7_add(uint32_t x, uint32_t rc_minus_p) {
+    int32_t s = (int32_t)(x + rc_minus_p);
+    int32_t s2 = smul(s, s);
+    int32_t s3 = smul(s2, s);
+    int32_t s6 = smul(s3, s3);
+    return canon(smul(s6, s));
+}
+
 struct Ext {
     uint32_t c[4];
 };

@@ -160,6 +160,7 @@ int rk_ctx_create(int device, void* stream, rk_ctx** out) {
         std::memcpy(ctx->h_p2.rc_ext, P2_RC_EXT_MONT, sizeof ctx->h_p2.rc_ext);
         std::memcpy(ctx->h_p2.rc_int, P2_RC_INT_MONT, sizeof ctx->h_p2.rc_int);
         std::memcpy(ctx->h_p2.diag, P2_INT_DIAG_MONT, sizeof ctx->h_p2.diag);
+        p2::derive(ctx->h_p2);
         if (hipMalloc((void**)&ctx->d_p2, sizeof(p2::Consts)) != hipSuccess) { st = RK_ERR_NOMEM; break; }
         if (hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice) != hipSuccess) {
             st = RK_ERR_HIP;
@@ -235,6 +236,7 @@ int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t*
     std::memcpy(ctx->h_p2.rc_ext, rc_ext, sizeof ctx->h_p2.rc_ext);
     std::memcpy(ctx->h_p2.rc_int, rc_int, sizeof ctx->h_p2.rc_int);
     std::memcpy(ctx->h_p2.diag, diag, sizeof ctx->h_p2.diag);
+    p2::derive(ctx->h_p2);
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     RK_HIP_TRY(ctx, hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice));

@@ -110,7 +110,10 @@ int gather_rows(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_matrix, size_t r
                 const uint32_t* d_idx, size_t n_idx);
 // digests: d_dst[i] = d_nodes[d_idx[i]]
 int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const uint32_t* d_idx, size_t n_idx);
-int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n);
+int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool bit_reversed);
+int bit_reverse_ext(rk_ctx* ctx, uint32_t* d_io_ext, size_t size, size_t count);
+// levels of a Merkle tree with <= 1024 parents, fused in one launch (kernels_hash.hip)
+int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size);
 // d_out_ext[e] = sum_k coeffs[which[e]*size + k] * pw[pw_sel[e]*size + k]
 int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t size, const uint32_t* d_which,
              const uint32_t* d_pw_ext, const uint32_t* d_pw_sel, size_t eval_count);

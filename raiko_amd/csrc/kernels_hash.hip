@@ -52,6 +52,39 @@ __global__ __launch_bounds__(HASH_BLOCK) void hash_fold_kernel(uint32_t* __restr
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// The last levels of a tree (<= 1024 parents) in one launch: the level lives in LDS between
+// steps, every parent is also written to its heap slot in HBM.  Replaces ~11 latency-bound
+// launches per tree.
+constexpr int TAIL_MAX = 1024;
+__global__ __launch_bounds__(TAIL_MAX) void hash_fold_tail_kernel(uint32_t* __restrict__ nodes, unsigned top_out,
+                                                                  const p2::Consts* __restrict__ kc) {
+    __shared__ uint32_t level[2 * TAIL_MAX * p2::OUT];
+    const unsigned tid = threadIdx.x;
+    const p2::Consts& k = *kc;
+    for (unsigned i = tid; i < 2 * top_out * p2::OUT; i += blockDim.x) level[i] = nodes[(size_t)2 * top_out * p2::OUT + i];
+    __syncthreads();
+    for (unsigned out = top_out; out >= 1; out >>= 1) {
+        uint32_t s[p2::CELLS];
+        const bool active = tid < out;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 2 * p2::OUT; i++) s[i] = level[2 * tid * p2::OUT + i];
+#pragma unroll
+            for (int i = 2 * p2::OUT; i < p2::CELLS; i++) s[i] = 0;
+            p2::permute(s, k);
+        }
+        __syncthreads();  // every child has been read before the level is overwritten
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < p2::OUT; i++) {
+                level[tid * p2::OUT + i] = s[i];
+                nodes[(size_t)(out + tid) * p2::OUT + i] = s[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 namespace rk {
@@ -79,8 +112,19 @@ int hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t output_size) {
 int merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols) {
     if (!is_pow2(rows)) return RK_ERR_INVALID;
     RK_TRY(hash_rows(ctx, d_nodes + rows * p2::OUT, d_matrix, rows, cols));
-    for (size_t layer = rows / 2; layer >= 1; layer /= 2) RK_TRY(hash_fold(ctx, d_nodes, layer));
+    size_t layer = rows / 2;
+    for (; layer > TAIL_MAX; layer /= 2) RK_TRY(hash_fold(ctx, d_nodes, layer));
+    if (layer >= 1) RK_TRY(hash_fold_tail(ctx, d_nodes, layer));
     return RK_OK;
+}
+
+int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
+    if (!is_pow2(top_output_size) || top_output_size > TAIL_MAX) return RK_ERR_INVALID;
+    unsigned threads = top_output_size < 64 ? 64u : (unsigned)top_output_size;
+    KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)(2 * top_output_size - 1) * 96);
+    hipLaunchKernelGGL(hash_fold_tail_kernel, dim3(1), dim3(threads), 0, ctx->stream, d_nodes, (unsigned)top_output_size,
+                       ctx->d_p2);
+    return post_launch(ctx, "hash_fold_tail_kernel");
 }
 
 }  // namespace rk

@@ -30,6 +30,31 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(ntt::PassArgs a, ntt::Ta
     }
 }
 
+// unrolled form: tile == EPT * blockDim.x, every phase issues its memory operations up front
+template <bool FWD, int EPT, bool VEC>
+__global__ __launch_bounds__(1024) void ntt_pass_kernel_u(ntt::PassArgs a, ntt::Tables tb) {
+    extern __shared__ uint32_t lds[];
+    const unsigned tid = threadIdx.x, nthr = blockDim.x;
+    const ntt::Tile t = ntt::tile_of(a, blockIdx.x);
+    if (FWD) {
+        ntt::fwd_load_t<EPT, VEC>(a, tb, t, lds, tid, nthr);
+        __syncthreads();
+        for (unsigned s = a.expand_bits; s < a.g; s++) {
+            ntt::fwd_stage_t<EPT / 2>(a, tb, lds, tid, nthr, s);
+            __syncthreads();
+        }
+        ntt::fwd_store_t<EPT, VEC>(a, t, lds, tid, nthr);
+    } else {
+        ntt::rev_load_t<EPT, VEC>(a, t, lds, tid, nthr);
+        __syncthreads();
+        for (unsigned s = 0; s < a.g; s++) {
+            ntt::rev_stage_t<EPT / 2>(a, tb, lds, tid, nthr, s);
+            __syncthreads();
+        }
+        ntt::rev_store_t<EPT, VEC>(a, tb, t, lds, tid, nthr);
+    }
+}
+
 __global__ void zk_shift_kernel(uint32_t* io, size_t total, size_t size, unsigned bits, ntt::Tables tb) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -56,14 +81,23 @@ __global__ void bit_reverse_kernel(uint32_t* io, size_t total, size_t size, unsi
 
 template <bool FWD>
 int launch_pass(rk_ctx* ctx, const ntt::PassArgs& a, size_t count) {
+    constexpr int EPT = 16;
     size_t tile = (size_t)1 << (a.g + a.logT);
     size_t blocks = count * (a.n >> (a.g + a.logT));
     if (blocks == 0 || blocks > 0x7fffffffu) return RK_ERR_INVALID;
-    unsigned threads = tile / 2 >= 1024 ? 1024 : (unsigned)(tile / 2);
-    if (threads < 64) threads = 64;
     size_t lds_bytes = tile * sizeof(uint32_t);
     rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)count * 4 * ((a.expand_bits ? a.n_src : a.n) + a.n));
-    hipLaunchKernelGGL(ntt_pass_kernel<FWD>, dim3((unsigned)blocks), dim3(threads), lds_bytes, ctx->stream, a, ctx->tb);
+    if (ntt::can_unroll(a, EPT)) {
+        unsigned threads = (unsigned)(tile / EPT);
+        if (ntt::can_vec(a))
+            hipLaunchKernelGGL((ntt_pass_kernel_u<FWD, EPT, true>), dim3((unsigned)blocks), dim3(threads), lds_bytes,
+                               ctx->stream, a, ctx->tb);
+        else
+            hipLaunchKernelGGL((ntt_pass_kernel_u<FWD, EPT, false>), dim3((unsigned)blocks), dim3(threads), lds_bytes,
+                               ctx->stream, a, ctx->tb);
+    } else {
+        hipLaunchKernelGGL(ntt_pass_kernel<FWD>, dim3((unsigned)blocks), dim3(64), lds_bytes, ctx->stream, a, ctx->tb);
+    }
     return rk::post_launch(ctx, FWD ? "ntt_pass_kernel<fwd>" : "ntt_pass_kernel<rev>");
 }
 

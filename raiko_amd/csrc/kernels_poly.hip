@@ -83,15 +83,31 @@ __global__ void gather_digests_kernel(uint32_t* dst, const uint32_t* nodes, cons
 
 // pw[k] = x^k: each lane seeds x^(lane_start) by square-and-multiply, then walks CH powers
 constexpr int PW_CH = 32;
-__global__ void ext_powers_kernel(uint32_t* pw, Ext x, size_t n) {
+// rev_bits != 0: x^k is stored at position bitrev(k), matching bit-reversed coefficient storage
+__global__ void ext_powers_kernel(uint32_t* pw, Ext x, size_t n, unsigned rev_bits) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t start = t * PW_CH;
     if (start >= n) return;
     Ext cur = bb::pow(x, (uint64_t)start);
     size_t end = start + PW_CH < n ? start + PW_CH : n;
     for (size_t k = start; k < end; k++) {
-        store_ext(pw + k * 4, cur);
+        size_t pos = rev_bits ? (size_t)bb::bitrev((uint32_t)k, rev_bits) : k;
+        store_ext(pw + pos * 4, cur);
         cur = bb::mul(cur, x);
+    }
+}
+// in-place bit reversal of `count` polynomials of `size` extension elements (16-byte items)
+__global__ void bit_reverse_ext_kernel(uint32_t* io, size_t total, size_t size, unsigned bits) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; idx < total; idx += st) {
+        uint32_t pos = (uint32_t)(idx & (size - 1));
+        uint32_t rev = bb::bitrev(pos, bits);
+        if (pos < rev) {
+            size_t other = idx - pos + rev;
+            Ext a = load_ext(io + idx * 4), b = load_ext(io + other * 4);
+            store_ext(io + idx * 4, b);
+            store_ext(io + other * 4, a);
+        }
     }
 }
 
@@ -165,7 +181,8 @@ __global__ __launch_bounds__(TPB) void div_carry_kernel(uint32_t* carry, const u
                                                         uint32_t* rem_out) {
     __shared__ uint32_t seg_top[TPB * 4];
     __shared__ uint32_t seg_in[TPB * 4];
-    size_t per = (nchunks + TPB - 1) / TPB;
+    const int NT = (int)blockDim.x;  // one wave: 64 segments, 64 sequential carry steps
+    size_t per = (nchunks + NT - 1) / NT;
     size_t s0 = threadIdx.x * per, s1 = s0 + per < nchunks ? s0 + per : nchunks;
     // local pass: value at the segment's first chunk assuming zero carry-in, and zL^(segment length)
     Ext acc = bb::ext_zero();
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(TPB) void div_carry_kernel(uint32_t* carry, const u
     if (threadIdx.x == 0) {
         Ext zseg = bb::pow(zL, (uint64_t)per);
         Ext run = bb::ext_zero();  // T at the start of segment t+1
-        for (int t = TPB - 1; t >= 0; t--) {
+        for (int t = NT - 1; t >= 0; t--) {
 #pragma unroll
             for (int j = 0; j < 4; j++) seg_in[t * 4 + j] = run.c[j];
             size_t a0 = (size_t)t * per;
@@ -271,13 +288,23 @@ int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const 
                        d_nodes, d_idx, n_idx);
     return post_launch(ctx, "gather_digests_kernel");
 }
-int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n) {
+int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool bit_reversed) {
     if (n == 0) return RK_OK;
+    if (bit_reversed && !is_pow2(n)) return RK_ERR_INVALID;
     size_t lanes = (n + PW_CH - 1) / PW_CH;
     KTimer kt(ctx, RK_KCLASS_POLY, (double)n * 16);
     hipLaunchKernelGGL(ext_powers_kernel, dim3((unsigned)((lanes + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_pw_ext,
-                       x, n);
+                       x, n, bit_reversed ? log2u(n) : 0u);
     return post_launch(ctx, "ext_powers_kernel");
+}
+int bit_reverse_ext(rk_ctx* ctx, uint32_t* d_io_ext, size_t size, size_t count) {
+    if (!is_pow2(size) || count == 0) return RK_ERR_INVALID;
+    if (size <= 2) return RK_OK;
+    size_t total = size * count;
+    KTimer kt(ctx, RK_KCLASS_BIT_REVERSE, (double)total * 32);
+    hipLaunchKernelGGL(bit_reverse_ext_kernel, dim3(grid_for(total)), dim3(TPB), 0, ctx->stream, d_io_ext, total, size,
+                       log2u(size));
+    return post_launch(ctx, "bit_reverse_ext_kernel");
 }
 int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t size, const uint32_t* d_which,
              const uint32_t* d_pw_ext, const uint32_t* d_pw_sel, size_t eval_count) {
@@ -359,7 +386,7 @@ int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& 
     hipLaunchKernelGGL(div_tops_kernel, dim3(blocks), dim3(TPB), 0, ctx->stream, tops, d_poly_ext, count, z);
     int st = post_launch(ctx, "div_tops_kernel");
     if (st == RK_OK) {
-        hipLaunchKernelGGL(div_carry_kernel, dim3(1), dim3(TPB), 0, ctx->stream, carry, tops, nchunks, zL, rem);
+        hipLaunchKernelGGL(div_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, carry, tops, nchunks, zL, rem);
         st = post_launch(ctx, "div_carry_kernel");
     }
     if (st == RK_OK) {
@@ -468,7 +495,7 @@ int rk_batch_evaluate_any(rk_ctx* ctx, const uint32_t* d_coeffs, size_t poly_cou
         hipError_t e2 = hipMemcpyAsync(d_sel, sel.data(), eval_count * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e1 != hipSuccess || e2 != hipSuccess) { st = RK_ERR_HIP; ctx->last_error = "evaluate_any h2d"; break; }
         for (size_t j = 0; j < pts.size() && st == RK_OK; j++)
-            st = rk::ext_powers(ctx, (uint32_t*)d_pw + j * size * 4, pts[j], size);
+            st = rk::ext_powers(ctx, (uint32_t*)d_pw + j * size * 4, pts[j], size, false);
         if (st != RK_OK) break;
         st = rk::eval_dot(ctx, d_out, d_coeffs, size, d_which, (const uint32_t*)d_pw, d_sel, eval_count);
         if (st != RK_OK) break;

@@ -166,6 +166,207 @@ RK_HD void fwd_store(const PassArgs& a, const Tile& t, const uint32_t* lds, unsi
     }
 }
 
+// ---------------------------------------------------------------- unrolled variants
+// Same arithmetic as the loops above with the per-thread trip count fixed at compile time
+// (EPT elements = EPT/2 butterflies per thread, tile == EPT * nthr) so every LDS / table /
+// global access of a phase is issued before the first use: the generic loops expose one
+// memory round trip per butterfly, these expose one per phase.  VEC: 16-byte global accesses
+// (4 consecutive tile elements are consecutive in memory when T >= 4 or the pass is contiguous).
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+template <int EPT, bool VEC>
+RK_HD void rev_load_t(const PassArgs& a, const Tile& t, uint32_t* lds, unsigned tid, unsigned nthr) {
+    unsigned tmask = (1u << a.logT) - 1;
+    if (VEC) {
+        U4 v[EPT / 4];
+#pragma unroll
+        for (int i = 0; i < EPT / 4; i++) {
+            unsigned e = 4 * (tid + i * nthr);
+            unsigned hi = e >> a.logT, lo = e & tmask;
+            v[i] = *reinterpret_cast<const U4*>(a.src + t.base + (size_t)hi * t.S + lo);
+        }
+#pragma unroll
+        for (int i = 0; i < EPT / 4; i++) *reinterpret_cast<U4*>(lds + 4 * (tid + i * nthr)) = v[i];
+    } else {
+        uint32_t v[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            unsigned e = tid + i * nthr;
+            v[i] = a.src[t.base + (size_t)(e >> a.logT) * t.S + (e & tmask)];
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; i++) lds[tid + i * nthr] = v[i];
+    }
+}
+template <int BPT>
+RK_HD void rev_stage_t(const PassArgs& a, const Tables& tb, uint32_t* lds, unsigned tid, unsigned nthr, unsigned s) {
+    unsigned tmask = (1u << a.logT) - 1;
+    unsigned hlog = a.g - 1 - s, half = 1u << hlog;
+    unsigned i0[BPT];
+    uint32_t x[BPT], y[BPT], w[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; i++) {
+        unsigned b = tid + i * nthr;
+        unsigned lo = b & tmask, hb = b >> a.logT;
+        unsigned j = hb & (half - 1), blk = hb >> hlog;
+        i0[i] = (((blk << (hlog + 1)) + j) << a.logT) + lo;
+        w[i] = tb.small[1][j << (s + KS - a.g)];
+        x[i] = lds[i0[i]];
+        y[i] = lds[i0[i] + (half << a.logT)];
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; i++) {
+        lds[i0[i]] = bb::add(x[i], y[i]);
+        lds[i0[i] + (half << a.logT)] = bb::mul(bb::sub(x[i], y[i]), w[i]);
+    }
+}
+RK_HD uint32_t rev_out_factor(const PassArgs& a, const Tables& tb, const Tile& t, unsigned p1, unsigned lo, size_t pos,
+                              bool& has) {
+    uint32_t f = bb::ONE;
+    has = false;
+    if (t.S > 1) {
+        uint32_t k1 = bb::bitrev(p1, a.g);
+        f = root_pow(tb, 1, ((t.lo0 + lo) * k1) << (LAMBDA - a.mu));
+        has = true;
+    }
+    if (a.scale) {
+        uint32_t g = a.scale;
+        if (a.zk_bits) g = bb::mul(g, pow3(tb, bb::bitrev((uint32_t)(pos & (a.n - 1)), a.zk_bits)));
+        f = has ? bb::mul(f, g) : g;
+        has = true;
+    }
+    return f;
+}
+template <int EPT, bool VEC>
+RK_HD void rev_store_t(const PassArgs& a, const Tables& tb, const Tile& t, const uint32_t* lds, unsigned tid,
+                       unsigned nthr) {
+    unsigned tmask = (1u << a.logT) - 1;
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < EPT / 4; i++) {
+            unsigned e = 4 * (tid + i * nthr);
+            unsigned p1 = e >> a.logT, lo = e & tmask;
+            size_t pos = t.base + (size_t)p1 * t.S + lo;
+            U4 v = *reinterpret_cast<const U4*>(lds + e);
+            uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                // T >= 4 keeps the 4 elements in one tile row; the contiguous pass (T == 1) has S == 1
+                unsigned pc = a.logT >= 2 ? p1 : p1 + c, lc = a.logT >= 2 ? lo + c : lo;
+                bool has;
+                uint32_t f = rev_out_factor(a, tb, t, pc, lc, pos + c, has);
+                if (has) r[c] = bb::mul(r[c], f);
+            }
+            *reinterpret_cast<U4*>(a.dst + pos) = U4{r[0], r[1], r[2], r[3]};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            unsigned e = tid + i * nthr;
+            unsigned p1 = e >> a.logT, lo = e & tmask;
+            size_t pos = t.base + (size_t)p1 * t.S + lo;
+            bool has;
+            uint32_t f = rev_out_factor(a, tb, t, p1, lo, pos, has);
+            uint32_t v = lds[e];
+            a.dst[pos] = has ? bb::mul(v, f) : v;
+        }
+    }
+}
+
+template <int EPT, bool VEC>
+RK_HD void fwd_load_t(const PassArgs& a, const Tables& tb, const Tile& t, uint32_t* lds, unsigned tid, unsigned nthr) {
+    unsigned tmask = (1u << a.logT) - 1;
+    bool tw = t.S > 1;
+    if (a.expand_bits) {
+        // contiguous first pass of an LDE: 2^expand_bits consecutive outputs share one input
+        // (T == 1, S == 1).  One source word feeds a group of EX tile slots.
+        unsigned ex = 1u << a.expand_bits;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            unsigned e = tid + i * nthr;
+            lds[e] = a.src[t.src_base + (e / ex)];
+        }
+        return;
+    }
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < EPT / 4; i++) {
+            unsigned e = 4 * (tid + i * nthr);
+            unsigned hi = e >> a.logT, lo = e & tmask;
+            U4 v = *reinterpret_cast<const U4*>(a.src + t.base + (size_t)hi * t.S + lo);
+            uint32_t r[4] = {v.x, v.y, v.z, v.w};
+            if (tw) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    unsigned hc = a.logT >= 2 ? hi : hi + c, lc = a.logT >= 2 ? lo + c : lo;
+                    uint32_t rr = bb::bitrev(hc, a.g);
+                    r[c] = bb::mul(r[c], root_pow(tb, 0, (rr * (t.lo0 + lc)) << (LAMBDA - a.mu)));
+                }
+            }
+            *reinterpret_cast<U4*>(lds + e) = U4{r[0], r[1], r[2], r[3]};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            unsigned e = tid + i * nthr;
+            unsigned hi = e >> a.logT, lo = e & tmask;
+            uint32_t v = a.src[t.base + (size_t)hi * t.S + lo];
+            if (tw) v = bb::mul(v, root_pow(tb, 0, (bb::bitrev(hi, a.g) * (t.lo0 + lo)) << (LAMBDA - a.mu)));
+            lds[e] = v;
+        }
+    }
+}
+template <int BPT>
+RK_HD void fwd_stage_t(const PassArgs& a, const Tables& tb, uint32_t* lds, unsigned tid, unsigned nthr, unsigned tt) {
+    unsigned tmask = (1u << a.logT) - 1;
+    unsigned half = 1u << tt;
+    unsigned i0[BPT];
+    uint32_t x[BPT], y[BPT], w[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; i++) {
+        unsigned b = tid + i * nthr;
+        unsigned lo = b & tmask, hb = b >> a.logT;
+        unsigned j = hb & (half - 1), blk = hb >> tt;
+        i0[i] = (((blk << (tt + 1)) + j) << a.logT) + lo;
+        w[i] = tb.small[0][j << (KS - 1 - tt)];
+        x[i] = lds[i0[i]];
+        y[i] = lds[i0[i] + (half << a.logT)];
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; i++) {
+        uint32_t yy = bb::mul(y[i], w[i]);
+        lds[i0[i]] = bb::add(x[i], yy);
+        lds[i0[i] + (half << a.logT)] = bb::sub(x[i], yy);
+    }
+}
+template <int EPT, bool VEC>
+RK_HD void fwd_store_t(const PassArgs& a, const Tile& t, const uint32_t* lds, unsigned tid, unsigned nthr) {
+    unsigned tmask = (1u << a.logT) - 1;
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < EPT / 4; i++) {
+            unsigned e = 4 * (tid + i * nthr);
+            unsigned hi = e >> a.logT, lo = e & tmask;
+            *reinterpret_cast<U4*>(a.dst + t.base + (size_t)hi * t.S + lo) = *reinterpret_cast<const U4*>(lds + e);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            unsigned e = tid + i * nthr;
+            a.dst[t.base + (size_t)(e >> a.logT) * t.S + (e & tmask)] = lds[e];
+        }
+    }
+}
+// may the unrolled/vector form be used for this pass?
+inline bool can_unroll(const PassArgs& a, int ept) { return ((size_t)1 << (a.g + a.logT)) >= (size_t)ept * 64; }
+inline bool can_vec(const PassArgs& a) {
+    size_t S = ((size_t)1 << a.mu) >> a.g;
+    bool contiguous4 = a.logT >= 2 || (a.logT == 0 && S == 1);
+    return contiguous4 && (a.n % 4 == 0) && (((uintptr_t)a.dst | (uintptr_t)a.src) & 15) == 0;
+}
+
 // ---------------------------------------------------------------- pass planning
 struct Plan {
     unsigned npass;

@@ -22,7 +22,17 @@ struct Consts {
     uint32_t rc_ext[2 * ROUNDS_HALF_FULL * CELLS];  // Montgomery form
     uint32_t rc_int[ROUNDS_PARTIAL];
     uint32_t diag[CELLS];
+    // derived by derive(): rc - p (so `x + rc` needs no reduction before the S-box) and
+    // diag * p^-1 mod 2^32 (companion of the constant multiplier, bb::smul_const)
+    uint32_t rc_ext_mp[2 * ROUNDS_HALF_FULL * CELLS];
+    uint32_t rc_int_mp[ROUNDS_PARTIAL];
+    uint32_t diag_q[CELLS];
 };
+inline void derive(Consts& k) {
+    for (int i = 0; i < 2 * ROUNDS_HALF_FULL * CELLS; i++) k.rc_ext_mp[i] = k.rc_ext[i] - bb::P;
+    for (int i = 0; i < ROUNDS_PARTIAL; i++) k.rc_int_mp[i] = k.rc_int[i] - bb::P;
+    for (int i = 0; i < CELLS; i++) k.diag_q[i] = k.diag[i] * bb::MPRIME;
+}
 
 // circ(2*M4, M4, ..., M4) with M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
 RK_HD void m_ext(uint32_t* s) {
@@ -46,11 +56,12 @@ RK_HD void m_int(uint32_t* s, const Consts& k) {
 #pragma unroll
     for (int i = 0; i < CELLS; i++) sum = bb::add(sum, s[i]);
 #pragma unroll
-    for (int i = 0; i < CELLS; i++) s[i] = bb::add(sum, bb::mul(s[i], k.diag[i]));
+    for (int i = 0; i < CELLS; i++)
+        s[i] = bb::add(sum, bb::canon(bb::smul_const((int32_t)s[i], (int32_t)k.diag[i], k.diag_q[i])));
 }
 RK_HD void full_round(uint32_t* s, const Consts& k, int r) {
 #pragma unroll
-    for (int i = 0; i < CELLS; i++) s[i] = bb::sbox7(bb::add(s[i], k.rc_ext[r * CELLS + i]));
+    for (int i = 0; i < CELLS; i++) s[i] = bb::sbox7_add(s[i], k.rc_ext_mp[r * CELLS + i]);
     m_ext(s);
 }
 RK_HD void permute(uint32_t* s, const Consts& k) {
@@ -59,7 +70,7 @@ RK_HD void permute(uint32_t* s, const Consts& k) {
     for (int r = 0; r < ROUNDS_HALF_FULL; r++) full_round(s, k, r);
 #pragma unroll 1
     for (int r = 0; r < ROUNDS_PARTIAL; r++) {
-        s[0] = bb::sbox7(bb::add(s[0], k.rc_int[r]));
+        s[0] = bb::sbox7_add(s[0], k.rc_int_mp[r]);
         m_int(s, k);
     }
 #pragma unroll 1

@@ -192,7 +192,11 @@ struct PolyGroup {
         size_t domain = sz * 4;
         RK_TRY(evaluated.alloc(ctx, cnt * domain * 4));
         RK_TRY(rk::ntt_forward(ctx, evaluated.u32(), coeffs.u32(), sz, cnt, 2));
-        RK_TRY(rk::bit_reverse(ctx, coeffs.u32(), sz, cnt));
+        // risc0 bit-reverses the coefficients here (PolyGroup::new) because its later users
+        // index them in natural order.  The device pipeline instead keeps them bit-reversed:
+        // the tap evaluation multiplies by power tables stored in the same order and the
+        // DEEP mix is pointwise, so only the (combo_count + 1) mixed polynomials are permuted
+        // afterwards -- 1/50th of the data for the same field results.
         return RK_OK;
     }
 };
@@ -354,7 +358,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     {
         DevBuf d_pw, d_small;
         RK_TRY(d_pw.alloc(ctx, n_pts * N * 16));
-        for (size_t j = 0; j < n_pts; j++) RK_TRY(rk::ext_powers(ctx, d_pw.u32() + j * N * 4, pts[j], N));
+        for (size_t j = 0; j < n_pts; j++) RK_TRY(rk::ext_powers(ctx, d_pw.u32() + j * N * 4, pts[j], N, true));
         size_t max_evals = tot_taps > CHECK_SIZE ? tot_taps : CHECK_SIZE;
         RK_TRY(d_small.alloc(ctx, max_evals * (4 + 4 + 16) + 32));
         std::vector<Ext> eval_u(tot_taps + CHECK_SIZE);
@@ -428,6 +432,8 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         }
         which.assign(CHECK_SIZE, (uint32_t)combo_count);
         RK_TRY(rk::mix_poly_coeffs(ctx, combos.u32(), cur_mix, mix, check.coeffs.u32(), which.data(), CHECK_SIZE, N));
+        // inputs were bit-reversed, so are the mixed polynomials: natural order for the division
+        RK_TRY(rk::bit_reverse_ext(ctx, combos.u32(), N, combo_count + 1));
     }
     {
         // combos[size*combo + i] -= cur * coeff_u[...]: accumulate per touched coefficient on the host

@@ -25,10 +25,39 @@ p2::Consts consts() {
     std::memcpy(k.rc_ext, P2_RC_EXT_MONT, sizeof k.rc_ext);
     std::memcpy(k.rc_int, P2_RC_INT_MONT, sizeof k.rc_int);
     std::memcpy(k.diag, P2_INT_DIAG_MONT, sizeof k.diag);
+    p2::derive(k);
     return k;
+}
+// mirrors launch_pass / ntt_pass_kernel(_u) of kernels_ntt.hip, one emulated lane at a time
+template <bool FWD, bool VEC>
+void run_pass_u(const ntt::PassArgs& a, size_t count) {
+    constexpr int EPT = 16;
+    size_t tile = (size_t)1 << (a.g + a.logT);
+    size_t blocks = count * (a.n >> (a.g + a.logT));
+    unsigned nthr = (unsigned)(tile / EPT);
+    std::vector<uint32_t> lds(tile);
+    for (size_t blk = 0; blk < blocks; blk++) {
+        ntt::Tile t = ntt::tile_of(a, blk);
+        if (FWD) {
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::fwd_load_t<EPT, VEC>(a, g_tb, t, lds.data(), tid, nthr);
+            for (unsigned s = a.expand_bits; s < a.g; s++)
+                for (unsigned tid = 0; tid < nthr; tid++) ntt::fwd_stage_t<EPT / 2>(a, g_tb, lds.data(), tid, nthr, s);
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::fwd_store_t<EPT, VEC>(a, t, lds.data(), tid, nthr);
+        } else {
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::rev_load_t<EPT, VEC>(a, t, lds.data(), tid, nthr);
+            for (unsigned s = 0; s < a.g; s++)
+                for (unsigned tid = 0; tid < nthr; tid++) ntt::rev_stage_t<EPT / 2>(a, g_tb, lds.data(), tid, nthr, s);
+            for (unsigned tid = 0; tid < nthr; tid++) ntt::rev_store_t<EPT, VEC>(a, g_tb, t, lds.data(), tid, nthr);
+        }
+    }
 }
 template <bool FWD>
 void run_pass(const ntt::PassArgs& a, size_t count, unsigned nthr) {
+    if (ntt::can_unroll(a, 16)) {
+        if (ntt::can_vec(a)) run_pass_u<FWD, true>(a, count);
+        else run_pass_u<FWD, false>(a, count);
+        return;
+    }
     size_t tile = (size_t)1 << (a.g + a.logT);
     size_t blocks = count * (a.n >> (a.g + a.logT));
     std::vector<uint32_t> lds(tile);

@@ -22,14 +22,14 @@ __global__ __launch_bounds__(256) void k_op(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < ITERS; i++) {
 #pragma unroll
         for (int j = 0; j < ILP; j++) {
-            if (OP == 0) x[j] = x[j] * y;                       // v_mul_lo_u32
+            if (OP == 0) x[j] = x[j] * (x[(j + 1) % ILP] | 1u); // v_mul_lo_u32 (+v_or)
             if (OP == 1) x[j] = __umulhi(x[j], y);              // v_mul_hi_u32
             if (OP == 2) {                                       // v_mad_u64_u32
                 uint64_t t = (uint64_t)x[j] * y + x[(j + 1) % ILP];
                 x[j] = (uint32_t)t ^ (uint32_t)(t >> 32);
             }
             if (OP == 3) x[j] = __umul24(x[j], y);              // v_mul_u32_u24
-            if (OP == 4) x[j] = x[j] + y;                       // v_add_u32 (full-rate reference)
+            if (OP == 4) x[j] = x[j] + (x[(j + 1) % ILP] ^ y);  // v_add_u32 + v_xor (full-rate reference)
             if (OP == 5) x[j] = bb::mul(x[j] % bb::P, y % bb::P);  // not used
         }
     }
@@ -51,6 +51,20 @@ __global__ __launch_bounds__(256) void k_montmul(uint32_t* out, uint32_t seed) {
 #pragma unroll
     for (int j = 0; j < ILP; j++) acc ^= x[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_smul(uint32_t* out, uint32_t seed) {
+    int32_t x[ILP], y = (int32_t)((seed | 1u) % bb::P);
+#pragma unroll
+    for (int j = 0; j < ILP; j++) x[j] = (int32_t)((threadIdx.x * 2654435761u + j * 40503u + seed) % bb::P);
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) x[j] = bb::smul(x[j], x[(j + 1) % ILP]);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc ^= (uint32_t)x[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc + y;
 }
 
 __global__ __launch_bounds__(256) void k_fma64(double* out, double seed) {
@@ -110,6 +124,7 @@ int main() {
     memcpy(h.rc_ext, P2_RC_EXT_MONT, sizeof h.rc_ext);
     memcpy(h.rc_int, P2_RC_INT_MONT, sizeof h.rc_int);
     memcpy(h.diag, P2_INT_DIAG_MONT, sizeof h.diag);
+    p2::derive(h);
     CK(hipMalloc(&d, sizeof h));
     CK(hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice));
     double nops = (double)blocks * threads * ITERS * ILP;
@@ -127,6 +142,8 @@ int main() {
     printf("%-22s %8.3f ms  %8.1f Gop/s  %.2f op/clk/CU@2.4GHz\n", names[4], ms, nops / ms / 1e6, nops / ms / 1e6 / cus / 2.4);
     ms = time_ms([&] { hipLaunchKernelGGL(k_montmul, dim3(blocks), dim3(threads), 0, 0, out, 12345u); });
     printf("%-22s %8.3f ms  %8.1f Gmulmod/s  %.2f /clk/CU@2.4GHz\n", "bb::mul (Montgomery)", ms, nops / ms / 1e6, nops / ms / 1e6 / cus / 2.4);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_smul, dim3(blocks), dim3(threads), 0, 0, out, 12345u); });
+    printf("%-22s %8.3f ms  %8.1f Gmulmod/s  %.2f /clk/CU@2.4GHz\n", "bb::smul (signed, var)", ms, nops / ms / 1e6, nops / ms / 1e6 / cus / 2.4);
     ms = time_ms([&] { hipLaunchKernelGGL(k_fma64, dim3(blocks), dim3(threads), 0, 0, outd, 1.0000001); });
     printf("%-22s %8.3f ms  %8.1f Gop/s  %.2f op/clk/CU@2.4GHz\n", "v_fma_f64", ms, nops / ms / 1e6, nops / ms / 1e6 / cus / 2.4);
     double nperm = (double)blocks * threads * P2_ITERS;
