@@ -26,7 +26,9 @@ constexpr unsigned MAX_TILE_LOG = 14;  // 2^14 elements = 64 KiB of LDS
 
 struct Tables {
     // [0] = forward roots, [1] = inverse roots
-    const uint32_t* small[2];  // w_{2^KS}^{+-j}, j < 2^(KS-1)
+    // per-stage twiddles in heap order: small[d][half + j] = w_{2*half}^{+-j}, j < half, half = 1 .. 2^(KS-1);
+    // consecutive butterflies of a stage read consecutive words (one coalesced line per wave)
+    const uint32_t* small[2];
     const uint32_t* hi[2];     // W^{+-(a << TW_SPLIT)}, W = w_{2^LAMBDA}, a < 2^(LAMBDA-TW_SPLIT)
     const uint32_t* lo[2];     // W^{+-b}, b < 2^TW_SPLIT
     const uint32_t* pow3_hi;   // 3^(a << TW_SPLIT)
@@ -96,7 +98,7 @@ RK_HD void rev_stage(const PassArgs& a, const Tables& tb, uint32_t* lds, unsigne
         unsigned i1 = i0 + (half << a.logT);
         uint32_t x = lds[i0], y = lds[i1];
         lds[i0] = bb::add(x, y);
-        lds[i1] = bb::mul(bb::sub(x, y), tb.small[1][j << (s + KS - a.g)]);
+        lds[i1] = bb::mul(bb::sub(x, y), tb.small[1][half + j]);
     }
 }
 RK_HD void rev_store(const PassArgs& a, const Tables& tb, const Tile& t, const uint32_t* lds, unsigned tid,
@@ -153,7 +155,7 @@ RK_HD void fwd_stage(const PassArgs& a, const Tables& tb, uint32_t* lds, unsigne
         unsigned i0 = (((blk << (tt + 1)) + j) << a.logT) + lo;
         unsigned i1 = i0 + (half << a.logT);
         uint32_t x = lds[i0];
-        uint32_t y = bb::mul(lds[i1], tb.small[0][j << (KS - 1 - tt)]);
+        uint32_t y = bb::mul(lds[i1], tb.small[0][half + j]);
         lds[i0] = bb::add(x, y);
         lds[i1] = bb::sub(x, y);
     }
@@ -212,7 +214,7 @@ RK_HD void rev_stage_t(const PassArgs& a, const Tables& tb, uint32_t* lds, unsig
         unsigned lo = b & tmask, hb = b >> a.logT;
         unsigned j = hb & (half - 1), blk = hb >> hlog;
         i0[i] = (((blk << (hlog + 1)) + j) << a.logT) + lo;
-        w[i] = tb.small[1][j << (s + KS - a.g)];
+        w[i] = tb.small[1][half + j];
         x[i] = lds[i0[i]];
         y[i] = lds[i0[i] + (half << a.logT)];
     }
@@ -330,7 +332,7 @@ RK_HD void fwd_stage_t(const PassArgs& a, const Tables& tb, uint32_t* lds, unsig
         unsigned lo = b & tmask, hb = b >> a.logT;
         unsigned j = hb & (half - 1), blk = hb >> tt;
         i0[i] = (((blk << (tt + 1)) + j) << a.logT) + lo;
-        w[i] = tb.small[0][j << (KS - 1 - tt)];
+        w[i] = tb.small[0][half + j];
         x[i] = lds[i0[i]];
         y[i] = lds[i0[i] + (half << a.logT)];
     }
@@ -411,7 +413,7 @@ struct TableLayout {
     size_t small[2], hi[2], lo[2], pow3_hi, pow3_lo, total;
 };
 inline TableLayout table_layout() {
-    const size_t n_small = (size_t)1 << (KS - 1);
+    const size_t n_small = (size_t)1 << KS;
     const size_t n_hi = (size_t)1 << (LAMBDA - TW_SPLIT);
     const size_t n_lo = (size_t)1 << TW_SPLIT;
     TableLayout l{};
@@ -433,15 +435,19 @@ inline void fill_pow(uint32_t* v, size_t n, uint32_t base) {
 // h must hold table_layout().total words
 inline void fill_tables(uint32_t* h) {
     const TableLayout l = table_layout();
-    const size_t n_small = (size_t)1 << (KS - 1);
     const size_t n_hi = (size_t)1 << (LAMBDA - TW_SPLIT);
     const size_t n_lo = (size_t)1 << TW_SPLIT;
     // 137 generates the 2^27 subgroup of BabyBear
     uint32_t W = bb::pow(bb::encode(137), (uint64_t)1 << (27 - LAMBDA));
     uint32_t Winv = bb::inv(W);
-    uint32_t ws = bb::pow(W, (uint64_t)1 << (LAMBDA - KS));
-    fill_pow(h + l.small[0], n_small, ws);
-    fill_pow(h + l.small[1], n_small, bb::inv(ws));
+    for (int d = 0; d < 2; d++) {
+        h[l.small[d]] = bb::ONE;  // slot 0 unused
+        for (unsigned lg = 0; lg < KS; lg++) {
+            size_t half = (size_t)1 << lg;
+            uint32_t w = bb::pow(d == 0 ? W : Winv, (uint64_t)1 << (LAMBDA - lg - 1));  // order 2*half
+            fill_pow(h + l.small[d] + half, half, w);
+        }
+    }
     for (int d = 0; d < 2; d++) {
         uint32_t g = d == 0 ? W : Winv;
         fill_pow(h + l.hi[d], n_hi, bb::pow(g, (uint64_t)1 << TW_SPLIT));

@@ -93,6 +93,26 @@ __global__ __launch_bounds__(256) void k_poseidon2(uint32_t* out, const p2::Cons
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// same loop, stamped: shader clock (s_memtime) against the 100 MHz constant clock gives the
+// clock the chip actually holds under this integer load (stamps go to their own buffer)
+__global__ __launch_bounds__(256) void k_poseidon2_clk(uint32_t* out, const p2::Consts* __restrict__ kc,
+                                                       unsigned long long* stamps) {
+    uint32_t s[p2::CELLS];
+#pragma unroll
+    for (int i = 0; i < p2::CELLS; i++) s[i] = (threadIdx.x * 977u + i * 131u + blockIdx.x) % bb::P;
+    unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < P2_ITERS; it++) p2::permute(s, *kc);
+    unsigned long long c1 = clock64(), w1 = wall_clock64();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < p2::CELLS; i++) acc ^= s[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = c1 - c0;
+        stamps[2 * blockIdx.x + 1] = w1 - w0;
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
 template <typename F>
@@ -149,6 +169,24 @@ int main() {
     double nperm = (double)blocks * threads * P2_ITERS;
     ms = time_ms([&] { hipLaunchKernelGGL(k_poseidon2, dim3(blocks), dim3(threads), 0, 0, out, d); });
     printf("%-22s %8.3f ms  %8.3f Gperm/s  (%.1f ns/perm/CU-lane)\n", "poseidon2 t=24 permute", ms, nperm / ms / 1e6, ms * 1e6 / P2_ITERS);
+    {
+        unsigned long long* d_st;
+        CK(hipMalloc(&d_st, (size_t)blocks * 16));
+        for (int r = 0; r < 20; r++) hipLaunchKernelGGL(k_poseidon2, dim3(blocks), dim3(threads), 0, 0, out, d);  // heat up
+        hipLaunchKernelGGL(k_poseidon2_clk, dim3(blocks), dim3(threads), 0, 0, out, d, d_st);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st((size_t)blocks * 2);
+        CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> mhz;
+        double cyc = 0;
+        for (int b = 0; b < blocks; b++) {
+            if (st[2 * b + 1]) mhz.push_back((double)st[2 * b] / (double)st[2 * b + 1] * 100.0);
+            cyc += (double)st[2 * b];
+        }
+        std::sort(mhz.begin(), mhz.end());
+        printf("in-kernel clock under poseidon2 load: median %.0f MHz (min %.0f, max %.0f); %.0f shader cycles per wave-permutation-block\n",
+               mhz[mhz.size() / 2], mhz.front(), mhz.back(), cyc / blocks / P2_ITERS);
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }
