@@ -68,29 +68,58 @@ RK_HD uint32_t sbox7(uint32_t x) {
     return mul(x6, x);
 }
 
-// Signed Montgomery product: for |a|, |b| <= p returns r == a*b*2^-32 (mod p) with
-// |r| < 0.97 p, so chains of products need no conditional subtraction in between:
-//   t = a*b (signed 64-bit), q = lo32(t) * p^-1 as int32, r = hi32(t) - hi32(q*p)
-// (t - q*p is divisible by 2^32, |q*p| / 2^32 <= p/2, |t| / 2^32 <= 0.469 p).
-// gfx950: 2 x v_mul_lo_u32 + 2 x v_mul_hi_i32 (half rate) + v_sub; cheaper than the
-// v_mad_u64_u32 form (quarter rate) -- profiles/r01_ubench_intmul.txt.
-RK_HD int32_t mulhi_s32(int32_t a, int32_t b) {
+// Signed Montgomery product.  For ANY int32 a, b it returns r == a*b*2^-32 (mod p) with
+// |r| <= |a*b| / 2^32 + p/2 < 2^31, so chains of products need no reduction in between:
+//   t = a*b (signed 64-bit), q = lo32(t) * p^-1 (as int32), u = t - q*p (divisible by 2^32),
+//   r = hi32(u).
+// gfx950: v_mad_i64_i32 + v_mul_lo_u32 + v_mad_i64_i32.  Every VALU instruction except plain
+// VGPR/literal v_add/v_sub issues at 16 lanes/clk/SIMD on MI355X -- a 64-bit mad costs the
+// same as a v_min_u32 (profiles/r01_ubench_isa.txt) -- so instruction count is what matters.
+constexpr int32_t NEG_P = (int32_t)(0u - P);
+RK_HD int32_t redc64(int64_t t) {
+    int32_t q = (int32_t)((uint32_t)t * MPRIME);
+    int64_t u = t + (int64_t)q * (int64_t)NEG_P;
+    return (int32_t)(u >> 32);
+}
+RK_HD int32_t smul(int32_t a, int32_t b) { return redc64((int64_t)a * (int64_t)b); }
+// product with a constant c whose companion c_q = c * p^-1 mod 2^32 is precomputed: q does not
+// wait for the low half of the product
+RK_HD int32_t smul_const(int32_t a, int32_t c, uint32_t c_q) {
+    int64_t t = (int64_t)a * (int64_t)c;
+    int32_t q = (int32_t)((uint32_t)a * c_q);
+    int64_t u = t + (int64_t)q * (int64_t)NEG_P;
+    return (int32_t)(u >> 32);
+}
+// Unsigned Montgomery product with a constant c < p whose companion c_nq = c * (-p^-1) mod 2^32
+// is precomputed.  For any u with u*c < 2^32 * p + ... (here u < 2p): returns
+// r == u*c*2^-32 (mod p) with r < u*c / 2^32 + p  (< 1.94 p for u < 2p), one subtraction
+// from canonical.  v_mad_u64_u32 + v_mul_lo_u32 + v_mad_u64_u32.
+RK_HD uint32_t umul_const(uint32_t u, uint32_t c, uint32_t c_nq) {
+    uint64_t t = (uint64_t)u * c;
+    uint32_t q = u * c_nq;
+    uint64_t w = t + (uint64_t)q * P;  // low word cancels, no overflow: t, q*p < 2^63
+    return (uint32_t)(w >> 32);
+}
+// t * 2^-32 (mod p) for an unsigned 64-bit t < 2^63: result < t / 2^32 + p
+RK_HD uint32_t uredc64(uint64_t t) {
+    uint32_t q = (uint32_t)t * (0u - MPRIME);
+    uint64_t w = t + (uint64_t)q * P;
+    return (uint32_t)(w >> 32);
+}
+// acc + x as one 64-bit v_mad_u64_u32 (x * 1 + acc): hipcc otherwise zero-extends x with a
+// v_mov and adds with v_lshl_add_u64, two 4-cycle instructions per term
+RK_HD uint64_t acc_u32(uint64_t acc, uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __mulhi(a, b);
+    asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(x) : "vcc");
+    return acc;
 #else
-    return (int32_t)(((int64_t)a * (int64_t)b) >> 32);
+    return acc + x;
 #endif
 }
-RK_HD int32_t smul(int32_t a, int32_t b) {
-    uint32_t lo = (uint32_t)a * (uint32_t)b;
-    int32_t q = (int32_t)(lo * MPRIME);
-    return mulhi_s32(a, b) - mulhi_s32(q, (int32_t)P);
-}
-// product with a constant c whose companion c_q = c * p^-1 mod 2^32 is precomputed:
-// q = a * c_q needs no dependence on the low product (3 multiplies instead of 4)
-RK_HD int32_t smul_const(int32_t a, int32_t c, uint32_t c_q) {
-    int32_t q = (int32_t)((uint32_t)a * c_q);
-    return mulhi_s32(a, c) - mulhi_s32(q, (int32_t)P);
+// [0, 2p) -> [0, p)
+RK_HD uint32_t ucanon(uint32_t r) {
+    uint32_t s = r - P;
+    return s < r ? s : r;
 }
 // signed-lazy value in (-p, p) -> canonical [0, p)
 RK_HD uint32_t canon(int32_t r) {
