@@ -3,6 +3,7 @@
 // Each pass: one workgroup per 2^g x T tile, tile staged in LDS (<= 64 KiB so two
 // workgroups share a CU's 160 KiB), coalesced tile rows of T consecutive elements.
 #include "internal.hpp"
+#include "ntt_r16.hpp"
 
 namespace {
 
@@ -55,6 +56,46 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel_u(ntt::PassArgs a, ntt::
     }
 }
 
+// register-blocked passes on full 2^14 tiles (ntt_r16.hpp)
+template <bool FWD, int NST>
+__device__ __forceinline__ void r16_round(uint32_t* v, const ntt::Tables& tb, unsigned ls, unsigned rlow) {
+    if (FWD) r16::round_dit<NST>(v, tb.small[0], ls, rlow);
+    else r16::round_dif<NST>(v, tb.small[1], ls, rlow);
+}
+template <bool FWD, bool CONTIG>
+__global__ __launch_bounds__(1024) void ntt_r16_kernel(r16::Args a, ntt::Tables tb, r16::Sched sc) {
+    __shared__ uint32_t lds[r16::LDS_WORDS];
+    const unsigned tid = threadIdx.x;
+    const r16::Tile t = r16::tile_of(a, blockIdx.x);
+    if (CONTIG) {
+        if (FWD) r16::load_fwd_contig(a, t, lds, tid);
+        else r16::load_rev_contig(a, tb, t, lds, tid);
+    } else {
+        r16::load_plain(a, t, lds, tid);
+    }
+    __syncthreads();
+    for (unsigned rd = 0; rd < sc.n; rd++) {
+        const unsigned ls = sc.ls[rd];
+        const r16::RoundIdx x = r16::round_idx(tid, a.g, ls);
+        uint32_t v[16];
+        r16::round_read(v, lds, x);
+        switch (sc.nst[rd]) {
+            case 4: r16_round<FWD, 4>(v, tb, ls, x.rlow); break;
+            case 3: r16_round<FWD, 3>(v, tb, ls, x.rlow); break;
+            case 2: r16_round<FWD, 2>(v, tb, ls, x.rlow); break;
+            default: r16_round<FWD, 1>(v, tb, ls, x.rlow); break;
+        }
+        r16::round_write(v, lds, x);
+        __syncthreads();
+    }
+    if (CONTIG) {
+        if (FWD) r16::store_fwd_contig(a, tb, t, lds, tid);
+        else r16::store_rev_contig(a, tb, t, lds, tid);
+    } else {
+        r16::store_plain(a, t, lds, tid);
+    }
+}
+
 __global__ void zk_shift_kernel(uint32_t* io, size_t total, size_t size, unsigned bits, ntt::Tables tb) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -101,6 +142,18 @@ int launch_pass(rk_ctx* ctx, const ntt::PassArgs& a, size_t count) {
     return rk::post_launch(ctx, FWD ? "ntt_pass_kernel<fwd>" : "ntt_pass_kernel<rev>");
 }
 
+template <bool FWD, bool CONTIG>
+int launch_r16(rk_ctx* ctx, const r16::Args& a, size_t count) {
+    size_t blocks = count * (a.n >> r16::TILE_LOG);
+    if (blocks == 0 || blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    r16::Sched sc = FWD ? r16::sched_dit(a.g, a.expand_bits) : r16::sched_dif(a.g);
+    rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)count * 4 * (a.n_src + a.n));
+    hipLaunchKernelGGL((ntt_r16_kernel<FWD, CONTIG>), dim3((unsigned)blocks), dim3(r16::NTHR), 0, ctx->stream, a, ctx->tb,
+                       sc);
+    return rk::post_launch(ctx, "ntt_r16_kernel");
+}
+inline bool aligned16(const void* p, const void* q) { return ((((uintptr_t)p) | ((uintptr_t)q)) & 15) == 0; }
+
 }  // namespace
 
 namespace rk {
@@ -112,6 +165,20 @@ int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fus
     if (k == 0) {
         // size-1 transform: identity (1/1 scale, 3^0 shift)
         return RK_OK;
+    }
+    if (r16::usable(k, 0, aligned16(d_io, d_io))) {
+        r16::Args a{};
+        a.dst = d_io;
+        a.src = d_io;
+        a.n = a.n_src = size;
+        a.k = k;
+        a.g = k - r16::TILE_LOG;
+        RK_TRY((launch_r16<false, false>(ctx, a, count)));
+        a.g_outer = a.g;
+        a.g = r16::TILE_LOG;
+        a.scale = scale;
+        a.zk = fuse_zk_shift ? 1 : 0;
+        return launch_r16<false, true>(ctx, a, count);
     }
     ntt::Plan plan = ntt::make_plan(k);
     for (unsigned p = 0; p < plan.npass; p++) {
@@ -142,6 +209,24 @@ int ntt_forward(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_si
         if (d_out != d_in)
             RK_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
         return RK_OK;
+    }
+    if (r16::usable(k, expand_bits, aligned16(d_out, d_in))) {
+        r16::Args a{};
+        a.dst = d_out;
+        a.src = d_in;
+        a.n = size;
+        a.n_src = in_size;
+        a.k = k;
+        a.g = r16::TILE_LOG;
+        a.g_outer = k - r16::TILE_LOG;
+        a.expand_bits = expand_bits;
+        RK_TRY((launch_r16<true, true>(ctx, a, count)));
+        a.src = d_out;
+        a.n_src = size;
+        a.g = k - r16::TILE_LOG;
+        a.g_outer = 0;
+        a.expand_bits = 0;
+        return launch_r16<true, false>(ctx, a, count);
     }
     if (expand_bits == 0 && d_out != d_in) {
         RK_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, count * size * sizeof(uint32_t), hipMemcpyDeviceToDevice,

@@ -8,6 +8,7 @@
 
 #include "bb.hpp"
 #include "ntt_core.hpp"
+#include "ntt_r16.hpp"
 #include "poseidon2_core.hpp"
 #include "poseidon2_consts.inc"
 
@@ -76,6 +77,50 @@ void run_pass(const ntt::PassArgs& a, size_t count, unsigned nthr) {
         }
     }
 }
+// mirrors ntt_r16_kernel / launch_r16 of kernels_ntt.hip
+template <bool FWD, bool CONTIG>
+void run_r16(const r16::Args& a, size_t count) {
+    size_t blocks = count * (a.n >> r16::TILE_LOG);
+    r16::Sched sc = FWD ? r16::sched_dit(a.g, a.expand_bits) : r16::sched_dif(a.g);
+    std::vector<uint32_t> lds(r16::LDS_WORDS);
+    for (size_t blk = 0; blk < blocks; blk++) {
+        r16::Tile t = r16::tile_of(a, blk);
+        for (unsigned tid = 0; tid < r16::NTHR; tid++) {
+            if (CONTIG) {
+                if (FWD) r16::load_fwd_contig(a, t, lds.data(), tid);
+                else r16::load_rev_contig(a, g_tb, t, lds.data(), tid);
+            } else {
+                r16::load_plain(a, t, lds.data(), tid);
+            }
+        }
+        for (unsigned rd = 0; rd < sc.n; rd++) {
+            unsigned ls = sc.ls[rd];
+            // all lanes read, then all lanes write: a round is in place per lane, so lane order is free
+            for (unsigned tid = 0; tid < r16::NTHR; tid++) {
+                r16::RoundIdx x = r16::round_idx(tid, a.g, ls);
+                uint32_t v[16];
+                r16::round_read(v, lds.data(), x);
+                const uint32_t* tw = g_tb.small[FWD ? 0 : 1];
+                switch (sc.nst[rd]) {
+                    case 4: FWD ? r16::round_dit<4>(v, tw, ls, x.rlow) : r16::round_dif<4>(v, tw, ls, x.rlow); break;
+                    case 3: FWD ? r16::round_dit<3>(v, tw, ls, x.rlow) : r16::round_dif<3>(v, tw, ls, x.rlow); break;
+                    case 2: FWD ? r16::round_dit<2>(v, tw, ls, x.rlow) : r16::round_dif<2>(v, tw, ls, x.rlow); break;
+                    default: FWD ? r16::round_dit<1>(v, tw, ls, x.rlow) : r16::round_dif<1>(v, tw, ls, x.rlow); break;
+                }
+                r16::round_write(v, lds.data(), x);
+            }
+        }
+        for (unsigned tid = 0; tid < r16::NTHR; tid++) {
+            if (CONTIG) {
+                if (FWD) r16::store_fwd_contig(a, g_tb, t, lds.data(), tid);
+                else r16::store_rev_contig(a, g_tb, t, lds.data(), tid);
+            } else {
+                r16::store_plain(a, t, lds.data(), tid);
+            }
+        }
+    }
+}
+inline bool aligned16(const void* p, const void* q) { return ((((uintptr_t)p) | ((uintptr_t)q)) & 15) == 0; }
 unsigned log2u(size_t n) {
     unsigned k = 0;
     while (((size_t)1 << k) < n) k++;
@@ -91,6 +136,14 @@ int emul_ntt_reverse(uint32_t* io, size_t size, size_t count, int fuse_zk, unsig
     unsigned k = log2u(size);
     if (k == 0) return 0;
     uint32_t scale = bb::inv(bb::encode((uint32_t)size));
+    if (max_tile_log == ntt::MAX_TILE_LOG && r16::usable(k, 0, aligned16(io, io))) {
+        r16::Args a{};
+        a.dst = io; a.src = io; a.n = a.n_src = size; a.k = k; a.g = k - r16::TILE_LOG;
+        run_r16<false, false>(a, count);
+        a.g_outer = a.g; a.g = r16::TILE_LOG; a.scale = scale; a.zk = fuse_zk ? 1 : 0;
+        run_r16<false, true>(a, count);
+        return 102;
+    }
     ntt::Plan plan = ntt::make_plan(k, max_tile_log);
     for (unsigned p = 0; p < plan.npass; p++) {
         ntt::PassArgs a{};
@@ -110,6 +163,15 @@ int emul_ntt_forward(uint32_t* out, const uint32_t* in, size_t in_size, size_t c
     size_t size = in_size << expand_bits;
     unsigned k = log2u(size);
     if (k == 0) { std::memcpy(out, in, count * 4); return 0; }
+    if (max_tile_log == ntt::MAX_TILE_LOG && r16::usable(k, expand_bits, aligned16(out, in))) {
+        r16::Args a{};
+        a.dst = out; a.src = in; a.n = size; a.n_src = in_size; a.k = k; a.g = r16::TILE_LOG;
+        a.g_outer = k - r16::TILE_LOG; a.expand_bits = expand_bits;
+        run_r16<true, true>(a, count);
+        a.src = out; a.n_src = size; a.g = k - r16::TILE_LOG; a.g_outer = 0; a.expand_bits = 0;
+        run_r16<true, false>(a, count);
+        return 102;
+    }
     if (expand_bits == 0 && out != in) { std::memcpy(out, in, count * size * 4); in = out; }
     ntt::Plan plan = ntt::make_plan(k, max_tile_log);
     for (unsigned pi = plan.npass; pi-- > 0;) {
