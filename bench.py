@@ -31,6 +31,10 @@ def parse_args():
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,16,224", help="accum,code,data column counts")
     ap.add_argument("--cpu-po2", type=int, default=16, help="segment size of the bounded CPU-oracle sample")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="segments proven concurrently per GPU (one prover context + HIP stream each); "
+                         "the latency-bound parts of one proof (Merkle tops, transcript round trips) "
+                         "overlap the throughput-bound parts of the other")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
@@ -72,33 +76,59 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    stream = torch.cuda.Stream(device=device)
-    hal = HipHal(local_rank, stream=stream.cuda_stream)
+    import threading
+    n_ctx = max(1, min(args.inflight, args.steps))
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_ctx)]
+    hals = [HipHal(local_rank, stream=st.cuda_stream) for st in streams]
+    hal = hals[0]
 
     # two distinct resident segments per rank, alternated, so no step sees data it just proved
     segs = [device_segment(torch, seg_mod, args.po2, widths, 20240807 + 1000 * rank + i, device) for i in range(2)]
     torch.cuda.synchronize()
 
-    def prove(i):
+    def prove(i, h=None):
         seg, groups, check = segs[i % 2]
-        return hal.prove_segment(seg, device_inputs=(groups, check))
+        return (h or hal).prove_segment(seg, device_inputs=(groups, check))
+
+    def prove_many(indices):
+        """prove the given step indices, n_ctx at a time (one host thread per context)"""
+        out = {}
+        stage = {}
+        err = []
+
+        def worker(w):
+            try:
+                for i in indices[w::n_ctx]:
+                    out[i] = prove(i, hals[w])
+                    for k, v in hals[w].last_timing().items():
+                        stage[(w, i, k)] = v
+            except Exception as e:  # surface in the main thread
+                err.append(e)
+
+        ts = [threading.Thread(target=worker, args=(w,)) for w in range(n_ctx)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return [out[i] for i in indices], stage
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        prove(i)
-    hal.set_kernel_timing(True)
+    if args.warmup:
+        prove_many(list(range(max(args.warmup, n_ctx))))
+    for h in hals:
+        h.set_kernel_timing(True)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    seals = []
+    seals, stage = prove_many(list(range(args.steps)))
     stage_ms = {}
-    for i in range(args.steps):
-        seals.append(prove(i))
-        for k, v in hal.last_timing().items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    for (w, i, k), v in stage.items():
+        stage_ms[k] = stage_ms.get(k, 0.0) + v
     if world > 1:
         # rank r proved global segments r, r+world, ...: gather in that order (one collective)
         gather_seals(seals, args.steps * world, device=device)
@@ -109,8 +139,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kstats = hal.kernel_stats()
-    hal.set_kernel_timing(False)
+    kstats = {}
+    for h in hals:
+        for name, st in h.kernel_stats().items():
+            acc = kstats.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0})
+            for f in acc:
+                acc[f] += st[f]
+        h.set_kernel_timing(False)
 
     if rank == 0:
         cycles = world * args.steps * (1 << args.po2)
@@ -146,7 +181,8 @@ def main():
             "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
             "config": {"workload": "S%d: one 2^%d-cycle segment proof, W=%s (accum/code/data) + 16 check columns, "
                                    "blow-up 4, Poseidon2 Merkle, FRI arity 16, 50 queries" % (args.po2, args.po2, args.widths),
-                       "segments_per_gpu_per_step": 1, "parallelism": "segment-parallel x%d" % world},
+                       "segments_per_gpu_per_step": 1, "segments_in_flight_per_gpu": n_ctx,
+                       "parallelism": "segment-parallel x%d" % world},
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_segment": algo["total"],
                          "hbm_frac_end_to_end": round(algo["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
@@ -179,7 +215,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    hal.close()
+    for h in hals:
+        h.close()
 
 
 if __name__ == "__main__":
