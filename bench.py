@@ -118,6 +118,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # One serial calibration proof (also a warm-up): with a single stream the hipEvent brackets
+    # are pure kernel time, which picks the dominant kernel class; under concurrency a bracket
+    # also contains time spent queued behind the other context's kernels.
+    hal.set_kernel_timing(True)
+    prove(0)
+    calib = hal.kernel_stats()
+    hal.set_kernel_timing(False)
+    dom_name = max(calib.items(), key=lambda kv: kv[1]["ms"])[0]
     if args.warmup:
         prove_many(list(range(max(args.warmup, n_ctx))))
     for h in hals:
@@ -150,16 +158,19 @@ def main():
     if rank == 0:
         cycles = world * args.steps * (1 << args.po2)
         value = cycles / elapsed
-        # dominant kernel = the class with the most device time in the timed region
-        dom_name, dom = max(kstats.items(), key=lambda kv: kv[1]["ms"])
+        # dominant kernel = the class with the most device time in a serial proof (see above);
+        # its numbers below are from the hipEvent brackets of the timed region
+        dom = kstats[dom_name]
         achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
             "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
-            "note": "Poseidon2 hashing is integer-ALU-bound (about 1.36k modular multiplies per 64 B absorbed); "
-                    "the HBM fraction is reported because it is the contract figure",
+            "serial_avg_launch_ms": round(calib[dom_name]["ms"] / max(calib[dom_name]["launches"], 1), 4),
+            "note": "Poseidon2 hashing is integer-ALU-bound (about 1.36k modular multiplies per 64 B absorbed, "
+                    "~14k VALU instructions per permutation at 16 lanes/clk/SIMD); the HBM fraction is "
+                    "reported because it is the contract figure",
         }
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):

@@ -133,6 +133,39 @@ KERNELBIG(k_big_add_4k, "v_add_u32", 512, 8)
         if (threadIdx.x == 0) { st[2 * blockIdx.x] = c1 - c0; st[2 * blockIdx.x + 1] = w1 - w0; }  \
     }
 KERNELMAD(k_mad_u64, "v_mad_u64_u32")
+// 64-bit shift-add: d = (a << k) + b on register pairs
+#define KERNELLSHL(NAME, SH)                                                                      \
+    __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned long long* st, unsigned y) { \
+        unsigned long long x0 = threadIdx.x + 1, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7, z = y;     \
+        unsigned long long c0 = clock64(), w0 = wall_clock64();                                   \
+        for (int i = 0; i < ITERS; i++) {                                                         \
+            asm volatile("v_lshl_add_u64 %0, %0, " #SH ", %4\n v_lshl_add_u64 %1, %1, " #SH ", %4\n"  \
+                         "v_lshl_add_u64 %2, %2, " #SH ", %4\n v_lshl_add_u64 %3, %3, " #SH ", %4\n"  \
+                         "v_lshl_add_u64 %0, %0, " #SH ", %4\n v_lshl_add_u64 %1, %1, " #SH ", %4\n"  \
+                         "v_lshl_add_u64 %2, %2, " #SH ", %4\n v_lshl_add_u64 %3, %3, " #SH ", %4\n"  \
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(z));                       \
+        }                                                                                         \
+        unsigned long long c1 = clock64(), w1 = wall_clock64();                                   \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(x0 ^ x1 ^ x2 ^ x3);               \
+        if (threadIdx.x == 0) { st[2 * blockIdx.x] = c1 - c0; st[2 * blockIdx.x + 1] = w1 - w0; }  \
+    }
+KERNELLSHL(k_lshl_add_u64_0, 0)
+KERNELLSHL(k_lshl_add_u64_2, 2)
+// mad with an inline-constant multiplier (5*x + acc)
+__global__ __launch_bounds__(256) void k_mad_u64_lit(unsigned* out, unsigned long long* st, unsigned y) {
+    unsigned long long x0 = threadIdx.x + 1, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+    unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < ITERS; i++) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %4, 5, %0\n v_mad_u64_u32 %1, vcc, %4, 7, %1\n"
+                     "v_mad_u64_u32 %2, vcc, %4, 3, %2\n v_mad_u64_u32 %3, vcc, %4, 1, %3\n"
+                     "v_mad_u64_u32 %0, vcc, %4, 5, %0\n v_mad_u64_u32 %1, vcc, %4, 7, %1\n"
+                     "v_mad_u64_u32 %2, vcc, %4, 3, %2\n v_mad_u64_u32 %3, vcc, %4, 1, %3\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y) : "vcc");
+    }
+    unsigned long long c1 = clock64(), w1 = wall_clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(x0 ^ x1 ^ x2 ^ x3);
+    if (threadIdx.x == 0) { st[2 * blockIdx.x] = c1 - c0; st[2 * blockIdx.x + 1] = w1 - w0; }
+}
 KERNELMAD(k_mad_i64, "v_mad_i64_i32")
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -196,6 +229,9 @@ int main() {
     run("dep v_mul_hi_u32", k_dep_mul_hi, cus);
     printf("dependent chains, 4 waves per SIMD:\n");
     run("v_mad_u64_u32", k_mad_u64, cus);
+    run("v_mad_u64_u32 (inline const)", k_mad_u64_lit, cus);
+    run("v_lshl_add_u64 (shift 0)", k_lshl_add_u64_0, cus);
+    run("v_lshl_add_u64 (shift 2)", k_lshl_add_u64_2, cus);
     run("v_mad_i64_i32", k_mad_i64, cus);
     return 0;
 }
