@@ -39,6 +39,49 @@ def test_ntt_passes_match_oracle(orc, emu, k, max_tile_log, nthr):
     assert np.array_equal(back, x)
 
 
+@pytest.mark.parametrize("k", [18, 19, 21])
+def test_register_blocked_passes_match_oracle(orc, emu, k):
+    """ntt_r16.hpp (the path taken for 2^18..2^22 points): strided radix-16 rounds + contiguous
+    pass carrying the four-step twiddle, fused 1/n and zk shift, 4x expanding forward pass"""
+    rng = np.random.default_rng(4000 + k)
+    n, cnt = 1 << k, 1
+    x = o.rand_elems(rng, (cnt, n))
+    want = x.copy()
+    orc.or_batch_interpolate_ntt(want.ctypes.data, n, cnt)
+    got = x.copy()
+    assert emu.emul_ntt_reverse(got.ctypes.data, n, cnt, 0, 14, 64) == 102  # 102 = r16 path taken
+    assert np.array_equal(got, want)
+    want_zk = want.copy()
+    orc.or_zk_shift(want_zk.ctypes.data, n, cnt)
+    got_zk = x.copy()
+    emu.emul_ntt_reverse(got_zk.ctypes.data, n, cnt, 1, 14, 64)
+    assert np.array_equal(got_zk, want_zk)
+    back = want.copy()
+    assert emu.emul_ntt_forward(back.ctypes.data, back.ctypes.data, n, cnt, 0, 14, 64) == 102
+    assert np.array_equal(back, x)
+    if k <= 19:
+        want_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
+        orc.or_batch_expand_into_evaluate_ntt(want_e.ctypes.data, want_zk.ctypes.data, n, cnt, 2)
+        got_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
+        assert emu.emul_ntt_forward(got_e.ctypes.data, got_zk.ctypes.data, n, cnt, 2, 14, 64) == 102
+        assert np.array_equal(got_e, want_e)
+
+
+def test_poseidon2_many_states(orc, emu):
+    """the scaled-round / 64-bit-layer permutation against the oracle on many states incl. extremes"""
+    rng = np.random.default_rng(99)
+    for i in range(3000):
+        st = o.rand_elems(rng, (24,))
+        if i < 4:
+            st[:] = [0, P - 1, 1, P - 2][i]
+        if i == 4:
+            st[::2] = P - 1
+        a, b = st.copy(), st.copy()
+        orc.or_poseidon2_mix(a.ctypes.data)
+        emu.emul_poseidon2_permute(b.ctypes.data)
+        assert np.array_equal(a, b), i
+
+
 def test_three_pass_plan(orc, emu):
     """sizes that need two strided passes + the contiguous one"""
     rng = np.random.default_rng(77)
