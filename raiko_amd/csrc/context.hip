@@ -22,6 +22,7 @@ int dev_alloc(rk_ctx* ctx, size_t bytes, void** out) {
     if (it != ctx->free_list.end()) {
         *out = it->second;
         ctx->free_list.erase(it);
+        ctx->pooled_bytes -= bytes;
         ctx->live[*out] = bytes;
         return RK_OK;
     }
@@ -29,8 +30,10 @@ int dev_alloc(rk_ctx* ctx, size_t bytes, void** out) {
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         // drop the cache and retry once
+        (void)hipStreamSynchronize(ctx->stream);
         for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
         ctx->free_list.clear();
+        ctx->pooled_bytes = 0;
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
@@ -46,7 +49,16 @@ int dev_free(rk_ctx* ctx, void* p) {
     auto it = ctx->live.find(p);
     if (it == ctx->live.end()) return RK_ERR_INVALID;
     ctx->free_list.emplace(it->second, p);
+    ctx->pooled_bytes += it->second;
     ctx->live.erase(it);
+    if (ctx->pooled_bytes > ctx->pool_limit) {
+        // shapes keep changing (e.g. a service proving different po2): hand the cache back.
+        // Blocks may still be referenced by queued kernels, so drain the stream first.
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
+        ctx->free_list.clear();
+        ctx->pooled_bytes = 0;
+    }
     return RK_OK;
 }
 int scratch(rk_ctx* ctx, size_t bytes, void** out) {

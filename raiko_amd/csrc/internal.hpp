@@ -29,6 +29,8 @@ struct rk_ctx {
     // caching allocator (exact-size free lists) so steady-state proving never calls hipMalloc
     std::multimap<size_t, void*> free_list;
     std::unordered_map<void*, size_t> live;
+    size_t pooled_bytes = 0;                         // bytes parked in free_list
+    size_t pool_limit = (size_t)64 << 30;            // above this the cache is dropped (varying shapes)
 
     // small staging area for per-call parameter uploads
     void* d_scratch = nullptr;
