@@ -35,6 +35,7 @@ def parse_args():
                     help="segments proven concurrently per GPU (one prover context + HIP stream each); "
                          "the latency-bound parts of one proof (Merkle tops, transcript round trips) "
                          "overlap the throughput-bound parts of the other")
+    ap.add_argument("--pinned", action="store_true", help="with --host-inputs: page-locked host arrays")
     ap.add_argument("--host-inputs", action="store_true",
                     help="prove from pageable host arrays (PCIe upload inside the timed region); not the contract "
                          "configuration, used for the PCIe-inclusive rate quoted in DESIGN.md")
@@ -92,10 +93,17 @@ def main():
     host_segs = None
     if args.host_inputs:
         host_segs = []
+        def to_host(t):
+            h = t.cpu()
+            if args.pinned:
+                h = h.pin_memory()
+            host_keep.append(h)
+            return h.numpy().view(np.uint32)
+
+        host_keep = []
         for seg, groups, check in segs:
-            host_segs.append(seg_mod.Segment(po2=seg.po2, taps=seg.taps,
-                                             groups=[g.cpu().numpy().view(np.uint32) for g in groups],
-                                             check=check.cpu().numpy().view(np.uint32), globals_=seg.globals_))
+            host_segs.append(seg_mod.Segment(po2=seg.po2, taps=seg.taps, groups=[to_host(g) for g in groups],
+                                             check=to_host(check), globals_=seg.globals_))
 
     def prove(i, h=None):
         if host_segs is not None:

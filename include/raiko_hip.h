@@ -127,6 +127,13 @@ typedef struct {
 /* Produces the seal (the u32 Fiat-Shamir transcript) of one segment. */
 int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t seal_capacity_words,
                      size_t* seal_words);
+/* Host-side verifier (no GPU needed): the counterpart of `receipt.verify()` the reference calls
+ * after proving (provers/risc0/driver/src/lib.rs:136, benchmark.rs:19); restates risc0-zkp
+ * verify/{mod,fri,merkle}.rs for the flow of rk_prove_segment.  Reads only the public part of
+ * `pub` (po2, taps, globals, n_accum_mix, infos).  Returns 0 for a valid seal, RK_ERR_INVALID for
+ * malformed arguments, a positive reason code otherwise (see verify.hip).  The circuit's
+ * constraint identity is NOT checked (no rv32im circuit in this repo). */
+int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_words);
 /* Upper bound on the seal size for a given shape. */
 size_t rk_seal_bound_words(const rk_segment* seg);
 

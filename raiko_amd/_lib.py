@@ -95,6 +95,7 @@ SYMBOLS = {
     "rk_merkle_build": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
     "rk_poly_divide": (C.c_int, [_vp, _vp, _sz, u32p, u32p]),
     "rk_prove_segment": (C.c_int, [_vp, C.POINTER(RkSegment), u32p, _sz, C.POINTER(_sz)]),
+    "rk_verify_segment": (C.c_int, [C.POINTER(RkSegment), u32p, _sz]),
     "rk_seal_bound_words": (_sz, [C.POINTER(RkSegment)]),
     "rk_last_timing": (C.c_int, [_vp, C.POINTER(RkTiming)]),
     "rk_set_kernel_timing": (C.c_int, [_vp, C.c_int]),

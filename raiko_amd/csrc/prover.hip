@@ -300,7 +300,9 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         RK_TRY(dst.alloc(ctx, words * 4));
         RK_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, words * 4,
                                        seg->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-        if (!seg->on_device) RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // host inputs stay valid until rk_prove_segment returns (it always drains the stream before
+        // returning), so the upload needs no synchronisation here: with page-locked buffers it is a
+        // true DMA that overlaps the kernels already queued
         return RK_OK;
     };
     // Prover::commit_group

@@ -1,0 +1,320 @@
+// Host-side seal verifier: the counterpart of `receipt.verify(image_id)` that the reference
+// calls after proving (provers/risc0/driver/src/lib.rs:136, benchmark.rs:19, bonsai.rs:67),
+// restating risc0-zkp 1.0.1 verify/{mod,fri,merkle,read_iop}.rs for the flow of
+// rk_prove_segment.  Pure CPU code (no GPU needed): a host can check seals produced elsewhere.
+//
+// Not checked: the circuit's constraint identity (check polynomial against the rv32im
+// constraint system evaluated on the tap openings) -- risc0-circuit-rv32im is not available,
+// see DESIGN.md section 6.  Everything else is: transcript binding, Merkle openings, the DEEP
+// quotient at every query, FRI folds and the final low-degree polynomial.
+#include "internal.hpp"
+#include "poseidon2_consts.inc"
+
+#include <cstring>
+
+namespace {
+
+using bb::Ext;
+
+const p2::Consts& default_consts() {
+    static p2::Consts k = [] {
+        p2::Consts c{};
+        std::memcpy(c.rc_ext, P2_RC_EXT_MONT, sizeof c.rc_ext);
+        std::memcpy(c.rc_int, P2_RC_INT_MONT, sizeof c.rc_int);
+        std::memcpy(c.diag, P2_INT_DIAG_MONT, sizeof c.diag);
+        p2::derive(c);
+        return c;
+    }();
+    return k;
+}
+
+struct Sponge {  // Poseidon2Rng
+    const p2::Consts& k;
+    uint32_t cells[p2::CELLS];
+    unsigned used = 0;
+    explicit Sponge(const p2::Consts& kc) : k(kc) { std::memset(cells, 0, sizeof cells); }
+    void mix(const uint32_t* d) {
+        if (used) {
+            p2::permute(cells, k);
+            used = 0;
+        }
+        for (int i = 0; i < p2::OUT; i++) cells[i] = bb::add(cells[i], d[i]);
+        p2::permute(cells, k);
+    }
+    uint32_t elem() {
+        if (used == p2::RATE) {
+            p2::permute(cells, k);
+            used = 0;
+        }
+        return cells[used++];
+    }
+    Ext ext() {
+        Ext r;
+        for (int i = 0; i < 4; i++) r.c[i] = elem();
+        return r;
+    }
+    uint32_t bits(unsigned n) {
+        uint32_t v = bb::decode(elem());
+        for (int i = 0; i < 3; i++) v ^= bb::decode(elem());
+        return v & (uint32_t)(((uint64_t)1 << n) - 1);
+    }
+};
+
+void hash_slice(const p2::Consts& k, const uint32_t* in, size_t n, uint32_t* out) {
+    uint32_t s[p2::CELLS];
+    std::memset(s, 0, sizeof s);
+    size_t fill = 0;
+    for (size_t i = 0; i < n; i++) {
+        s[fill++] = in[i];
+        if (fill == p2::RATE) {
+            p2::permute(s, k);
+            fill = 0;
+        }
+    }
+    if (fill || n == 0) {
+        for (size_t i = fill; i < p2::RATE; i++) s[i] = 0;
+        p2::permute(s, k);
+    }
+    std::memcpy(out, s, 32);
+}
+void hash_pair(const p2::Consts& k, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    uint32_t s[p2::CELLS];
+    std::memcpy(s, a, 32);
+    std::memcpy(s + 8, b, 32);
+    std::memset(s + 16, 0, 32);
+    p2::permute(s, k);
+    std::memcpy(out, s, 32);
+}
+
+struct Reader {
+    const uint32_t* p;
+    size_t len, pos = 0;
+    bool short_read = false;
+    void read(uint32_t* out, size_t n) {
+        if (pos + n > len) {
+            short_read = true;
+            std::memset(out, 0, n * 4);
+            return;
+        }
+        std::memcpy(out, p + pos, n * 4);
+        pos += n;
+    }
+};
+
+struct TreeVerifier {  // MerkleTreeVerifier
+    size_t rows = 0, cols = 0, top_size = 1;
+    std::vector<uint32_t> top;  // heap, index 1 = root
+    void init(const p2::Consts& k, Reader& r, Sponge& rng, size_t rows_, size_t cols_, size_t queries) {
+        rows = rows_;
+        cols = cols_;
+        size_t layers = log2u(rows), top_layer = 0;
+        for (size_t i = 1; i < layers; i++) {
+            if (((size_t)1 << i) > queries) break;
+            top_layer = i;
+        }
+        top_size = (size_t)1 << top_layer;
+        top.assign(2 * top_size * 8, 0);
+        r.read(top.data() + top_size * 8, top_size * 8);
+        for (size_t i = top_size; i-- > 1;) hash_pair(k, &top[2 * i * 8], &top[(2 * i + 1) * 8], &top[i * 8]);
+        rng.mix(&top[8]);
+    }
+    bool open(const p2::Consts& k, Reader& r, size_t idx, uint32_t* row) const {
+        if (idx >= rows) return false;
+        r.read(row, cols);
+        uint32_t cur[8], other[8], nxt[8];
+        hash_slice(k, row, cols, cur);
+        idx += rows;
+        while (idx >= 2 * top_size) {
+            bool right = idx & 1;
+            r.read(other, 8);
+            idx >>= 1;
+            if (right) hash_pair(k, other, cur, nxt);
+            else hash_pair(k, cur, other, nxt);
+            std::memcpy(cur, nxt, 32);
+        }
+        return std::memcmp(cur, &top[idx * 8], 32) == 0;
+    }
+};
+
+Ext poly_eval(const Ext* c, size_t n, const Ext& x) {
+    Ext acc = bb::ext_zero();
+    for (size_t i = n; i-- > 0;) acc = bb::add(bb::mul(acc, x), c[i]);
+    return acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 0: the seal is a valid proof for the public data of `pub` (po2, taps, globals, infos);
+// RK_ERR_INVALID: malformed arguments; otherwise a positive reason code:
+//   10 header mismatch, 2x group opening failed (x = group id, 3 = check), 3x FRI round opening,
+//   4x fold inconsistency, 50 final polynomial mismatch, 60 seal too short, 61 trailing words
+int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_words) {
+    if (!pub || !seal) return RK_ERR_INVALID;
+    const rk_taps& taps = pub->taps;
+    if (!taps.reg_group || !taps.reg_offset || !taps.reg_combo || !taps.combo_off || !taps.combo_backs)
+        return RK_ERR_INVALID;
+    if (pub->po2 < 1 || pub->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
+    const p2::Consts& k = default_consts();
+    const size_t QUERIES = 50, FOLD = 16, MIN_DEGREE = 256, CHECK = 16;
+    Reader r{seal, seal_words};
+    Sponge rng(k);
+    uint32_t digest[8], e16[16];
+    for (int i = 0; i < 16; i++) e16[i] = bb::encode(pub->proof_system_info[i]);
+    hash_slice(k, e16, 16, digest);
+    rng.mix(digest);
+    for (int i = 0; i < 16; i++) e16[i] = bb::encode(pub->circuit_info[i]);
+    hash_slice(k, e16, 16, digest);
+    rng.mix(digest);
+
+    std::vector<uint32_t> io(pub->n_globals + 1);
+    r.read(io.data(), pub->n_globals);
+    uint32_t po2 = 0;
+    r.read(&po2, 1);
+    if (r.short_read || po2 != pub->po2) return 10;
+    if (pub->n_globals && std::memcmp(io.data(), pub->globals, pub->n_globals * 4) != 0) return 10;
+    io[pub->n_globals] = bb::encode(po2);
+    hash_slice(k, io.data(), io.size(), digest);
+    rng.mix(digest);
+
+    const size_t N = (size_t)1 << po2, D = 4 * N;
+    TreeVerifier tg[3], tcheck;
+    tg[1].init(k, r, rng, D, taps.group_size[1], QUERIES);
+    tg[2].init(k, r, rng, D, taps.group_size[2], QUERIES);
+    for (uint32_t i = 0; i < pub->n_accum_mix; i++) (void)rng.elem();
+    tg[0].init(k, r, rng, D, taps.group_size[0], QUERIES);
+    (void)rng.ext();  // poly_mix
+    tcheck.init(k, r, rng, D, CHECK, QUERIES);
+    const Ext z = rng.ext();
+    const uint32_t w27 = bb::encode(137);
+    const uint32_t back_one = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - po2)));
+
+    size_t tot_taps = 0;
+    const size_t tot_backs = taps.combo_off[taps.n_combos];
+    for (uint32_t i = 0; i < taps.n_regs; i++) {
+        if (taps.reg_combo[i] >= taps.n_combos || taps.reg_group[i] > 2 ||
+            taps.reg_offset[i] >= taps.group_size[taps.reg_group[i]])
+            return RK_ERR_INVALID;
+        tot_taps += taps.combo_off[taps.reg_combo[i] + 1] - taps.combo_off[taps.reg_combo[i]];
+    }
+    std::vector<Ext> coeff_u(tot_taps + CHECK);
+    r.read((uint32_t*)coeff_u.data(), coeff_u.size() * 4);
+    hash_slice(k, (const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
+    rng.mix(digest);
+    // (the circuit's constraint identity on the tap openings would be checked here)
+    const Ext mix = rng.ext();
+    std::vector<Ext> combo_u(tot_backs + 1, bb::ext_zero());
+    {
+        Ext cur = bb::ext_one();
+        size_t pos = 0;
+        for (uint32_t i = 0; i < taps.n_regs; i++) {
+            uint32_t cb = taps.reg_combo[i];
+            size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
+            for (size_t j = 0; j < sz; j++)
+                combo_u[taps.combo_off[cb] + j] = bb::add(combo_u[taps.combo_off[cb] + j], bb::mul(cur, coeff_u[pos + j]));
+            cur = bb::mul(cur, mix);
+            pos += sz;
+        }
+        for (size_t i = 0; i < CHECK; i++) {
+            combo_u[tot_backs] = bb::add(combo_u[tot_backs], bb::mul(cur, coeff_u[pos++]));
+            cur = bb::mul(cur, mix);
+        }
+    }
+    const Ext z_pow = bb::pow(z, 4);
+
+    // FRI commitments
+    struct Round {
+        size_t domain;
+        TreeVerifier tree;
+        Ext mix;
+    };
+    std::vector<Round> rounds;
+    size_t degree = N, domain = D;
+    while (degree > MIN_DEGREE) {
+        rounds.emplace_back();
+        Round& rd = rounds.back();
+        rd.domain = domain;
+        rd.tree.init(k, r, rng, domain / FOLD, FOLD * 4, QUERIES);
+        rd.mix = rng.ext();
+        domain /= FOLD;
+        degree /= FOLD;
+    }
+    std::vector<uint32_t> final_coeffs(4 * degree);
+    r.read(final_coeffs.data(), final_coeffs.size());
+    hash_slice(k, final_coeffs.data(), final_coeffs.size(), digest);
+    rng.mix(digest);
+    if (r.short_read) return 60;
+
+    const uint32_t gen0 = bb::pow(w27, (uint64_t)1 << (27 - log2u(D)));
+    const uint32_t gen_final = bb::pow(w27, (uint64_t)1 << (27 - log2u(domain)));
+    const uint32_t w16_inv = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - 4)));
+    const uint32_t inv16 = bb::inv(bb::encode(16));
+    std::vector<uint32_t> row[3];
+    for (int g = 0; g < 3; g++) row[g].resize(taps.group_size[g] + 1);
+    uint32_t check_row[16];
+    std::vector<Ext> tot(taps.n_combos + 1);
+
+    for (size_t q = 0; q < QUERIES; q++) {
+        size_t pos = rng.bits(log2u(D)) % D;
+        const Ext x = bb::ext_from(bb::pow(gen0, pos));
+        for (int g = 0; g < 3; g++)
+            if (!tg[g].open(k, r, pos, row[g].data())) return r.short_read ? 60 : 20 + g;
+        if (!tcheck.open(k, r, pos, check_row)) return r.short_read ? 60 : 23;
+        for (auto& t : tot) t = bb::ext_zero();
+        Ext cur = bb::ext_one();
+        for (uint32_t i = 0; i < taps.n_regs; i++) {
+            uint32_t v = row[taps.reg_group[i]][taps.reg_offset[i]];
+            tot[taps.reg_combo[i]] = bb::add(tot[taps.reg_combo[i]], bb::scale(cur, v));
+            cur = bb::mul(cur, mix);
+        }
+        for (size_t i = 0; i < CHECK; i++) {
+            tot[taps.n_combos] = bb::add(tot[taps.n_combos], bb::scale(cur, check_row[i]));
+            cur = bb::mul(cur, mix);
+        }
+        Ext goal = bb::ext_zero();
+        for (uint32_t c = 0; c < taps.n_combos; c++) {
+            size_t b0 = taps.combo_off[c], b1 = taps.combo_off[c + 1];
+            Ext num = bb::sub(tot[c], poly_eval(&combo_u[b0], b1 - b0, x));
+            Ext den = bb::ext_one();
+            for (size_t b = b0; b < b1; b++)
+                den = bb::mul(den, bb::sub(x, bb::scale(z, bb::pow(back_one, taps.combo_backs[b]))));
+            goal = bb::add(goal, bb::mul(num, bb::inv(den)));
+        }
+        goal = bb::add(goal, bb::mul(bb::sub(tot[taps.n_combos], combo_u[tot_backs]), bb::inv(bb::sub(x, z_pow))));
+
+        for (size_t kr = 0; kr < rounds.size(); kr++) {
+            const Round& rd = rounds[kr];
+            size_t rows = rd.domain / FOLD;
+            size_t quot = pos / rows, group = pos % rows;
+            uint32_t data[64];
+            if (!rd.tree.open(k, r, group, data)) return r.short_read ? 60 : 30 + (int)kr;
+            Ext de[16];
+            for (int i = 0; i < 16; i++)
+                for (int c = 0; c < 4; c++) de[i].c[c] = data[c * 16 + i];
+            if (!bb::eq(de[quot], goal)) return 40 + (int)kr;
+            // interpolate the 16 coset values and evaluate at mix * w^-group
+            Ext co[16];
+            for (int i = 0; i < 16; i++) {
+                Ext acc = bb::ext_zero();
+                for (int j = 0; j < 16; j++) acc = bb::add(acc, bb::scale(de[j], bb::pow(w16_inv, (uint64_t)((i * j) & 15))));
+                co[i] = bb::scale(acc, inv16);
+            }
+            uint32_t inv_wk = bb::pow(bb::inv(bb::pow(w27, (uint64_t)1 << (27 - log2u(rd.domain)))), group);
+            goal = poly_eval(co, 16, bb::scale(rd.mix, inv_wk));
+            pos = group;
+        }
+        const Ext xf = bb::ext_from(bb::pow(gen_final, pos));
+        Ext fx = bb::ext_zero();
+        for (size_t i = degree; i-- > 0;) {
+            Ext c{{final_coeffs[i], final_coeffs[degree + i], final_coeffs[2 * degree + i], final_coeffs[3 * degree + i]}};
+            fx = bb::add(bb::mul(fx, xf), c);
+        }
+        if (!bb::eq(fx, goal)) return 50;
+    }
+    if (r.short_read) return 60;
+    if (r.pos != r.len) return 61;
+    return RK_OK;
+}
+
+}  // extern "C"

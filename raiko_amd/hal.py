@@ -205,6 +205,25 @@ class HipHal:
         return {n: getattr(t, n) for n, _ in t._fields_}
 
 
+def verify_segment(seg: Segment, seal: np.ndarray) -> int:
+    """Host-side check of a seal against the public data of `seg` (no GPU needed): 0 = valid,
+    positive = reason code of the first failed check (raiko_amd/csrc/verify.hip)."""
+    lib = _lib.load()
+    c = _lib.RkSegment()
+    keep = []
+    c.po2 = seg.po2
+    fill_c_taps(c.taps, seg.taps, keep)
+    gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)
+    c.globals = _u32p(gl)
+    c.n_globals = gl.size
+    c.n_accum_mix = seg.n_accum_mix
+    for i in range(16):
+        c.proof_system_info[i] = seg.proof_system_info[i]
+        c.circuit_info[i] = seg.circuit_info[i]
+    s = np.ascontiguousarray(seal, dtype=np.uint32)
+    return int(lib.rk_verify_segment(C.byref(c), _u32p(s), s.size))
+
+
 def fill_c_taps(c_taps, taps: TapSet, keep: list):
     arrs = {}
     for name in ("reg_group", "reg_offset", "reg_combo", "combo_off", "combo_backs"):

@@ -206,6 +206,12 @@ def prove_locally(segment_limit_po2: int, session: Session, device: int = 0) -> 
             local = [hal.prove_segment(session.segments[i]) for i in mine]
         except Exception as e:  # RkError etc.: surface as GuestError like `From<String>` (prover.rs:19-23)
             raise GuestError(str(e))
+    # `receipt.verify()` of the reference tests (lib.rs:136): every seal this rank produced must verify
+    from .hal import verify_segment
+    for i, seal in zip(mine, local):
+        rc = verify_segment(session.segments[i], seal)
+        if rc != 0:
+            raise GuestError("segment %d: seal failed verification (reason %d)" % (i, rc))
     seals = rdist.gather_seals(local, len(session.segments)) if world > 1 else local
     if seals is None:  # non-root rank of a sharded proof
         seals = []
