@@ -75,15 +75,24 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # RAIKO_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share
+    # GPUs (LOCAL_RANK modulo the device count) and the collectives run on CPU tensors.  The
+    # driver's runs use the default: one rank per GPU over RCCL ("nccl" on ROCm).
+    backend = os.environ.get("RAIKO_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(gpu_index)
+    device = torch.device("cuda", gpu_index)
+    coll_device = torch.device("cpu") if backend == "gloo" else device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     import threading
     n_ctx = max(1, min(args.inflight, args.steps))
     streams = [torch.cuda.Stream(device=device) for _ in range(n_ctx)]
-    hals = [HipHal(local_rank, stream=st.cuda_stream) for st in streams]
+    hals = [HipHal(gpu_index, stream=st.cuda_stream) for st in streams]
     hal = hals[0]
 
     # two distinct resident segments per rank, alternated, so no step sees data it just proved
@@ -160,12 +169,12 @@ def main():
         stage_ms[k] = stage_ms.get(k, 0.0) + v
     if world > 1:
         # rank r proved global segments r, r+world, ...: gather in that order (one collective)
-        gather_seals(seals, args.steps * world, device=device)
+        gather_seals(seals, args.steps * world, device=coll_device)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kstats = {}
