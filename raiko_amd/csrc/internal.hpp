@@ -122,6 +122,10 @@ int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t 
 int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, const bb::Ext& mix,
                     const uint32_t* d_in, const uint32_t* h_combos, size_t input_size, size_t count);
 int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& z, bb::Ext* h_rem);
+// n_items polynomials of `count` ext coefficients at d_base_ext + h_offsets[i] (in ext elements), each divided
+// by (x - h_z[i]) in one batch of launches; remainders to h_rems (may be null)
+int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size_t* h_offsets, const bb::Ext* h_z,
+                     size_t n_items, bb::Ext* h_rems);
 // d_ext[idx[i]] -= delta[i]
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n);
 

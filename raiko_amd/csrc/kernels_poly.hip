@@ -163,69 +163,106 @@ __global__ void mix_kernel(uint32_t* out, const uint32_t* in, size_t count, cons
     }
 }
 
-// ---- synthetic division by (x - z): q[i-1] = c[i] + z*q[i], chunked Horner ----
-constexpr int DIV_CH = 256;
-// tops[b] = sum_{k in chunk b} c[k] z^(k - start_b)
-__global__ void div_tops_kernel(uint32_t* tops, const uint32_t* poly, size_t count, Ext z) {
+// ---- synthetic division by (x - z): q[i-1] = c[i] + z*q[i], chunked Horner -----------------
+// Several polynomials (each with its own z) per launch: blockIdx.y = item.  Three launches per
+// batch: per-chunk Horner tops, one workgroup per item that turns the tops into the carry entering
+// every chunk (three-level scan: 16 + 32 + 32 + 32 + 16 dependent steps for 2^20 coefficients),
+// per-chunk apply.
+constexpr int DIV_CH = 64;
+constexpr int DIV_NT = 1024;   // lanes of the carry workgroup
+constexpr int DIV_GRP = 32;    // segments per leader lane
+struct DivItem {
+    Ext z, zL;               // divisor point, z^DIV_CH
+    unsigned long long off;  // first ext element of the polynomial
+};
+// tops[item][b] = sum_{k in chunk b} c[k] z^(k - start_b)
+__global__ void div_tops_kernel(uint32_t* tops, const uint32_t* base, size_t count, size_t nchunks, const DivItem* items) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nchunks) return;
+    const DivItem it = items[blockIdx.y];
+    const uint32_t* poly = base + it.off * 4;
     size_t start = b * DIV_CH;
-    if (start >= count) return;
     size_t end = start + DIV_CH < count ? start + DIV_CH : count;
     Ext s = bb::ext_zero();
-    for (size_t k = end; k-- > start;) s = bb::add(bb::mul(s, z), load_ext(poly + k * 4));
-    store_ext(tops + b * 4, s);
+    for (size_t k = end; k-- > start;) s = bb::add(bb::mul(s, it.z), load_ext(poly + k * 4));
+    store_ext(tops + ((size_t)blockIdx.y * nchunks + b) * 4, s);
 }
-// carry[b] = value of the running Horner state entering chunk b from above:
-// carry[b] = T[b+1], T[b] = tops[b] + zL * T[b+1], T[nchunks] = 0.  Single block, two-level.
-__global__ __launch_bounds__(TPB) void div_carry_kernel(uint32_t* carry, const uint32_t* tops, size_t nchunks, Ext zL,
-                                                        uint32_t* rem_out) {
-    __shared__ uint32_t seg_top[TPB * 4];
-    __shared__ uint32_t seg_in[TPB * 4];
-    const int NT = (int)blockDim.x;  // one wave: 64 segments, 64 sequential carry steps
-    size_t per = (nchunks + NT - 1) / NT;
-    size_t s0 = threadIdx.x * per, s1 = s0 + per < nchunks ? s0 + per : nchunks;
-    // local pass: value at the segment's first chunk assuming zero carry-in, and zL^(segment length)
+// carry[b] = T[b+1] with T[b] = tops[b] + zL * T[b+1], T[nchunks] = 0; rem = T[0] = f(z)
+__global__ __launch_bounds__(DIV_NT) void div_carry_kernel(uint32_t* carry, const uint32_t* tops, size_t nchunks,
+                                                           const DivItem* items, uint32_t* rem_out) {
+    __shared__ uint32_t seg[DIV_NT * 4];   // segment tops, later the carry entering each segment
+    __shared__ uint32_t sup[DIV_GRP * 4];  // same for groups of DIV_GRP segments
+    const unsigned t = threadIdx.x;
+    const DivItem it = items[blockIdx.y];
+    tops += (size_t)blockIdx.y * nchunks * 4;
+    carry += (size_t)blockIdx.y * nchunks * 4;
+    const size_t per = (nchunks + DIV_NT - 1) / DIV_NT;
+    const size_t s0 = (size_t)t * per, s1 = s0 + per < nchunks ? s0 + per : nchunks;
+    // A: value at the segment's first chunk with zero carry-in (missing chunks count as zero)
     Ext acc = bb::ext_zero();
     if (s0 < nchunks)
-        for (size_t b = s1; b-- > s0;) acc = bb::add(bb::mul(acc, zL), load_ext(tops + b * 4));
+        for (size_t b = s1; b-- > s0;) acc = bb::add(bb::mul(acc, it.zL), load_ext(tops + b * 4));
 #pragma unroll
-    for (int j = 0; j < 4; j++) seg_top[threadIdx.x * 4 + j] = acc.c[j];
+    for (int j = 0; j < 4; j++) seg[t * 4 + j] = acc.c[j];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        Ext zseg = bb::pow(zL, (uint64_t)per);
-        Ext run = bb::ext_zero();  // T at the start of segment t+1
-        for (int t = NT - 1; t >= 0; t--) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) seg_in[t * 4 + j] = run.c[j];
-            size_t a0 = (size_t)t * per;
-            if (a0 >= nchunks) continue;
-            size_t a1 = a0 + per < nchunks ? a0 + per : nchunks;
-            Ext zs = (a1 - a0 == per) ? zseg : bb::pow(zL, (uint64_t)(a1 - a0));
-            Ext top{{seg_top[t * 4], seg_top[t * 4 + 1], seg_top[t * 4 + 2], seg_top[t * 4 + 3]}};
-            run = bb::add(top, bb::mul(zs, run));
+    const Ext zseg = bb::pow(it.zL, (uint64_t)per);
+    // B: leaders fold their DIV_GRP segments
+    if (t < DIV_GRP) {
+        Ext g = bb::ext_zero();
+        for (int i = DIV_GRP - 1; i >= 0; i--) {
+            unsigned sidx = t * DIV_GRP + i;
+            Ext top{{seg[sidx * 4], seg[sidx * 4 + 1], seg[sidx * 4 + 2], seg[sidx * 4 + 3]}};
+            g = bb::add(top, bb::mul(zseg, g));
         }
-        // run == T[0] == sum_k c[k] z^k == remainder of the division
-        store_ext(rem_out, run);
+#pragma unroll
+        for (int j = 0; j < 4; j++) sup[t * 4 + j] = g.c[j];
     }
     __syncthreads();
+    // C: one lane walks the groups from the top; sup[] becomes the carry entering each group
+    if (t == 0) {
+        const Ext zsup = bb::pow(zseg, (uint64_t)DIV_GRP);
+        Ext run = bb::ext_zero();
+        for (int u = DIV_GRP - 1; u >= 0; u--) {
+            Ext top{{sup[u * 4], sup[u * 4 + 1], sup[u * 4 + 2], sup[u * 4 + 3]}};
+#pragma unroll
+            for (int j = 0; j < 4; j++) sup[u * 4 + j] = run.c[j];
+            run = bb::add(top, bb::mul(zsup, run));
+        }
+        store_ext(rem_out + (size_t)blockIdx.y * 4, run);
+    }
+    __syncthreads();
+    // B': leaders turn seg[] into the carry entering each segment
+    if (t < DIV_GRP) {
+        Ext run{{sup[t * 4], sup[t * 4 + 1], sup[t * 4 + 2], sup[t * 4 + 3]}};
+        for (int i = DIV_GRP - 1; i >= 0; i--) {
+            unsigned sidx = t * DIV_GRP + i;
+            Ext top{{seg[sidx * 4], seg[sidx * 4 + 1], seg[sidx * 4 + 2], seg[sidx * 4 + 3]}};
+#pragma unroll
+            for (int j = 0; j < 4; j++) seg[sidx * 4 + j] = run.c[j];
+            run = bb::add(top, bb::mul(zseg, run));
+        }
+    }
+    __syncthreads();
+    // A': carries of the segment's chunks
     if (s0 < nchunks) {
-        Ext run{{seg_in[threadIdx.x * 4], seg_in[threadIdx.x * 4 + 1], seg_in[threadIdx.x * 4 + 2],
-                 seg_in[threadIdx.x * 4 + 3]}};
+        Ext run{{seg[t * 4], seg[t * 4 + 1], seg[t * 4 + 2], seg[t * 4 + 3]}};
         for (size_t b = s1; b-- > s0;) {
             store_ext(carry + b * 4, run);
-            run = bb::add(load_ext(tops + b * 4), bb::mul(zL, run));
+            run = bb::add(load_ext(tops + b * 4), bb::mul(it.zL, run));
         }
     }
 }
 // within chunk b: cur = carry[b]; for k from top: next = z*cur + c[k]; c[k] = cur; cur = next
-__global__ void div_apply_kernel(uint32_t* poly, const uint32_t* carry, size_t count, Ext z) {
+__global__ void div_apply_kernel(uint32_t* base, const uint32_t* carry, size_t count, size_t nchunks, const DivItem* items) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nchunks) return;
+    const DivItem it = items[blockIdx.y];
+    uint32_t* poly = base + it.off * 4;
     size_t start = b * DIV_CH;
-    if (start >= count) return;
     size_t end = start + DIV_CH < count ? start + DIV_CH : count;
-    Ext cur = load_ext(carry + b * 4);
+    Ext cur = load_ext(carry + ((size_t)blockIdx.y * nchunks + b) * 4);
     for (size_t k = end; k-- > start;) {
-        Ext next = bb::add(bb::mul(z, cur), load_ext(poly + k * 4));
+        Ext next = bb::add(bb::mul(it.z, cur), load_ext(poly + k * 4));
         store_ext(poly + k * 4, cur);
         cur = next;
     }
@@ -372,37 +409,62 @@ int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, 
     return post_launch(ctx, "mix_kernel");
 }
 
-int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& z, bb::Ext* h_rem) {
-    if (count == 0) return RK_ERR_INVALID;
+int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size_t* h_offsets, const bb::Ext* h_z,
+                     size_t n_items, bb::Ext* h_rems) {
+    if (count == 0 || n_items == 0 || n_items > 65535) return RK_ERR_INVALID;
     size_t nchunks = (count + DIV_CH - 1) / DIV_CH;
+    if (nchunks > (size_t)DIV_NT * 4096) return RK_ERR_INVALID;
+    std::vector<DivItem> items(n_items);
+    for (size_t i = 0; i < n_items; i++) {
+        items[i].z = h_z[i];
+        items[i].zL = bb::pow(h_z[i], (uint64_t)DIV_CH);
+        items[i].off = h_offsets[i];
+    }
     void* buf = nullptr;
-    RK_TRY(dev_alloc(ctx, (2 * nchunks + 1) * 16, &buf));
-    uint32_t* tops = (uint32_t*)buf;
-    uint32_t* carry = tops + nchunks * 4;
-    uint32_t* rem = carry + nchunks * 4;
-    bb::Ext zL = bb::pow(z, (uint64_t)DIV_CH);
-    unsigned blocks = (unsigned)((nchunks + TPB - 1) / TPB);
-    KTimer kt(ctx, RK_KCLASS_POLY, (double)count * 48);
-    hipLaunchKernelGGL(div_tops_kernel, dim3(blocks), dim3(TPB), 0, ctx->stream, tops, d_poly_ext, count, z);
-    int st = post_launch(ctx, "div_tops_kernel");
-    if (st == RK_OK) {
-        hipLaunchKernelGGL(div_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, carry, tops, nchunks, zL, rem);
-        st = post_launch(ctx, "div_carry_kernel");
-    }
-    if (st == RK_OK) {
-        hipLaunchKernelGGL(div_apply_kernel, dim3(blocks), dim3(TPB), 0, ctx->stream, d_poly_ext, carry, count, z);
-        st = post_launch(ctx, "div_apply_kernel");
-    }
-    if (st == RK_OK && h_rem) {
-        hipError_t e = hipMemcpyAsync(h_rem, rem, 16, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    size_t items_bytes = (n_items * sizeof(DivItem) + 15) & ~(size_t)15;
+    RK_TRY(dev_alloc(ctx, items_bytes + n_items * (2 * nchunks + 1) * 16, &buf));
+    DivItem* d_items = (DivItem*)buf;
+    uint32_t* tops = (uint32_t*)((char*)buf + items_bytes);
+    uint32_t* carry = tops + n_items * nchunks * 4;
+    uint32_t* rem = carry + n_items * nchunks * 4;
+    int st = RK_OK;
+    do {
+        hipError_t e = hipMemcpyAsync(d_items, items.data(), n_items * sizeof(DivItem), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `items` is a local
         if (e != hipSuccess) {
-            ctx->last_error = std::string("poly_divide d2h: ") + hipGetErrorString(e);
+            ctx->last_error = std::string("poly_divide h2d: ") + hipGetErrorString(e);
             st = RK_ERR_HIP;
+            break;
         }
-    }
+        unsigned blocks = (unsigned)((nchunks + TPB - 1) / TPB);
+        KTimer kt(ctx, RK_KCLASS_POLY, (double)count * 48 * n_items);
+        hipLaunchKernelGGL(div_tops_kernel, dim3(blocks, (unsigned)n_items), dim3(TPB), 0, ctx->stream, tops, d_base_ext,
+                           count, nchunks, d_items);
+        st = post_launch(ctx, "div_tops_kernel");
+        if (st != RK_OK) break;
+        hipLaunchKernelGGL(div_carry_kernel, dim3(1, (unsigned)n_items), dim3(DIV_NT), 0, ctx->stream, carry, tops, nchunks,
+                           d_items, rem);
+        st = post_launch(ctx, "div_carry_kernel");
+        if (st != RK_OK) break;
+        hipLaunchKernelGGL(div_apply_kernel, dim3(blocks, (unsigned)n_items), dim3(TPB), 0, ctx->stream, d_base_ext, carry,
+                           count, nchunks, d_items);
+        st = post_launch(ctx, "div_apply_kernel");
+        if (st != RK_OK) break;
+        if (h_rems) {
+            e = hipMemcpyAsync(h_rems, rem, n_items * 16, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                ctx->last_error = std::string("poly_divide d2h: ") + hipGetErrorString(e);
+                st = RK_ERR_HIP;
+            }
+        }
+    } while (0);
     dev_free(ctx, buf);
     return st;
+}
+int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& z, bb::Ext* h_rem) {
+    size_t off = 0;
+    return poly_divide_many(ctx, d_poly_ext, count, &off, &z, 1, h_rem);
 }
 
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n) {

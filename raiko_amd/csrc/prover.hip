@@ -12,6 +12,7 @@
 // are inputs here: rk_segment carries their outputs.
 #include "internal.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 
@@ -466,15 +467,29 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
             }
         }
         RK_TRY(rk::ext_sub_at(ctx, combos.u32(), delta_idx.data(), dl.data(), dl.size()));
-        for (size_t c = 0; c < combo_count; c++)
-            for (uint32_t b = taps.combo_off[c]; b < taps.combo_off[c + 1]; b++) {
-                Ext rem;
-                RK_TRY(rk::poly_divide(ctx, combos.u32() + c * N * 4, N, pts[taps.combo_backs[b]], &rem));
-                if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+        // divide every combo by (x - z*w^-back) for each of its backs and the check combo by
+        // (x - z^4): round j handles the j-th back of every combo that has one, in one batch
+        size_t max_sz = 1;
+        for (size_t c = 0; c < combo_count; c++) max_sz = std::max<size_t>(max_sz, taps.combo_off[c + 1] - taps.combo_off[c]);
+        for (size_t j = 0; j < max_sz; j++) {
+            std::vector<size_t> offs;
+            std::vector<Ext> zs;
+            for (size_t c = 0; c < combo_count; c++) {
+                size_t sz = taps.combo_off[c + 1] - taps.combo_off[c];
+                if (j < sz) {
+                    offs.push_back(c * N);
+                    zs.push_back(pts[taps.combo_backs[taps.combo_off[c] + j]]);
+                }
             }
-        Ext rem;
-        RK_TRY(rk::poly_divide(ctx, combos.u32() + combo_count * N * 4, N, z_pow, &rem));
-        if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+            if (j == 0) {
+                offs.push_back(combo_count * N);
+                zs.push_back(z_pow);
+            }
+            std::vector<Ext> rems(offs.size());
+            RK_TRY(rk::poly_divide_many(ctx, combos.u32(), N, offs.data(), zs.data(), offs.size(), rems.data()));
+            for (const Ext& rem : rems)
+                if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+        }
     }
     DevBuf final_poly;
     RK_TRY(final_poly.alloc(ctx, N * 16));
