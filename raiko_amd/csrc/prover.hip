@@ -238,8 +238,12 @@ int check_taps(const rk_taps& t) {
             if (t.reg_combo[r] >= t.n_combos) return RK_ERR_INVALID;
         }
     if (t.combo_off[0] != 0) return RK_ERR_INVALID;
-    for (uint32_t c = 0; c < t.n_combos; c++)
+    for (uint32_t c = 0; c < t.n_combos; c++) {
         if (t.combo_off[c + 1] <= t.combo_off[c]) return RK_ERR_INVALID;
+        // backs of a combo are distinct (each is divided out once) and increasing, as TapSet builds them
+        for (uint32_t b = t.combo_off[c] + 1; b < t.combo_off[c + 1]; b++)
+            if (t.combo_backs[b] <= t.combo_backs[b - 1]) return RK_ERR_INVALID;
+    }
     return RK_OK;
 }
 

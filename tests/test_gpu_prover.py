@@ -108,3 +108,35 @@ def test_hip_prover_run_end_to_end(hal):
     assert rec is not None and len(rec.seals) == 3
     for s, seal in zip(segs, rec.seals):
         assert np.array_equal(seal, o.oracle_prove(s))
+
+
+def test_random_shapes_and_tapsets(hal):
+    """seeded random widths, tap sets and segment sizes: seal identical to the oracle's"""
+    rng = np.random.default_rng(2026)
+    for case in range(8):
+        po2 = int(rng.integers(4, 13))
+        widths = [int(rng.integers(1, 40)) for _ in range(3)]
+        menu = [(0,), (0, 1), (0, 1, 2), (0, 2), (1,), (0, 3), (0, 1, 2, 3), (0, 4)]
+        groups = [[menu[int(rng.integers(0, len(menu)))] for _ in range(w)] for w in widths]
+        taps = make_tapset(groups)
+        n = 1 << po2
+        seg = Segment(po2=po2, taps=taps, groups=[o.rand_elems(rng, (w, n)) for w in widths],
+                      check=o.rand_elems(rng, (4, 4 * n)), globals_=o.rand_elems(rng, (int(rng.integers(0, 9)),)),
+                      n_accum_mix=int(rng.integers(0, 50)))
+        want = o.oracle_prove(seg)
+        got = hal.prove_segment(seg)
+        assert np.array_equal(got, want), (case, po2, widths)
+
+
+def test_malformed_segments_are_rejected(hal):
+    from raiko_amd._lib import RkError
+    seg = synthetic_segment(8, (2, 2, 4), seed=5)
+    seg.taps.combo_backs = seg.taps.combo_backs.copy()
+    seg.taps.combo_backs[-1] = seg.taps.combo_backs[-2]  # duplicate back inside a combo
+    with pytest.raises(RkError):
+        hal.prove_segment(seg)
+    seg2 = synthetic_segment(8, (2, 2, 4), seed=5)
+    seg2.taps.reg_combo = seg2.taps.reg_combo.copy()
+    seg2.taps.reg_combo[0] = 99
+    with pytest.raises(RkError):
+        hal.prove_segment(seg2)
