@@ -31,7 +31,7 @@ def parse_args():
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,16,224", help="accum,code,data column counts")
     ap.add_argument("--cpu-po2", type=int, default=16, help="segment size of the bounded CPU-oracle sample")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="segments proven concurrently per GPU (one prover context + HIP stream each); "
                          "the latency-bound parts of one proof (Merkle tops, transcript round trips) "
                          "overlap the throughput-bound parts of the other")
