@@ -21,6 +21,8 @@
 //   * internal layer: 64-bit exact sum, one constant product + one conditional subtraction per
 //     cell, unsigned-lazy cells in [0, 2p).
 #pragma once
+#include <type_traits>
+
 #include "bb.hpp"
 
 namespace p2 {
@@ -30,6 +32,11 @@ constexpr int RATE = 16;
 constexpr int OUT = 8;
 constexpr int ROUNDS_HALF_FULL = 4;
 constexpr int ROUNDS_PARTIAL = 21;
+
+// per round r: 23 pairs d_i^r, r pairs c_(r-1-j), then d_0 + 1; at the end 23 x (d_i^21, d_i^(20-j))
+constexpr int PR_STREAM_USED = ROUNDS_PARTIAL * (2 * (CELLS - 1) + 1) + ROUNDS_PARTIAL * (ROUNDS_PARTIAL - 1) +
+                               (CELLS - 1) * 2 * (ROUNDS_PARTIAL + 1);
+constexpr int PR_STREAM_WORDS = (PR_STREAM_USED + 15) / 16 * 16 + 16;
 
 struct Consts {
     // the instance (Montgomery form), set by the caller
@@ -42,6 +49,10 @@ struct Consts {
     uint32_t diag_q[CELLS];                            // diag * (-p^-1) mod 2^32 (bb::umul_const companion)
     uint32_t r2_q;                                     // companion of bb::R2 for bb::umul_const
     uint32_t fix[2], fix_q[2];                         // block-end rescale constants and bb::smul_const companions
+    // partial rounds in closed form (see partial_rounds()): the constants in the order the
+    // code consumes them, each as a pair {c, c * 2^16 mod p} for the low / high 16-bit halves
+    // of the variable it multiplies (+ one chunk of padding for the read-ahead)
+    uint32_t pr_stream[PR_STREAM_WORDS];
 };
 
 // exponent e of the scale 2^(32 e) carried by the state at the S-box input of each full round
@@ -75,7 +86,38 @@ inline void derive(Consts& k) {
         k.fix[b] = bb::decode(rpow(9 - 7 * e));
         k.fix_q[b] = k.fix[b] * bb::MPRIME;
     }
+    // closed-form partial rounds: powers of the diagonal (Montgomery residues: they multiply a
+    // Montgomery-form variable and the sum goes through one REDC)
+    const uint32_t two16 = bb::encode(65536u);
+    uint32_t pw[CELLS - 1][ROUNDS_PARTIAL + 1];
+    for (int i = 1; i < CELLS; i++) {
+        pw[i - 1][0] = bb::ONE;
+        for (int m = 1; m <= ROUNDS_PARTIAL; m++) pw[i - 1][m] = bb::mul(pw[i - 1][m - 1], k.diag[i]);
+    }
+    uint32_t csum[ROUNDS_PARTIAL];
+    for (int m = 0; m < ROUNDS_PARTIAL; m++) {
+        csum[m] = 0;
+        for (int i = 0; i < CELLS - 1; i++) csum[m] = bb::add(csum[m], pw[i][m]);
+    }
+    int n = 0;
+    auto put = [&](uint32_t c) { k.pr_stream[n++] = c; k.pr_stream[n++] = bb::mul(c, two16); };
+    for (int r = 0; r < ROUNDS_PARTIAL; r++) {
+        for (int i = 0; i < CELLS - 1; i++) put(pw[i][r]);
+        for (int j = 0; j < r; j++) put(csum[r - 1 - j]);
+        k.pr_stream[n++] = bb::add(k.diag[0], bb::ONE);
+    }
+    for (int i = 0; i < CELLS - 1; i++) {
+        put(pw[i][ROUNDS_PARTIAL]);
+        for (int j = 0; j < ROUNDS_PARTIAL; j++) put(pw[i][ROUNDS_PARTIAL - 1 - j]);
+    }
+    while (n < PR_STREAM_WORDS) k.pr_stream[n++] = 0;
 }
+
+// acc + x * c for a wave-uniform constant c (scalar register operand): one v_mad_u64_u32.
+// Plain C on purpose: an inline-asm mad makes the hazard recogniser pad every product with
+// s_nop 1 (its vcc write followed by an opaque SGPR read).
+RK_HD uint64_t mad_sc(uint64_t acc, uint32_t x, uint32_t c) { return acc + (uint64_t)x * (uint64_t)c; }
+RK_HD uint64_t mul_sc(uint32_t x, uint32_t c) { return (uint64_t)x * (uint64_t)c; }
 
 // acc + x * K with a literal multiplier: one v_mad_u64_u32
 template <int K>
@@ -156,16 +198,142 @@ RK_HD void partial_round(uint32_t* s, const Consts& k, int r) {
     for (int i = 1; i < CELLS; i++) s[i] = bb::ucanon(bb::umul_const(s[i], k.diag[i], k.diag_q[i])) + S;
 }
 
+// All 21 partial rounds in closed form.  With v = cells 1..23 at entry, y_k the S-box output of
+// round k and S_k = y_k + sum(cells 1..23 before round k):
+//     cells_i before round k   = d_i^k v_i + sum_{j<k} d_i^(k-1-j) S_j
+//     sum of them              = sum_i d_i^k v_i + sum_{j<k} c_(k-1-j) S_j,     c_m = sum_i d_i^m
+//     cell 0 after round k     = (d_0 + 1) y_k + that sum
+//     cells_i after round 20   = d_i^21 v_i + sum_j d_i^(20-j) S_j
+// so no cell is touched between entry and exit: each round is one dot product with constant
+// vectors, and every product is accumulated exactly in 64 bits -- variables are split into
+// 16-bit halves, constants come as {c, c 2^16}, so a term is < 2^47 and one v_mad_u64_u32 --
+// with one REDC per sum.  ~3.0 k instructions instead of ~4.1 k for 21 rounds of
+// multiply / reduce / add on every cell.
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) -- the stream positions
+// below must be constants for the scalar-register indexing, and `#pragma unroll` gives up on
+// loops that contain volatile asm
+template <int B, int E, class F>
+RK_HD void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// Reader of Consts::pr_stream.  On the device the constants live in scalar registers: chunks of
+// 16 are fetched with s_load_dwordx16 one chunk ahead of their use (the compiler's own scheduling
+// of ~2400 scalar loads spills SGPRs), and the wait is attached to the chunk's registers so that
+// no use can move above it.  Positions are consumed strictly in order.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t sgpr16 __attribute__((ext_vector_type(16)));
+struct KStream {
+    const uint32_t* p;
+    sgpr16 cur, nxt;
+    __device__ __forceinline__ explicit KStream(const uint32_t* base) : p(base) {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cur) : "s"(p));
+        asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(nxt) : "s"(p));
+    }
+    // `acc` (the running sum the constant is about to be multiplied into) is threaded through the
+    // wait so that the scheduler keeps it between the products of two chunks: without that it
+    // bunches several wait + load pairs together and nothing overlaps the load latency
+    template <int POS>
+    __device__ __forceinline__ uint32_t get(uint64_t& acc) {
+        uint32_t c = cur[POS & 15];
+        if constexpr ((POS & 15) == 15) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt), "+v"(acc));
+            cur = nxt;
+            // the chunk after next (byte offset as an immediate: no pointer arithmetic to hoist)
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(nxt) : "s"(p), "n"((POS / 16 + 2) * 64));
+        }
+        return c;
+    }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt)); }
+};
+#else
+struct KStream {
+    const uint32_t* p;
+    explicit KStream(const uint32_t* base) : p(base) {}
+    template <int POS>
+    uint32_t get(uint64_t&) { return p[POS]; }
+    void drain() {}
+};
+#endif
+
+// acc += x * (constant at stream position POS)
+template <int POS>
+RK_HD void pr_fma(KStream& ks, uint64_t& acc, uint32_t x) {
+    uint32_t c = ks.template get<POS>(acc);
+    acc = mad_sc(acc, x, c);
+}
+
+RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
+    constexpr int NV = CELLS - 1;
+    uint32_t vlo[NV], vhi[NV], slo[ROUNDS_PARTIAL], shi[ROUNDS_PARTIAL];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        vlo[i] = s[i + 1] & 0xffffu;
+        vhi[i] = s[i + 1] >> 16;
+    }
+    KStream ks(k.pr_stream);
+    uint32_t x0 = s[0];  // [0, p + 2^22)
+    static_for<0, ROUNDS_PARTIAL>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int R = decltype(rc)::value;
+        constexpr int BASE = (2 * NV + 1) * R + R * (R - 1);
+        uint32_t y = bb::canon(sbox7_lazy(x0, k.rc_int_mp[R]));
+        uint64_t acc = 0;
+        pr_fma<BASE>(ks, acc, vlo[0]);
+        pr_fma<BASE + 1>(ks, acc, vhi[0]);
+        static_for<1, NV>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            pr_fma<BASE + 2 * I>(ks, acc, vlo[I]);
+            pr_fma<BASE + 2 * I + 1>(ks, acc, vhi[I]);
+        });
+        static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int J = decltype(jc)::value;
+            pr_fma<BASE + 2 * NV + 2 * J>(ks, acc, slo[J]);
+            pr_fma<BASE + 2 * NV + 2 * J + 1>(ks, acc, shi[J]);
+        });
+        // acc < 88 * 2^47: sigma < p + 2^22, S = y + sigma < 2p + 2^22 < 2^32 (any representative
+        // serves: only its halves are used)
+        uint32_t S = y + bb::uredc64(acc);
+        slo[R] = S & 0xffffu;
+        shi[R] = S >> 16;
+        // acc + (d_0 + 1) y < 2^54 + 2^62: REDC < 2p
+        pr_fma<BASE + 2 * NV + 2 * R>(ks, acc, y);
+        x0 = bb::ucanon(bb::uredc64(acc));
+    });
+    s[0] = x0;
+    constexpr int FIN = (2 * NV + 1) * ROUNDS_PARTIAL + ROUNDS_PARTIAL * (ROUNDS_PARTIAL - 1);
+    static_for<0, NV>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int BASE = FIN + I * 2 * (ROUNDS_PARTIAL + 1);
+        uint64_t acc = 0;
+        pr_fma<BASE>(ks, acc, vlo[I]);
+        pr_fma<BASE + 1>(ks, acc, vhi[I]);
+        static_for<0, ROUNDS_PARTIAL>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int J = decltype(jc)::value;
+            pr_fma<BASE + 2 + 2 * J>(ks, acc, slo[J]);
+            pr_fma<BASE + 2 + 2 * J + 1>(ks, acc, shi[J]);
+        });
+        s[I + 1] = bb::uredc64(acc);  // < p + 2^22
+    });
+    ks.drain();
+}
+
 RK_HD void permute(uint32_t* s, const Consts& k) {
     m_ext_redc(s);  // canonical Montgomery input -> plain residues (scale 2^0)
 #pragma unroll 1
     for (int r = 0; r < ROUNDS_HALF_FULL - 1; r++) full_round<false>(s, k, r, 0);
     full_round<true>(s, k, ROUNDS_HALF_FULL - 1, 0);  // back to Montgomery form, cells in [0, p + 53)
+#if defined(P2_PARTIAL_PER_ROUND)
 #pragma unroll 1
     for (int r = 0; r < ROUNDS_PARTIAL; r++) partial_round(s, k, r);
     // cells 1..23 are representatives in [0, 2p): back to [0, p) before the S-box input offset
 #pragma unroll
     for (int i = 1; i < CELLS; i++) s[i] = bb::ucanon(s[i]);
+#else
+    partial_rounds(s, k);  // cells in [0, p + 2^22): fine for the S-box input offset (|x + rc - p| < 2^31)
+#endif
 #pragma unroll 1
     for (int r = ROUNDS_HALF_FULL; r < 2 * ROUNDS_HALF_FULL - 1; r++) full_round<false>(s, k, r, 1);
     full_round<true>(s, k, 2 * ROUNDS_HALF_FULL - 1, 1);
