@@ -18,6 +18,17 @@
 #define RK_D inline
 #endif
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E).  For code whose indices
+// must be constants after inlining (register arrays, scalar-register chunks): `#pragma unroll`
+// gives up on loops that contain volatile asm or whose bounds depend on an outer unrolled loop.
+template <int B, int E, class F>
+RK_HD void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 namespace bb {
 
 constexpr uint32_t P = 2013265921u;

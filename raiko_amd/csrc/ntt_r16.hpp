@@ -72,7 +72,18 @@ struct RoundIdx {
     unsigned e0;     // logical tile index of m = 0
     unsigned estep;  // logical index step per m
     unsigned rlow;   // hi & (2^ls - 1)
+    unsigned p0b;    // byte offset of phys(e0)
+    unsigned pstepb; // byte step of phys() per m when `linear`
+    bool linear;     // phys(e0 + m * estep) == phys(e0) + m * (estep + skew(estep)) for m < 16
 };
+// keep a wave-uniform value in a vector register: on gfx950 a v_add_u32 with only VGPR / literal
+// operands issues twice as fast as one with a scalar operand (profiles/r01_ubench_isa.txt)
+RK_HD unsigned in_vgpr(unsigned x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
 RK_HD RoundIdx round_idx(unsigned tid, unsigned g, unsigned ls) {
     unsigned logT = TILE_LOG - g;
     unsigned lo = tid & ((1u << logT) - 1), r = tid >> logT;
@@ -82,25 +93,62 @@ RK_HD RoundIdx round_idx(unsigned tid, unsigned g, unsigned ls) {
     x.e0 = (hi0 << logT) + lo;
     x.estep = 1u << (ls + logT);
     x.rlow = rlow;
+    // the 4-bit field m sits at bit ls + logT of the tile index: the skew (4 words per 64) is linear
+    // in m when the field lies entirely above or entirely below bit 6 -- every round of the
+    // schedules below; the per-element form stays for the remaining case
+    x.linear = ls + logT >= 6 || ls + logT + 4 <= 6;
+    x.p0b = phys(x.e0) << 2;
+    x.pstepb = in_vgpr((x.estep + ((x.estep >> 6) << 2)) << 2);
     return x;
 }
+RK_HD uint32_t& lds_at(uint32_t* lds, unsigned byte_off) {
+    return *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + byte_off);
+}
 RK_HD void round_read(uint32_t* v, const uint32_t* lds, const RoundIdx& x) {
+    if (x.linear) {
+        unsigned o = x.p0b;
 #pragma unroll
-    for (int m = 0; m < 16; m++) v[m] = lds[phys(x.e0 + m * x.estep)];
+        for (int m = 0; m < 16; m++) {
+            v[m] = lds_at(const_cast<uint32_t*>(lds), o);
+            o += x.pstepb;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = lds[phys(x.e0 + m * x.estep)];
+    }
 }
 RK_HD void round_write(const uint32_t* v, uint32_t* lds, const RoundIdx& x) {
+    if (x.linear) {
+        unsigned o = x.p0b;
 #pragma unroll
-    for (int m = 0; m < 16; m++) lds[phys(x.e0 + m * x.estep)] = v[m];
+        for (int m = 0; m < 16; m++) {
+            lds_at(lds, o) = v[m];
+            o += x.pstepb;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) lds[phys(x.e0 + m * x.estep)] = v[m];
+    }
+}
+// the 2^b twiddles of one stage: tw[H + (j << ls) + rlow], j < 2^b, addressed with 32-bit byte
+// offsets from the (scalar) table base and a VGPR step
+template <int B>
+RK_HD void stage_twiddles(uint32_t* w, const uint32_t* tw, unsigned ls, unsigned rlow) {
+    unsigned o = ((1u << (ls + B)) + rlow) << 2;
+    const unsigned step = in_vgpr(4u << ls);
+#pragma unroll
+    for (int j = 0; j < (1 << B); j++) {
+        w[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tw) + o);
+        o += step;
+    }
 }
 // inverse (DIF): (x, y) -> (x + y, (x - y) * w^-j), largest half first
 template <int NST>
 RK_HD void round_dif(uint32_t* v, const uint32_t* tw /* heap-ordered inverse roots */, unsigned ls, unsigned rlow) {
-#pragma unroll
-    for (int b = NST - 1; b >= 0; b--) {
-        const unsigned H = 1u << (ls + b);
-        uint32_t w[8];
-#pragma unroll
-        for (int j = 0; j < (1 << b); j++) w[j] = tw[H + ((unsigned)j << ls) + rlow];
+    static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int b = NST - 1 - decltype(bc)::value;
+        uint32_t w[1 << b];
+        stage_twiddles<b>(w, tw, ls, rlow);
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             if (m & (1 << b)) continue;
@@ -109,17 +157,15 @@ RK_HD void round_dif(uint32_t* v, const uint32_t* tw /* heap-ordered inverse roo
             // x - y in (-p, p) needs no reduction before the signed product
             v[m | (1 << b)] = bb::canon(bb::smul((int32_t)(x - y), (int32_t)w[m & ((1 << b) - 1)]));
         }
-    }
+    });
 }
 // forward (DIT): (x, y) -> (x + y * w^j, x - y * w^j), smallest half first
 template <int NST>
 RK_HD void round_dit(uint32_t* v, const uint32_t* tw /* heap-ordered forward roots */, unsigned ls, unsigned rlow) {
-#pragma unroll
-    for (int b = 0; b < NST; b++) {
-        const unsigned H = 1u << (ls + b);
-        uint32_t w[8];
-#pragma unroll
-        for (int j = 0; j < (1 << b); j++) w[j] = tw[H + ((unsigned)j << ls) + rlow];
+    static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        uint32_t w[1 << b];
+        stage_twiddles<b>(w, tw, ls, rlow);
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             if (m & (1 << b)) continue;
@@ -128,7 +174,7 @@ RK_HD void round_dit(uint32_t* v, const uint32_t* tw /* heap-ordered forward roo
             v[m] = bb::add(x, y);
             v[m | (1 << b)] = bb::sub(x, y);
         }
-    }
+    });
 }
 
 // ---- 16 factors A * C[c] * D[i] for the lane's elements e = 4*(tid + 1024*i) + c -----------

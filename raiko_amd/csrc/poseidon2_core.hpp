@@ -21,8 +21,6 @@
 //   * internal layer: 64-bit exact sum, one constant product + one conditional subtraction per
 //     cell, unsigned-lazy cells in [0, 2p).
 #pragma once
-#include <type_traits>
-
 #include "bb.hpp"
 
 namespace p2 {
@@ -209,17 +207,6 @@ RK_HD void partial_round(uint32_t* s, const Consts& k, int r) {
 // 16-bit halves, constants come as {c, c 2^16}, so a term is < 2^47 and one v_mad_u64_u32 --
 // with one REDC per sum.  ~3.0 k instructions instead of ~4.1 k for 21 rounds of
 // multiply / reduce / add on every cell.
-// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) -- the stream positions
-// below must be constants for the scalar-register indexing, and `#pragma unroll` gives up on
-// loops that contain volatile asm
-template <int B, int E, class F>
-RK_HD void static_for(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-
 // Reader of Consts::pr_stream.  On the device the constants live in scalar registers: chunks of
 // 16 are fetched with s_load_dwordx16 one chunk ahead of their use (the compiler's own scheduling
 // of ~2400 scalar loads spills SGPRs), and the wait is attached to the chunk's registers so that
