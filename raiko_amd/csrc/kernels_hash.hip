@@ -19,20 +19,9 @@ __global__ __launch_bounds__(HASH_BLOCK) void hash_rows_kernel(uint32_t* __restr
     for (int i = 0; i < p2::CELLS; i++) s[i] = 0;
     size_t full = cols / p2::RATE;
     const uint32_t* src = matrix + row;
-    // the next block's 16 column words are requested before the current permutation starts
-    // (~8 k instructions): at four waves per SIMD nothing else would cover the load latency
-    uint32_t nxt[p2::RATE];
-    if (full) {
-#pragma unroll
-        for (int i = 0; i < p2::RATE; i++) nxt[i] = src[(size_t)i * rows];
-    }
     for (size_t b = 0; b < full; b++) {
 #pragma unroll
-        for (int i = 0; i < p2::RATE; i++) s[i] = nxt[i];
-        if (b + 1 < full) {
-#pragma unroll
-            for (int i = 0; i < p2::RATE; i++) nxt[i] = src[((b + 1) * p2::RATE + i) * rows];
-        }
+        for (int i = 0; i < p2::RATE; i++) s[i] = src[(b * p2::RATE + i) * rows];
         p2::permute(s, k);
     }
     size_t rem = cols - full * p2::RATE;

@@ -62,8 +62,10 @@ __device__ __forceinline__ void r16_round(uint32_t* v, const ntt::Tables& tb, un
     if (FWD) r16::round_dit<NST>(v, tb.small[0], ls, rlow);
     else r16::round_dif<NST>(v, tb.small[1], ls, rlow);
 }
+// 8 waves per SIMD (<= 64 VGPRs): two 1024-lane workgroups per CU, so one group's barriers and LDS
+// round trips are covered by the other's arithmetic
 template <bool FWD, bool CONTIG>
-__global__ __launch_bounds__(1024) void ntt_r16_kernel(r16::Args a, ntt::Tables tb, r16::Sched sc) {
+__global__ __launch_bounds__(1024, 8) void ntt_r16_kernel(r16::Args a, ntt::Tables tb, r16::Sched sc) {
     __shared__ uint32_t lds[r16::LDS_WORDS];
     const unsigned tid = threadIdx.x;
     const r16::Tile t = r16::tile_of(a, blockIdx.x);
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(1024) void ntt_r16_kernel(r16::Args a, ntt::Tables 
         if (FWD) r16::store_fwd_contig(a, tb, t, lds, tid);
         else r16::store_rev_contig(a, tb, t, lds, tid);
     } else {
-        r16::store_plain(a, t, lds, tid);
+        r16::store_plain<FWD>(a, t, lds, tid);
     }
 }
 

@@ -159,7 +159,11 @@ RK_HD void round_dif(uint32_t* v, const uint32_t* tw /* heap-ordered inverse roo
         }
     });
 }
-// forward (DIT): (x, y) -> (x + y * w^j, x - y * w^j), smallest half first
+// forward (DIT): (x, y) -> (x + y * w^j, x - y * w^j), smallest half first.
+// Values stay "lazy" in [0, 2p) between stages, between rounds (LDS) and until the store phase:
+//   t = y * w via an unsigned REDC (any u32 y, result < 2p), t and x brought to [0, p) with one
+//   conditional subtraction each, then x + t and x - t + p need no reduction (both < 2p < 2^32).
+// One v_min less per butterfly than reducing the product and both outputs.
 template <int NST>
 RK_HD void round_dit(uint32_t* v, const uint32_t* tw /* heap-ordered forward roots */, unsigned ls, unsigned rlow) {
     static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
@@ -169,10 +173,10 @@ RK_HD void round_dit(uint32_t* v, const uint32_t* tw /* heap-ordered forward roo
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             if (m & (1 << b)) continue;
-            uint32_t x = v[m];
-            uint32_t y = bb::canon(bb::smul((int32_t)v[m | (1 << b)], (int32_t)w[m & ((1 << b) - 1)]));
-            v[m] = bb::add(x, y);
-            v[m | (1 << b)] = bb::sub(x, y);
+            uint32_t x = bb::ucanon(v[m]);
+            uint32_t t = bb::ucanon(bb::uredc64((uint64_t)v[m | (1 << b)] * w[m & ((1 << b) - 1)]));
+            v[m] = x + t;
+            v[m | (1 << b)] = x - t + bb::P;
         }
     });
 }
@@ -205,24 +209,39 @@ RK_HD void twiddle_parts(const Args& a, const ntt::Tables& tb, int dir, unsigned
 
 // ---- global <-> LDS phases (16-byte accesses; 4 consecutive tile elements are consecutive in
 // memory because T >= 64 or the pass is contiguous) -----------------------------------------
-RK_HD void load_plain(const Args& a, const Tile& t, uint32_t* lds, unsigned tid) {
+// strided tile rows: element e = 4 * (tid + 1024 i) lies in row (e >> logT) at column (e & tmask); the
+// four rows of a lane are 4096 >> logT rows apart, i.e. n / 4 elements: 32-bit byte offsets from the
+// (scalar) tile base, one add per access
+RK_HD unsigned plain_off(const Args& a, const Tile& t, unsigned tid) {
     unsigned logT = TILE_LOG - a.g, tmask = (1u << logT) - 1;
+    unsigned e = 4 * tid;
+    return ((e >> logT) * (unsigned)t.S + (e & tmask)) << 2;
+}
+RK_HD void load_plain(const Args& a, const Tile& t, uint32_t* lds, unsigned tid) {
+    const char* base = reinterpret_cast<const char*>(a.src + t.src_base);
+    unsigned off = plain_off(a, t, tid);
+    const unsigned step = in_vgpr((unsigned)(a.n >> 2) << 2);  // (4096 >> logT) * S elements = n / 4
     ntt::U4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        unsigned e = 4 * (tid + i * NTHR);
-        v[i] = *reinterpret_cast<const ntt::U4*>(a.src + t.src_base + (size_t)(e >> logT) * t.S + (e & tmask));
+        v[i] = *reinterpret_cast<const ntt::U4*>(base + off);
+        off += step;
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) *reinterpret_cast<ntt::U4*>(lds + phys(4 * (tid + i * NTHR))) = v[i];
 }
+// LAZY: the tile holds forward-transform values in [0, 2p) (round_dit): reduce on the way out
+template <bool LAZY>
 RK_HD void store_plain(const Args& a, const Tile& t, const uint32_t* lds, unsigned tid) {
-    unsigned logT = TILE_LOG - a.g, tmask = (1u << logT) - 1;
+    char* base = reinterpret_cast<char*>(a.dst + t.base);
+    unsigned off = plain_off(a, t, tid);
+    const unsigned step = in_vgpr((unsigned)(a.n >> 2) << 2);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        unsigned e = 4 * (tid + i * NTHR);
-        *reinterpret_cast<ntt::U4*>(a.dst + t.base + (size_t)(e >> logT) * t.S + (e & tmask)) =
-            *reinterpret_cast<const ntt::U4*>(lds + phys(e));
+        ntt::U4 v = *reinterpret_cast<const ntt::U4*>(lds + phys(4 * (tid + i * NTHR)));
+        if (LAZY) v = ntt::U4{bb::ucanon(v.x), bb::ucanon(v.y), bb::ucanon(v.z), bb::ucanon(v.w)};
+        *reinterpret_cast<ntt::U4*>(base + off) = v;
+        off += step;
     }
 }
 // inverse contiguous pass: load with the four-step twiddle w_n^-(e * bitrev(sp))
@@ -294,10 +313,14 @@ RK_HD void store_fwd_contig(const Args& a, const ntt::Tables& tb, const Tile& t,
         ntt::U4 v = *reinterpret_cast<const ntt::U4*>(lds + phys(4 * (tid + i * NTHR)));
         r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
     }
+    // r[] is lazy (< 2p, round_dit): bb::mul accepts that and returns canonical values
     if (a.g_outer && t.sp != 0) {
         uint32_t A, C[3], D[3];
         twiddle_parts(a, tb, 0, t.sp, tid, A, C, D);
         apply_factors(r, A, C, D);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) r[j] = bb::ucanon(r[j]);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)

@@ -115,7 +115,7 @@ void run_r16(const r16::Args& a, size_t count) {
                 if (FWD) r16::store_fwd_contig(a, g_tb, t, lds.data(), tid);
                 else r16::store_rev_contig(a, g_tb, t, lds.data(), tid);
             } else {
-                r16::store_plain(a, t, lds.data(), tid);
+                r16::store_plain<FWD>(a, t, lds.data(), tid);
             }
         }
     }
