@@ -70,7 +70,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raiko_amd import segment as seg_mod
-    from raiko_amd.hal import HipHal
+    from raiko_amd.pipeline import SegmentPipeline
     from raiko_amd.dist import gather_seals
 
     if not torch.cuda.is_available():
@@ -89,10 +89,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-    import threading
+    # the product's own multi-context pipeline (raiko_amd/pipeline.py), the same object
+    # HipProver.run proves a session's segments with
     n_ctx = max(1, min(args.inflight, args.steps))
     streams = [torch.cuda.Stream(device=device) for _ in range(n_ctx)]
-    hals = [HipHal(gpu_index, stream=st.cuda_stream) for st in streams]
+    pipe = SegmentPipeline(gpu_index, n_ctx, streams=[st.cuda_stream for st in streams])
+    hals = pipe.hals
     hal = hals[0]
 
     # two distinct resident segments per rank, alternated, so no step sees data it just proved
@@ -114,35 +116,28 @@ def main():
             host_segs.append(seg_mod.Segment(po2=seg.po2, taps=seg.taps, groups=[to_host(g) for g in groups],
                                              check=to_host(check), globals_=seg.globals_))
 
-    def prove(i, h=None):
+    def job(i):
+        """(segment, device inputs) of step i"""
         if host_segs is not None:
-            return (h or hal).prove_segment(host_segs[i % 2])
+            return host_segs[i % 2], None
         seg, groups, check = segs[i % 2]
-        return (h or hal).prove_segment(seg, device_inputs=(groups, check))
+        return seg, (groups, check)
+
+    def prove(i):
+        seg, dev = job(i)
+        return hal.prove_segment(seg, device_inputs=dev)
 
     def prove_many(indices):
-        """prove the given step indices, n_ctx at a time (one host thread per context)"""
-        out = {}
+        """prove the given step indices through the pipeline, n_ctx at a time"""
         stage = {}
-        err = []
+        jobs = [job(i) for i in indices]
 
-        def worker(w):
-            try:
-                for i in indices[w::n_ctx]:
-                    out[i] = prove(i, hals[w])
-                    for k, v in hals[w].last_timing().items():
-                        stage[(w, i, k)] = v
-            except Exception as e:  # surface in the main thread
-                err.append(e)
+        def on_done(j, h):
+            for k, v in h.last_timing().items():
+                stage[(j, k)] = v
 
-        ts = [threading.Thread(target=worker, args=(w,)) for w in range(n_ctx)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        if err:
-            raise err[0]
-        return [out[i] for i in indices], stage
+        dev = None if host_segs is not None else [d for _, d in jobs]
+        return pipe.prove([sg for sg, _ in jobs], device_inputs=dev, on_done=on_done), stage
 
     def barrier():
         if world > 1:
@@ -165,7 +160,7 @@ def main():
     t0 = time.perf_counter()
     seals, stage = prove_many(list(range(args.steps)))
     stage_ms = {}
-    for (w, i, k), v in stage.items():
+    for (i, k), v in stage.items():
         stage_ms[k] = stage_ms.get(k, 0.0) + v
     if world > 1:
         # rank r proved global segments r, r+world, ...: gather in that order (one collective)

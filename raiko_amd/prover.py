@@ -147,7 +147,7 @@ class Receipt:
 
 _CACHE_DIR = None
 _DEVICE_LOCK = threading.Lock()  # `run` may be entered from up to concurrency_limit threads (host/src/lib.rs:38-41)
-_HAL = {}
+_PIPELINES = {}  # (device, inflight) -> SegmentPipeline; process-global like every `Prover` backend's state
 
 
 def _cache_dir() -> str:
@@ -178,16 +178,18 @@ def load_receipt(label: str) -> Optional[Receipt]:
         return None
 
 
-def _hal(device: int):
-    from .hal import HipHal  # raises HipLibraryError when the library / GPU is missing: no fallback
-    if device not in _HAL:
-        _HAL[device] = HipHal(device)
-    return _HAL[device]
+def _pipeline(device: int, inflight: int):
+    from .pipeline import SegmentPipeline  # raises HipLibraryError when the library / GPU is missing: no fallback
+    key = (device, inflight)
+    if key not in _PIPELINES:
+        _PIPELINES[key] = SegmentPipeline(device, inflight)
+    return _PIPELINES[key]
 
 
-def prove_locally(segment_limit_po2: int, session: Session, device: int = 0) -> Receipt:
+def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inflight: int = 3) -> Receipt:
     """bonsai.rs:230-272 from the point the executor has produced the session: prove every
-    segment (this rank's shard when torch.distributed is initialised) and assemble the receipt."""
+    segment (this rank's shard when torch.distributed is initialised), `inflight` at a time on
+    the GPU (raiko_amd/pipeline.py), and assemble the receipt."""
     from . import dist as rdist
     for s in session.segments:
         if s.po2 > segment_limit_po2:
@@ -201,9 +203,8 @@ def prove_locally(segment_limit_po2: int, session: Session, device: int = 0) -> 
         pass
     mine = rdist.shard_indices(len(session.segments), rank, world)
     with _DEVICE_LOCK:
-        hal = _hal(device)
         try:
-            local = [hal.prove_segment(session.segments[i]) for i in mine]
+            local = _pipeline(device, inflight).prove([session.segments[i] for i in mine])
         except Exception as e:  # RkError etc.: surface as GuestError like `From<String>` (prover.rs:19-23)
             raise GuestError(str(e))
     # `receipt.verify()` of the reference tests (lib.rs:136): every seal this rank produced must verify
@@ -239,7 +240,14 @@ class HipProver:
         label = session.image_id.hex() + "-" + hashlib.sha3_256(expected).hexdigest()
         receipt = load_receipt(label)
         if receipt is None:
-            receipt = prove_locally(param.execution_po2, session, device=int(config.get("hip", {}).get("device", 0)))
+            hip = config.get("hip", {}) if isinstance(config.get("hip", {}), dict) else {}
+            try:
+                device, inflight = int(hip.get("device", 0)), int(hip.get("inflight", 3))
+            except (TypeError, ValueError):
+                raise Param("`hip.device` / `hip.inflight` must be integers")
+            if inflight < 1 or inflight > 16:
+                raise Param("`hip.inflight` must be in 1..16")
+            receipt = prove_locally(param.execution_po2, session, device=device, inflight=inflight)
             if receipt.seals:
                 save_receipt(label, receipt)
         # bonsai.rs:157-162: a journal mismatch is logged, not fatal

@@ -65,3 +65,49 @@ def test_receipt_roundtrip_and_cache(tmp_path, monkeypatch):
     proof = pv.HipProver.run(types.SimpleNamespace(session=sess), out, req())
     assert proof.to_json() == {"proof": ("ab" * 32), "quote": None, "kzg_proof": None}
     assert pv.HipProver.last_journal_matches is True
+
+
+class _FakeHal:
+    """stands in for HipHal in the scheduling logic of SegmentPipeline (no GPU in the CPU suite)"""
+
+    def __init__(self, delay=0.0, fail_on=None):
+        self.delay, self.fail_on, self.seen = delay, fail_on, []
+
+    def prove_segment(self, seg, device_inputs=None):
+        import time
+        time.sleep(self.delay)
+        if seg == self.fail_on:
+            raise RuntimeError("boom %s" % seg)
+        self.seen.append(seg)
+        return np.array([seg, 0 if device_inputs is None else device_inputs], dtype=np.uint32)
+
+    def close(self):
+        pass
+
+
+def _fake_pipeline(hals):
+    from raiko_amd.pipeline import SegmentPipeline
+    p = SegmentPipeline.__new__(SegmentPipeline)
+    p.device, p.hals = 0, hals
+    return p
+
+
+def test_pipeline_keeps_segment_order_and_balances():
+    slow, fast = _FakeHal(0.02), _FakeHal(0.0)
+    pipe = _fake_pipeline([slow, fast])
+    done = []
+    seals = pipe.prove(list(range(12)), device_inputs=[10 + i for i in range(12)], on_done=lambda i, h: done.append(i))
+    assert [int(s[0]) for s in seals] == list(range(12))
+    assert [int(s[1]) for s in seals] == [10 + i for i in range(12)]
+    assert sorted(done) == list(range(12))
+    # shared queue, not a static split: the fast context takes most of the work
+    assert len(fast.seen) > len(slow.seen)
+
+
+def test_pipeline_single_segment_and_errors():
+    pipe = _fake_pipeline([_FakeHal(), _FakeHal()])
+    assert [int(s[0]) for s in pipe.prove([7])] == [7]
+    assert pipe.prove([]) == []
+    bad = _fake_pipeline([_FakeHal(fail_on=3), _FakeHal(fail_on=3)])
+    with pytest.raises(RuntimeError, match="boom 3"):
+        bad.prove(list(range(8)))
