@@ -194,9 +194,19 @@ def main():
             "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
             "serial_avg_launch_ms": round(calib[dom_name]["ms"] / max(calib[dom_name]["launches"], 1), 4),
             "note": "Poseidon2 hashing is integer-ALU-bound (about 1.36k modular multiplies per 64 B absorbed, "
-                    "~8.8k VALU instructions per permutation at 16 lanes/clk/SIMD); the HBM fraction is "
+                    "~7.7k VALU instructions per permutation at 16 lanes/clk/SIMD: see `alu`); the HBM fraction is "
                     "reported because it is the contract figure",
         }
+        if dom_name == "hash_rows_kernel" and dom["ms"] > 0:
+            # the bound that actually applies: VALU issue.  peak = 256 CUs x 4 SIMDs x 16 lanes/clk x
+            # 2.4 GHz (profiles/r01_ubench_isa.txt: every VALU op except plain add/sub issues at that rate)
+            perms = seg_mod.poseidon2_permutations(args.po2, widths)["hash_rows"] * args.steps
+            alu_peak = 256 * 4 * 16 * 2.4e9 / 1e12
+            alu = perms * seg_mod.P2_VALU_PER_PERMUTATION / (dom["ms"] * 1e-3) / 1e12
+            roofline["alu"] = {"achieved": round(alu, 2), "peak": round(alu_peak, 2), "unit": "T lane-instr/s",
+                               "frac": round(alu / alu_peak, 4),
+                               "permutations_per_s": round(perms / (dom["ms"] * 1e-3) / 1e9, 3),
+                               "valu_per_permutation": seg_mod.P2_VALU_PER_PERMUTATION}
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:

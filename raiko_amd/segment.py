@@ -152,3 +152,24 @@ def algorithmic_bytes(po2: int, widths: Sequence[int]) -> dict:
     out["fri"] = fri
     out["total"] = sum(out.values())
     return out
+
+
+# VALU instructions of one Poseidon2 permutation as shipped (tools/census_p2.py on the gfx950 ISA of
+# poseidon2_core.hpp: 7682 dynamic v_* instructions, 600 of them plain add/sub)
+P2_VALU_PER_PERMUTATION = 7682
+
+
+def poseidon2_permutations(po2: int, widths: Sequence[int]) -> dict:
+    """Permutations of one segment proof: row hashing (one per 16 columns per LDE row: three trace
+    groups, the 16-column check group, 64-column FRI rows) and Merkle folds (one per parent)."""
+    n = 1 << po2
+    d = INV_RATE * n
+    rows = d * (sum((w + 15) // 16 for w in widths) + 1)
+    fold = 4 * (d - 1)
+    size = n
+    while size > FRI_MIN_DEGREE:
+        leaves = size * INV_RATE // FRI_FOLD
+        rows += leaves * (FRI_FOLD * 4 // 16)
+        fold += leaves - 1
+        size //= FRI_FOLD
+    return {"hash_rows": rows, "hash_fold": fold}

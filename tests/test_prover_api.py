@@ -111,3 +111,14 @@ def test_pipeline_single_segment_and_errors():
     bad = _fake_pipeline([_FakeHal(fail_on=3), _FakeHal(fail_on=3)])
     with pytest.raises(RuntimeError, match="boom 3"):
         bad.prove(list(range(8)))
+
+
+def test_permutation_count_of_s20():
+    from raiko_amd.segment import poseidon2_permutations
+    c = poseidon2_permutations(20, (16, 16, 224))
+    d = 1 << 22
+    fri_leaves = [(1 << 20) * 4 // 16, (1 << 16) * 4 // 16, (1 << 12) * 4 // 16]
+    assert c["hash_rows"] == d * 17 + 4 * sum(fri_leaves)
+    assert c["hash_fold"] == 4 * (d - 1) + sum(x - 1 for x in fri_leaves)
+    # ragged widths round up to whole sponge blocks
+    assert poseidon2_permutations(10, (3, 5, 33))["hash_rows"] == (1 << 12) * (1 + 1 + 3 + 1) + 4 * (1 << 12) // 16
