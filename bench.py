@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,16,224", help="accum,code,data column counts")
     ap.add_argument("--cpu-po2", type=int, default=16, help="segment size of the bounded CPU-oracle sample")
@@ -206,6 +206,10 @@ def main():
             roofline["alu"] = {"achieved": round(alu, 2), "peak": round(alu_peak, 2), "unit": "T lane-instr/s",
                                "frac": round(alu / alu_peak, 4),
                                "permutations_per_s": round(perms / (dom["ms"] * 1e-3) / 1e9, 3),
+                               # same kernel alone on the GPU (the serial calibration proof): launches of
+                               # concurrent contexts share the CUs, which stretches each bracket
+                               "serial_frac": round(perms / args.steps * seg_mod.P2_VALU_PER_PERMUTATION /
+                                                    (calib[dom_name]["ms"] * 1e-3) / 1e12 / alu_peak, 4),
                                "valu_per_permutation": seg_mod.P2_VALU_PER_PERMUTATION}
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):
