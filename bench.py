@@ -240,18 +240,17 @@ def main():
                          "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
                          "kernels": kernels},
         }
-        if not args.no_verify or not args.no_cpu:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib
         if not args.no_verify:
-            # outside the timed region: the last seal must pass the CPU verifier
+            # outside the timed region: the last seal must pass the product's host-side verifier
+            # (rk_verify_segment; it needs only the public data of the segment)
+            from raiko_amd.hal import verify_segment
             seg, groups, check = segs[(args.steps - 1) % 2]
-            host = seg_mod.Segment(po2=seg.po2, taps=seg.taps,
-                                   groups=[g.cpu().numpy().view(np.uint32) for g in groups],
-                                   check=check.cpu().numpy().view(np.uint32), globals_=seg.globals_)
-            out["seal_verified"] = oracle_lib.oracle_verify(host, seals[-1]) == 0
+            out["seal_verified"] = verify_segment(seg, seals[-1]) == 0
             out["seal_words"] = int(seals[-1].size)
         if not args.no_cpu and world == 1:
+            # the cpu_baseline leg is the only place bench.py touches oracle/ (test infrastructure)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
             cseg = seg_mod.synthetic_segment(args.cpu_po2, widths, seed=1)
             threads = oracle_lib.oracle().or_max_threads()
             t1 = time.perf_counter()

@@ -89,3 +89,37 @@ def test_merkle_paths_2p22(hal, orc):
                 orc.or_hash_pair(cur.ctypes.data, sib.ctypes.data, nxt.ctypes.data)
             cur, idx = nxt, idx >> 1
         assert np.array_equal(cur, root)
+
+
+@pytest.mark.parametrize("k", [21, 23, 24])
+def test_ntt_beyond_the_two_pass_sizes(hal, orc, k):
+    """2^23 / 2^24 points take the three-pass plan of ntt_core.hpp (the LDE of a po2 = 21 / 22
+    segment), 2^21 the register-blocked two-pass kernels with g = 7: compared with the oracle's
+    transform of the same column, plus the round trip and the expanding form."""
+    rng = np.random.default_rng(300 + k)
+    n = 1 << k
+    x = o.rand_elems(rng, (1, n))
+    buf = hal.copy_from_elem(x)
+    hal.batch_interpolate_ntt(buf, 1)
+    want = x[0].copy()
+    orc.or_interpolate_ntt(want.ctypes.data, n)
+    got = buf.to_host()
+    assert np.array_equal(got, want)
+    hal.batch_evaluate_ntt(buf, 1)
+    assert np.array_equal(buf.to_host(), x[0])
+    # 4x expansion of a quarter-size coefficient vector == forward transform of the repeated vector
+    quarter = np.ascontiguousarray(x[0, : n // 4])
+    small = hal.copy_from_elem(quarter)
+    out = hal.alloc_elem(n)
+    hal.batch_expand_into_evaluate_ntt(out, small, 1, 2)
+    want_e = np.zeros(n, dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(want_e.ctypes.data, quarter.ctypes.data, n // 4, 1, 2)
+    assert np.array_equal(out.to_host(), want_e)
+
+
+def test_po2_22_segment_verifies(hal):
+    """the largest segment the 64 GiB scratch pool holds at this width: LDE of 2^24 points per column"""
+    from raiko_amd.segment import synthetic_segment
+    seg = synthetic_segment(22, (4, 4, 24), seed=2222)
+    seal = hal.prove_segment(seg)
+    assert o.oracle_verify(seg, seal) == 0
