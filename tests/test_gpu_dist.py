@@ -34,3 +34,35 @@ def test_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["seal_verified"] is True
     assert d["config"]["parallelism"] == "segment-parallel x2"
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from raiko_amd.dist import gather_seals
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", %(port)r)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+rng = np.random.default_rng(5)
+local = [rng.integers(0, 2**32, size=n, dtype=np.uint32) for n in (7, 260000, 1, 33)]
+out = gather_seals(local, len(local), device=dev)
+assert out is not None and len(out) == len(local)
+for a, b in zip(out, local):
+    assert a.dtype == np.uint32 and np.array_equal(a, b)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-gather-ok")
+"""
+
+
+def test_gather_seals_over_rccl_single_rank():
+    """the device-tensor form of the seal gather (backend "nccl" = RCCL) with a one-rank communicator:
+    the only multi-GPU collective of the path, exercised as far as a one-GPU box allows"""
+    code = _RCCL_ONE_RANK % {"root": ROOT, "port": str(_free_port())}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-gather-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
