@@ -132,7 +132,7 @@ def main():
         stage = {}
         jobs = [job(i) for i in indices]
 
-        def on_done(j, h):
+        def on_done(j, h, seal):
             for k, v in h.last_timing().items():
                 stage[(j, k)] = v
 

@@ -202,17 +202,25 @@ def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inf
     except ImportError:
         pass
     mine = rdist.shard_indices(len(session.segments), rank, world)
+    # `receipt.verify()` of the reference tests (lib.rs:136): every seal this rank produced must
+    # verify.  The check is host code (rk_verify_segment); it runs on the worker thread that
+    # produced the seal, under the proofs still in flight on the GPU.
+    from .hal import verify_segment
+    my_segments = [session.segments[i] for i in mine]
+    failed = []
+
+    def verify(j, hal, seal):
+        rc = verify_segment(my_segments[j], seal)
+        if rc != 0:
+            failed.append((mine[j], rc))
+
     with _DEVICE_LOCK:
         try:
-            local = _pipeline(device, inflight).prove([session.segments[i] for i in mine])
+            local = _pipeline(device, inflight).prove(my_segments, on_done=verify)
         except Exception as e:  # RkError etc.: surface as GuestError like `From<String>` (prover.rs:19-23)
             raise GuestError(str(e))
-    # `receipt.verify()` of the reference tests (lib.rs:136): every seal this rank produced must verify
-    from .hal import verify_segment
-    for i, seal in zip(mine, local):
-        rc = verify_segment(session.segments[i], seal)
-        if rc != 0:
-            raise GuestError("segment %d: seal failed verification (reason %d)" % (i, rc))
+    if failed:
+        raise GuestError("segment %d: seal failed verification (reason %d)" % min(failed))
     seals = rdist.gather_seals(local, len(session.segments)) if world > 1 else local
     if seals is None:  # non-root rank of a sharded proof
         seals = []
