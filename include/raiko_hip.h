@@ -33,7 +33,8 @@ typedef enum {
     RK_ERR_NOMEM = -3,
     RK_ERR_NODEVICE = -4,
     RK_ERR_CAPACITY = -5,  /* caller-provided output buffer too small */
-    RK_ERR_INTERNAL = -6   /* a prover invariant failed (non-zero remainder in the DEEP division) */
+    RK_ERR_INTERNAL = -6,  /* a prover invariant failed (non-zero remainder in the DEEP division) */
+    RK_ERR_VERIFY = -7     /* rk_prove_session: a produced seal did not pass rk_verify_segment */
 } rk_status;
 
 typedef struct rk_ctx rk_ctx;
@@ -136,6 +137,30 @@ int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_
 int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_words);
 /* Upper bound on the seal size for a given shape. */
 size_t rk_seal_bound_words(const rk_segment* seg);
+
+/* ---- whole-session prover: what replaces `session.prove()` (provers/risc0/driver/src/bonsai.rs:271,
+ * which proves the segments one after the other) ----
+ * Proves segs[0..n) on one GPU with `inflight` segments in flight (one prover context, HIP stream
+ * and host thread each, taken from a shared index) and, for host-resident segments
+ * (on_device == 0), one more context that uploads `upload_ahead` segments ahead into a ring of
+ * device buffers, so the PCIe transfer runs under the previous proofs.  With `verify` != 0 every
+ * seal is checked with rk_verify_segment by the thread that produced it.  Seal i goes to
+ * h_seals[i] (capacity seal_capacity_words[i], e.g. rk_seal_bound_words), its length to
+ * seal_words[i].  Returns RK_OK or the first failure (RK_ERR_VERIFY for a seal that does not
+ * verify) with the segment's index in *failed_index; rk_session_last_error gives the detail.
+ * Contexts and staging buffers persist per device for the life of the process (the reference's
+ * `Prover` has no `self`: lib/src/prover.rs:52-62); concurrent calls for one device are
+ * serialised.  rk_session_release frees them. */
+typedef struct {
+    int device;
+    int inflight;      /* 1..16; 3 is where an MI355X saturates at 2^20-cycle segments */
+    int upload_ahead;  /* 0..16 staged segments waiting for a prover; 2 hides a 20 ms upload */
+    int verify;
+} rk_session_opts;
+int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n, uint32_t* const* h_seals,
+                     const size_t* seal_capacity_words, size_t* seal_words, size_t* failed_index);
+const char* rk_session_last_error(int device);
+int rk_session_release(void);
 
 /* per-stage device time of the last rk_prove_segment on this ctx, milliseconds (hipEvent) */
 typedef struct { float ntt, hash, deep, fri, query, total; } rk_timing;

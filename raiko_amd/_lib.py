@@ -51,6 +51,13 @@ class RkSegment(C.Structure):
     ]
 
 
+class RkSessionOpts(C.Structure):
+    _fields_ = [("device", C.c_int), ("inflight", C.c_int), ("upload_ahead", C.c_int), ("verify", C.c_int)]
+
+
+RK_ERR_VERIFY = -7
+
+
 class RkKernelStat(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("bytes", C.c_double)]
 
@@ -65,6 +72,10 @@ class RkTiming(C.Structure):
 # every symbol include/raiko_hip.h declares: name -> (restype, argtypes)
 _vp, _sz, _u32 = C.c_void_p, C.c_size_t, C.c_uint32
 SYMBOLS = {
+    "rk_prove_session": (C.c_int, [C.POINTER(RkSessionOpts), C.POINTER(RkSegment), _sz, C.POINTER(u32p), C.POINTER(_sz),
+                                   C.POINTER(_sz), C.POINTER(_sz)]),
+    "rk_session_last_error": (C.c_char_p, [C.c_int]),
+    "rk_session_release": (C.c_int, []),
     "rk_abi_version": (C.c_int, []),
     "rk_strerror": (C.c_char_p, [C.c_int]),
     "rk_last_error": (C.c_char_p, [_vp]),

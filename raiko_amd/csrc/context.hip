@@ -134,6 +134,7 @@ const char* rk_strerror(int s) {
         case RK_ERR_NODEVICE: return "no usable GPU";
         case RK_ERR_CAPACITY: return "output buffer too small";
         case RK_ERR_INTERNAL: return "prover invariant violated";
+        case RK_ERR_VERIFY: return "a produced seal failed verification";
         default: return "unknown status";
     }
 }

@@ -205,6 +205,45 @@ class HipHal:
         return {n: getattr(t, n) for n, _ in t._fields_}
 
 
+def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: int = 2, verify: bool = True,
+                  device_inputs=None):
+    """Seals of all `segments`, in order, through rk_prove_session: `inflight` proofs in flight on
+    the GPU, host-resident traces staged `upload_ahead` segments ahead on a separate stream, every
+    seal verified by the thread that produced it (raiko_amd/csrc/session.hip).  Raises RkError with
+    `.status` (RK_ERR_VERIFY = -7 for a seal that does not verify) and `.segment` = failing index."""
+    lib = _lib.load()
+    n = len(segments)
+    if n == 0:
+        return []
+    c_segs = (_lib.RkSegment * n)()
+    keep = []
+    for i, seg in enumerate(segments):
+        c, k = make_c_segment(seg, device_inputs[i] if device_inputs else None)
+        C.memmove(C.byref(c_segs[i]), C.byref(c), C.sizeof(_lib.RkSegment))
+        keep.append((c, k))
+    caps = (C.c_size_t * n)()
+    words = (C.c_size_t * n)()
+    ptrs = (_lib.u32p * n)()
+    seals = []
+    for i in range(n):
+        caps[i] = int(lib.rk_seal_bound_words(C.byref(c_segs[i])))
+        buf = np.empty(caps[i], dtype=np.uint32)
+        seals.append(buf)
+        ptrs[i] = _u32p(buf)
+    opts = _lib.RkSessionOpts(device=device, inflight=inflight, upload_ahead=upload_ahead, verify=1 if verify else 0)
+    failed = C.c_size_t(0)
+    st = lib.rk_prove_session(C.byref(opts), c_segs, n, ptrs, caps, words, C.byref(failed))
+    del keep
+    if st != 0:
+        detail = lib.rk_session_last_error(device).decode()
+        which = int(failed.value) if failed.value != C.c_size_t(-1).value else -1
+        e = _lib.RkError(st, "%s%s%s" % (lib.rk_strerror(st).decode(), ": " + detail if detail else "",
+                                         " (segment %d)" % which if which >= 0 else ""))
+        e.segment = which
+        raise e
+    return [seals[i][: words[i]].copy() for i in range(n)]
+
+
 def verify_segment(seg: Segment, seal: np.ndarray) -> int:
     """Host-side check of a seal against the public data of `seg` (no GPU needed): 0 = valid,
     positive = reason code of the first failed check (raiko_amd/csrc/verify.hip)."""

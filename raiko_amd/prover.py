@@ -27,7 +27,6 @@ import json
 import os
 import struct
 import tempfile
-import threading
 from dataclasses import dataclass, field
 from typing import Any, List, Optional, Sequence, Tuple
 
@@ -146,8 +145,8 @@ class Receipt:
 
 
 _CACHE_DIR = None
-_DEVICE_LOCK = threading.Lock()  # `run` may be entered from up to concurrency_limit threads (host/src/lib.rs:38-41)
-_PIPELINES = {}  # (device, inflight) -> SegmentPipeline; process-global like every `Prover` backend's state
+# `run` may be entered from up to concurrency_limit threads (host/src/lib.rs:38-41): rk_prove_session
+# serialises sessions per device inside the library, where the contexts live
 
 
 def _cache_dir() -> str:
@@ -178,14 +177,6 @@ def load_receipt(label: str) -> Optional[Receipt]:
         return None
 
 
-def _pipeline(device: int, inflight: int):
-    from .pipeline import SegmentPipeline  # raises HipLibraryError when the library / GPU is missing: no fallback
-    key = (device, inflight)
-    if key not in _PIPELINES:
-        _PIPELINES[key] = SegmentPipeline(device, inflight)
-    return _PIPELINES[key]
-
-
 def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inflight: int = 3) -> Receipt:
     """bonsai.rs:230-272 from the point the executor has produced the session: prove every
     segment (this rank's shard when torch.distributed is initialised), `inflight` at a time on
@@ -202,25 +193,18 @@ def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inf
     except ImportError:
         pass
     mine = rdist.shard_indices(len(session.segments), rank, world)
-    # `receipt.verify()` of the reference tests (lib.rs:136): every seal this rank produced must
-    # verify.  The check is host code (rk_verify_segment); it runs on the worker thread that
-    # produced the seal, under the proofs still in flight on the GPU.
-    from .hal import verify_segment
-    my_segments = [session.segments[i] for i in mine]
-    failed = []
-
-    def verify(j, hal, seal):
-        rc = verify_segment(my_segments[j], seal)
-        if rc != 0:
-            failed.append((mine[j], rc))
-
-    with _DEVICE_LOCK:
-        try:
-            local = _pipeline(device, inflight).prove(my_segments, on_done=verify)
-        except Exception as e:  # RkError etc.: surface as GuestError like `From<String>` (prover.rs:19-23)
-            raise GuestError(str(e))
-    if failed:
-        raise GuestError("segment %d: seal failed verification (reason %d)" % min(failed))
+    # rk_prove_session (raiko_amd/csrc/session.hip): `inflight` proofs in flight, uploads staged ahead
+    # on their own stream, and -- the `receipt.verify()` of the reference's tests (lib.rs:136) -- every
+    # seal verified by the thread that produced it.  The library serialises sessions per device and
+    # keeps its contexts for the life of the process.
+    from . import _lib
+    from .hal import prove_session
+    try:
+        local = prove_session([session.segments[i] for i in mine], device=device, inflight=inflight)
+    except _lib.RkError as e:  # surface as GuestError like `From<String>` (prover.rs:19-23)
+        if e.status == _lib.RK_ERR_VERIFY:
+            raise GuestError("segment %d: seal failed verification" % mine[e.segment])
+        raise GuestError(str(e))
     seals = rdist.gather_seals(local, len(session.segments)) if world > 1 else local
     if seals is None:  # non-root rank of a sharded proof
         seals = []

@@ -44,6 +44,17 @@ def test_no_gpu_means_loud_failure_not_fallback():
     ctx = C.c_void_p()
     assert lib.rk_ctx_create(0, None, C.byref(ctx)) == -4  # RK_ERR_NODEVICE
     assert not ctx.value
+    # the session entry point and the Prover mirror fail the same way: no seal comes out of a CPU
+    from raiko_amd.hal import prove_session
+    from raiko_amd.segment import synthetic_segment
+    segs = [synthetic_segment(5, (2, 2, 3), seed=s) for s in (1, 2)]
+    with pytest.raises(_lib.RkError) as ei:
+        prove_session(segs, inflight=2)
+    assert ei.value.status == -4 and ei.value.segment == -1
+    assert lib.rk_strerror(-7) == b"a produced seal failed verification"
+    opts = _lib.RkSessionOpts(device=0, inflight=0, upload_ahead=0, verify=1)
+    assert lib.rk_prove_session(C.byref(opts), None, 0, None, None, None, None) == -1  # inflight out of range
+    assert lib.rk_session_release() == 0
 
 
 def test_product_never_imports_the_oracle():

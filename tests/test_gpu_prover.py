@@ -140,3 +140,36 @@ def test_malformed_segments_are_rejected(hal):
     seg2.taps.reg_combo[0] = 99
     with pytest.raises(RkError):
         hal.prove_segment(seg2)
+
+
+def test_native_session_prover(hal):
+    """rk_prove_session: several segments in flight + staged uploads + per-seal verification inside
+    the library; seals identical to one-at-a-time proving, in order, for mixed shapes"""
+    from raiko_amd.hal import prove_session
+    segs = [synthetic_segment(9 + (i % 3), (4, 4, 8 + 4 * (i % 2)), seed=600 + i) for i in range(7)]
+    want = [hal.prove_segment(s) for s in segs]
+    for inflight, ahead in ((1, 0), (2, 1), (3, 2)):
+        got = prove_session(segs, device=0, inflight=inflight, upload_ahead=ahead, verify=True)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    assert np.array_equal(want[0], o.oracle_prove(segs[0]))
+    # HBM-resident inputs skip the staging ring
+    dev = [([hal.copy_from_elem(g) for g in s.groups], hal.copy_from_elem(s.check)) for s in segs[:3]]
+    got = prove_session(segs[:3], inflight=2, device_inputs=dev)
+    for a, b in zip(got, want[:3]):
+        assert np.array_equal(a, b)
+
+
+def test_native_session_reports_the_failing_segment(hal):
+    from raiko_amd._lib import RkError
+    from raiko_amd.hal import prove_session
+    segs = [synthetic_segment(8, (2, 2, 4), seed=700 + i) for i in range(5)]
+    segs[3].taps.reg_combo = segs[3].taps.reg_combo.copy()
+    segs[3].taps.reg_combo[0] = 99
+    with pytest.raises(RkError) as ei:
+        prove_session(segs, inflight=2)
+    assert ei.value.segment == 3
+    # the pool survives a failed session
+    good = prove_session(segs[:2], inflight=2)
+    assert np.array_equal(good[1], hal.prove_segment(segs[1]))
