@@ -30,7 +30,7 @@ struct rk_ctx {
     std::multimap<size_t, void*> free_list;
     std::unordered_map<void*, size_t> live;
     size_t pooled_bytes = 0;                         // bytes parked in free_list
-    size_t pool_limit = (size_t)64 << 30;            // above this the cache is dropped (varying shapes)
+    size_t pool_limit = (size_t)24 << 30;            // parked bytes above this: the cache is dropped (varying shapes); several contexts share one GPU
 
     // small staging area for per-call parameter uploads
     void* d_scratch = nullptr;

@@ -118,7 +118,7 @@ def test_ntt_beyond_the_two_pass_sizes(hal, orc, k):
 
 
 def test_po2_22_segment_verifies(hal):
-    """the largest segment the 64 GiB scratch pool holds at this width: LDE of 2^24 points per column"""
+    """a 2^22-cycle segment (narrow, to bound the test): LDE of 2^24 points per column, three-pass NTT plan"""
     from raiko_amd.segment import synthetic_segment
     seg = synthetic_segment(22, (4, 4, 24), seed=2222)
     seal = hal.prove_segment(seg)
