@@ -30,7 +30,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,16,224", help="accum,code,data column counts")
-    ap.add_argument("--cpu-po2", type=int, default=16, help="segment size of the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-po2", type=int, default=18, help="segment size of the bounded CPU-oracle sample")
     ap.add_argument("--inflight", type=int, default=3,
                     help="segments proven concurrently per GPU (one prover context + HIP stream each); "
                          "the latency-bound parts of one proof (Merkle tops, transcript round trips) "
@@ -146,8 +146,9 @@ def main():
     # One serial calibration proof (also a warm-up): with a single stream the hipEvent brackets
     # are pure kernel time, which picks the dominant kernel class; under concurrency a bracket
     # also contains time spent queued behind the other context's kernels.
+    prove(0)  # cold: first-touch allocations, table uploads
     hal.set_kernel_timing(True)
-    prove(0)
+    prove(1)
     calib = hal.kernel_stats()
     hal.set_kernel_timing(False)
     dom_name = max(calib.items(), key=lambda kv: kv[1]["ms"])[0]
