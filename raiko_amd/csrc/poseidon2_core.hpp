@@ -12,14 +12,16 @@
 // multiplies and 64-bit mads included -- issues at 16 lanes/clk/SIMD, only plain VGPR add/sub
 // is twice as fast.  The permutation is therefore written to minimise instruction count:
 //   * S-box: signed Montgomery products (3 instructions each, no reduction inside the chain);
-//   * external layer: exact 64-bit accumulation (v_mad_u64_u32 with small literal multipliers,
-//     64-bit adds) followed by one REDC per cell instead of ~5.5 modular additions per cell.
+//   * external layer: exact signed 64-bit accumulation of the signed-lazy S-box outputs
+//     (v_mad_i64_i32 with small literal multipliers, 64-bit adds) followed by one signed REDC per
+//     cell -- no modular addition and no canonicalisation anywhere in a full round.
 //     REDC divides by 2^32, so inside a block of four full rounds the state carries a known
-//     scale factor 2^(32 e) (e = 0, -7, -56, -399, ...): the round constants are pre-scaled
-//     per round, and one constant multiplication in the last round of the block brings the
-//     state back to Montgomery form;
-//   * internal layer: 64-bit exact sum, one constant product + one conditional subtraction per
-//     cell, unsigned-lazy cells in [0, 2p).
+//     scale factor 2^(32 e) (e = 0, -7, -56, -399, then -2800): the round constants are
+//     pre-scaled per round.  The first block's factor is absorbed by the constants of the
+//     partial rounds (one product for cell 0), the second block's by one product per OUTPUT cell
+//     after the last layer, so a caller that keeps only some cells (digest, sponge capacity)
+//     pays only for those;
+//   * internal layers: all 21 partial rounds in closed form (see partial_rounds()).
 #pragma once
 #include "bb.hpp"
 
@@ -42,11 +44,12 @@ struct Consts {
     uint32_t rc_int[ROUNDS_PARTIAL];
     uint32_t diag[CELLS];
     // derived by derive()
-    uint32_t rc_ext_in[2 * ROUNDS_HALF_FULL * CELLS];  // rc * scale(round) - p: added to the S-box input
+    uint32_t rc_ext_in[2 * ROUNDS_HALF_FULL * CELLS];  // rc * scale(round) as the S-box input offset: rc - p after an
+                                                       // unsigned state (rounds 0, 4), centred in (-p/2, p/2] otherwise
     uint32_t rc_int_mp[ROUNDS_PARTIAL];                // rc - p
-    uint32_t diag_q[CELLS];                            // diag * (-p^-1) mod 2^32 (bb::umul_const companion)
-    uint32_t r2_q;                                     // companion of bb::R2 for bb::umul_const
-    uint32_t fix[2], fix_q[2];                         // block-end rescale constants and bb::smul_const companions
+    uint32_t fix[2];                                   // block-end rescale constants 2^(32 (2 - e_end)), plain residues
+    uint32_t fix0_nq;                                  // fix[0] * (-p^-1) mod 2^32 (bb::umul_const companion)
+    uint32_t fix1_q;                                   // fix[1] * p^-1 mod 2^32 (bb::smul_const companion)
     // partial rounds in closed form (see partial_rounds()): the constants in the order the
     // code consumes them, each as a pair {c, c * 2^16 mod p} for the low / high 16-bit halves
     // of the variable it multiplies (+ one chunk of padding for the read-ahead)
@@ -68,24 +71,25 @@ inline void derive(Consts& k) {
         // residue a * 2^(32 e) for the true state a, so the residue to add is rc * 2^(32 e):
         // bb::mul(v, f) = v * f / 2^32 with the residue f = 2^(32 e) = rpow(e - 1).
         uint32_t f = rpow((long)SCALE_EXP[r] - 1);
+        const bool after_unsigned = r % ROUNDS_HALF_FULL == 0;  // input in [0, p + 2^22): offset rc - p
         for (int i = 0; i < CELLS; i++) {
             uint32_t c = bb::mul(k.rc_ext[r * CELLS + i], f);
-            k.rc_ext_in[r * CELLS + i] = c - bb::P;
+            // otherwise the input is a signed REDC output, |x| <= p/2 + 53: centred offset, |x + rc| < 2^31
+            k.rc_ext_in[r * CELLS + i] = (after_unsigned || c > bb::P / 2) ? c - bb::P : c;
         }
     }
     for (int i = 0; i < ROUNDS_PARTIAL; i++) k.rc_int_mp[i] = k.rc_int[i] - bb::P;
-    for (int i = 0; i < CELLS; i++) k.diag_q[i] = k.diag[i] * (0u - bb::MPRIME);
-    k.r2_q = bb::R2 * (0u - bb::MPRIME);
-    // last round of a block: S-box output carries 2^(32 (7 e - 6)); after x -> x * K / 2^32,
-    // the external layer and REDC (another / 2^32) the state must carry 2^32 (Montgomery form):
-    // K = 2^(32 (3 - (7 e - 6))) = 2^(32 (9 - 7 e)), as a plain residue.
+    // a block ends with the state scaled by 2^(32 e_end), e_end = 7 e - 7 for the last round's e;
+    // x -> x * K / 2^32 with K = 2^(32 (2 - e_end)) (plain residue) gives Montgomery form
     for (int b = 0; b < 2; b++) {
         long e = SCALE_EXP[b * ROUNDS_HALF_FULL + ROUNDS_HALF_FULL - 1];
-        k.fix[b] = bb::decode(rpow(9 - 7 * e));
-        k.fix_q[b] = k.fix[b] * bb::MPRIME;
+        k.fix[b] = bb::decode(rpow(2 - (7 * e - 7)));
     }
+    k.fix0_nq = k.fix[0] * (0u - bb::MPRIME);
+    k.fix1_q = k.fix[1] * bb::MPRIME;
     // closed-form partial rounds: powers of the diagonal (Montgomery residues: they multiply a
-    // Montgomery-form variable and the sum goes through one REDC)
+    // Montgomery-form variable and the sum goes through one REDC).  The constants that multiply
+    // the ENTRY cells also carry fix[0]: those cells arrive scaled by the first block.
     const uint32_t two16 = bb::encode(65536u);
     uint32_t pw[CELLS - 1][ROUNDS_PARTIAL + 1];
     for (int i = 1; i < CELLS; i++) {
@@ -100,12 +104,12 @@ inline void derive(Consts& k) {
     int n = 0;
     auto put = [&](uint32_t c) { k.pr_stream[n++] = c; k.pr_stream[n++] = bb::mul(c, two16); };
     for (int r = 0; r < ROUNDS_PARTIAL; r++) {
-        for (int i = 0; i < CELLS - 1; i++) put(pw[i][r]);
+        for (int i = 0; i < CELLS - 1; i++) put(bb::mul(pw[i][r], k.fix[0]));
         for (int j = 0; j < r; j++) put(csum[r - 1 - j]);
         k.pr_stream[n++] = bb::add(k.diag[0], bb::ONE);
     }
     for (int i = 0; i < CELLS - 1; i++) {
-        put(pw[i][ROUNDS_PARTIAL]);
+        put(bb::mul(pw[i][ROUNDS_PARTIAL], k.fix[0]));
         for (int j = 0; j < ROUNDS_PARTIAL; j++) put(pw[i][ROUNDS_PARTIAL - 1 - j]);
     }
     while (n < PR_STREAM_WORDS) k.pr_stream[n++] = 0;
@@ -138,6 +142,27 @@ RK_HD uint64_t mulk(uint32_t x) {
 #endif
 }
 
+// signed forms: acc + x * K on signed-lazy values (v_mad_i64_i32)
+template <int K>
+RK_HD int64_t smadk(int32_t x, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "n"(K) : "vcc");
+    return acc;
+#else
+    return acc + (int64_t)x * (int64_t)K;
+#endif
+}
+template <int K>
+RK_HD int64_t smulk(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(x), "n"(K) : "vcc");
+    return r;
+#else
+    return (int64_t)x * (int64_t)K;
+#endif
+}
+
 // External layer circ(2*M4, M4, ..., M4), M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]], on
 // canonical cells, exact: w[i] < 112 p < 2^38.  Then s[i] = w[i] * 2^-32 (mod p) in [0, p + 53).
 RK_HD void m_ext_redc(uint32_t* s) {
@@ -159,7 +184,30 @@ RK_HD void m_ext_redc(uint32_t* s) {
     for (int i = 0; i < CELLS; i++) s[i] = bb::uredc64(w[i] + t[i & 3]);
 }
 
-// (x + c)^7 * 2^(-6*32) as a signed-lazy value; x in [0, p + 53), c_mp = c - p
+// The same layer on signed-lazy cells |y| < p (S-box outputs), exact in int64 (|w| < 112 p), then
+// r[i] = w[i] * 2^-32 (mod p) as a signed value, |r| <= p/2 + 53.  Sums like a + b do not fit 32
+// bits here, so every term is its own mad: 14 per four cells instead of 10 + 2 additions, which
+// is less than the two instructions per cell a canonicalisation of the inputs would cost.
+RK_HD void m_ext_redc_s(const int32_t* y, int32_t* r) {
+    int64_t w[CELLS];
+#pragma unroll
+    for (int i = 0; i < CELLS; i += 4) {
+        int32_t a = y[i], b = y[i + 1], c = y[i + 2], d = y[i + 3];
+        int64_t u1 = smadk<1>(d, smadk<1>(c, smadk<6>(b, smulk<4>(a))));  // 4a + 6b +  c +  d
+        int64_t u0 = smadk<2>(d, smadk<1>(b, smadk<1>(a, u1)));           // 5a + 7b +  c + 3d
+        int64_t u3 = smadk<1>(b, smadk<1>(a, smadk<6>(d, smulk<4>(c))));  //  a +  b + 4c + 6d
+        int64_t u2 = smadk<2>(b, smadk<1>(d, smadk<1>(c, u3)));           //  a + 3b + 5c + 7d
+        w[i] = u0; w[i + 1] = u1; w[i + 2] = u2; w[i + 3] = u3;
+    }
+    int64_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[j] = ((w[j] + w[4 + j]) + (w[8 + j] + w[12 + j])) + (w[16 + j] + w[20 + j]);
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) r[i] = bb::redc64(w[i] + t[i & 3]);
+}
+
+// (x + c)^7 * 2^(-6*32) as a signed-lazy value, |result| < p.  x + c must fit an int32: x unsigned in
+// [0, p + 2^22) with c = rc - p, or x a signed REDC output (|x| <= p/2 + 53) with c centred.
 RK_HD int32_t sbox7_lazy(uint32_t x, uint32_t c_mp) {
     int32_t s = (int32_t)(x + c_mp);
     int32_t s2 = bb::smul(s, s);
@@ -167,36 +215,20 @@ RK_HD int32_t sbox7_lazy(uint32_t x, uint32_t c_mp) {
     int32_t s6 = bb::smul(s3, s3);
     return bb::smul(s6, s);
 }
-template <bool LAST>
-RK_HD void full_round(uint32_t* s, const Consts& k, int r, int block) {
+// One full round on the 32-bit patterns of the cells (unsigned after the first layer / the partial
+// rounds, signed otherwise: the offset form of the round constants follows, see derive()).
+RK_HD void full_round(uint32_t* s, const Consts& k, int r) {
+    int32_t y[CELLS], o[CELLS];
 #pragma unroll
-    for (int i = 0; i < CELLS; i++) {
-        int32_t y = sbox7_lazy(s[i], k.rc_ext_in[r * CELLS + i]);
-        if (LAST) y = bb::smul_const(y, (int32_t)k.fix[block], k.fix_q[block]);
-        s[i] = bb::canon(y);
-    }
-    m_ext_redc(s);
+    for (int i = 0; i < CELLS; i++) y[i] = sbox7_lazy(s[i], k.rc_ext_in[r * CELLS + i]);
+    m_ext_redc_s(y, o);
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) s[i] = (uint32_t)o[i];
 }
 
-// One partial round.  Cells are "unsigned-lazy" representatives in [0, 2p) (cell 0 < p + 53):
-//   cell0 <- sbox(cell0 + rc);  S = sum of all cells;  cell_i <- d_i * cell_i + S.
-// S is accumulated exactly in 64 bits (one v_mad_u64_u32 per cell, overlapping the power chain
-// of cell 0) and brought to [0, p) by REDC and a multiplication by 2^64 mod p; each product
-// d_i * cell_i is reduced to [0, p) with one conditional subtraction and S is added without
-// reduction (result < 2p fits a u32 because 2p < 2^32).
-RK_HD void partial_round(uint32_t* s, const Consts& k, int r) {
-    uint64_t acc = 0;
-#pragma unroll
-    for (int i = 1; i < CELLS; i++) acc = bb::acc_u32(acc, s[i]);
-    s[0] = bb::canon(sbox7_lazy(s[0], k.rc_int_mp[r]));
-    acc = bb::acc_u32(acc, s[0]);
-    uint32_t S = bb::ucanon(bb::umul_const(bb::uredc64(acc), bb::R2, k.r2_q));
-    s[0] = bb::add(S, bb::ucanon(bb::umul_const(s[0], k.diag[0], k.diag_q[0])));
-#pragma unroll
-    for (int i = 1; i < CELLS; i++) s[i] = bb::ucanon(bb::umul_const(s[i], k.diag[i], k.diag_q[i])) + S;
-}
-
-// All 21 partial rounds in closed form.  With v = cells 1..23 at entry, y_k the S-box output of
+// All 21 partial rounds in closed form.  Entry: any 32-bit representatives of the cells, scaled by
+// the first block of full rounds (see permute()); exit: Montgomery form, cells in [0, p + 2^22).
+// With v = cells 1..23 at entry, y_k the S-box output of
 // round k and S_k = y_k + sum(cells 1..23 before round k):
 //     cells_i before round k   = d_i^k v_i + sum_{j<k} d_i^(k-1-j) S_j
 //     sum of them              = sum_i d_i^k v_i + sum_{j<k} c_(k-1-j) S_j,     c_m = sum_i d_i^m
@@ -262,7 +294,9 @@ RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
         vhi[i] = s[i + 1] >> 16;
     }
     KStream ks(k.pr_stream);
-    uint32_t x0 = s[0];  // [0, p + 2^22)
+    // cell 0 feeds an S-box, so it needs its true (Montgomery) value: one product by fix[0]; the other
+    // cells only enter linear forms, whose constants carry fix[0] (derive())
+    uint32_t x0 = bb::ucanon(bb::umul_const(s[0], k.fix[0], k.fix0_nq));
     static_for<0, ROUNDS_PARTIAL>([&](auto rc) __attribute__((always_inline)) {
         constexpr int R = decltype(rc)::value;
         constexpr int BASE = (2 * NV + 1) * R + R * (R - 1);
@@ -308,24 +342,19 @@ RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
 }
 
 RK_HD void permute(uint32_t* s, const Consts& k) {
-    m_ext_redc(s);  // canonical Montgomery input -> plain residues (scale 2^0)
+    m_ext_redc(s);  // canonical Montgomery input -> plain residues (scale 2^0), cells in [0, p + 53)
 #pragma unroll 1
-    for (int r = 0; r < ROUNDS_HALF_FULL - 1; r++) full_round<false>(s, k, r, 0);
-    full_round<true>(s, k, ROUNDS_HALF_FULL - 1, 0);  // back to Montgomery form, cells in [0, p + 53)
-#if defined(P2_PARTIAL_PER_ROUND)
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS_PARTIAL; r++) partial_round(s, k, r);
-    // cells 1..23 are representatives in [0, 2p): back to [0, p) before the S-box input offset
+    for (int r = 0; r < ROUNDS_HALF_FULL; r++) full_round(s, k, r);
+    // signed cells (|x| <= p/2 + 53) scaled by 2^(32 * -2800): + p gives non-negative representatives,
+    // which is all partial_rounds() needs (it splits them into halves and owns the scale)
 #pragma unroll
-    for (int i = 1; i < CELLS; i++) s[i] = bb::ucanon(s[i]);
-#else
-    partial_rounds(s, k);  // cells in [0, p + 2^22): fine for the S-box input offset (|x + rc - p| < 2^31)
-#endif
+    for (int i = 0; i < CELLS; i++) s[i] += bb::P;
+    partial_rounds(s, k);  // Montgomery form again, cells in [0, p + 2^22)
 #pragma unroll 1
-    for (int r = ROUNDS_HALF_FULL; r < 2 * ROUNDS_HALF_FULL - 1; r++) full_round<false>(s, k, r, 1);
-    full_round<true>(s, k, 2 * ROUNDS_HALF_FULL - 1, 1);
+    for (int r = ROUNDS_HALF_FULL; r < 2 * ROUNDS_HALF_FULL; r++) full_round(s, k, r);
+    // per-cell rescale to Montgomery form + canonical range: cells the caller never reads cost nothing
 #pragma unroll
-    for (int i = 0; i < CELLS; i++) s[i] = bb::ucanon(s[i]);
+    for (int i = 0; i < CELLS; i++) s[i] = bb::canon(bb::smul_const((int32_t)s[i], (int32_t)k.fix[1], k.fix1_q));
 }
 
 }  // namespace p2

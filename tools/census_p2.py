@@ -2,7 +2,7 @@
 """Dynamic VALU instruction count of one Poseidon2 permutation from the gfx950 ISA.
 
 Compiles tools/ubench_p2.hip (which inlines p2::permute once inside a loop) to assembly, splits
-the kernel at its two rolled loops (three full rounds each, `#pragma unroll 1` in
+the kernel at its two rolled loops (four full rounds each, `#pragma unroll 1` in
 poseidon2_core.hpp) and weights their bodies by the trip count.  The result is the constant
 raiko_amd/segment.py:P2_VALU_PER_PERMUTATION used by bench.py's `roofline.alu`.
 
@@ -50,10 +50,10 @@ def main():
         return n, fast
 
     total = list(count(outer[0], outer[1]))
-    for a, b in inner:  # bodies run 3 times (rounds 0..2 and 4..6), counted once above
+    for a, b in inner:  # bodies run 4 times (rounds 0..3 and 4..7), counted once above
         n, f = count(a, b)
-        total[0] += 2 * n
-        total[1] += 2 * f
+        total[0] += 3 * n
+        total[1] += 3 * f
     print("VALU instructions per permutation: %d (plain add/sub: %d); loop bodies: %s" %
           (total[0], total[1], [count(a, b)[0] for a, b in inner]))
     return 0
