@@ -144,7 +144,7 @@ size_t rk_seal_bound_words(const rk_segment* seg);
  * and host thread each, taken from a shared index) and, for host-resident segments
  * (on_device == 0), one more context that uploads `upload_ahead` segments ahead into a ring of
  * device buffers, so the PCIe transfer runs under the previous proofs.  With `verify` != 0 every
- * seal is checked with rk_verify_segment by the thread that produced it.  Seal i goes to
+ * seal is checked with rk_verify_segment on one more host thread while the GPU goes on.  Seal i goes to
  * h_seals[i] (capacity seal_capacity_words[i], e.g. rk_seal_bound_words), its length to
  * seal_words[i].  Returns RK_OK or the first failure (RK_ERR_VERIFY for a seal that does not
  * verify) with the segment's index in *failed_index; rk_session_last_error gives the detail.

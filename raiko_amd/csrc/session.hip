@@ -6,8 +6,8 @@
 // independent, so this entry point runs `inflight` prover contexts (one HIP stream, scratch pool and
 // host thread each) over a shared index, and one more context + thread stages host-resident traces
 // `upload_ahead` segments ahead into a ring of device buffers, so the PCIe upload of segment i+1
-// runs under the proof of segment i.  Each seal is verified (rk_verify_segment, host code) by the
-// worker that produced it while the GPU runs the other contexts.  Contexts and staging buffers are
+// runs under the proof of segment i.  Each seal is verified (rk_verify_segment, host code) by one
+// more thread while the GPU goes on.  Contexts and staging buffers are
 // kept per device for the life of the process (rk_session_release frees them): the `Prover` trait
 // of the reference has no `self`, a backend's state is process-global (lib/src/prover.rs:52-62).
 #include <atomic>
@@ -76,6 +76,8 @@ struct Run {
     std::condition_variable cv;
     std::map<size_t, Slot*> ready;   // staged segments not yet taken by a prover
     std::deque<Slot*> free_slots;
+    std::deque<size_t> to_verify;    // finished seals waiting for the verifier thread
+    size_t provers_left = 0;
     bool stop = false;               // stager finished or the run is aborted
     int status = RK_OK;              // first failure
     size_t failed = (size_t)-1;
@@ -180,12 +182,36 @@ void prover(rk_ctx* ctx, Run* run) {
             run->fail(st, i, rk_last_error(ctx));
             return;
         }
-        if (run->verify) {
-            int rc = rk_verify_segment(&run->segs[i], run->h_seals[i], run->words[i]);
-            if (rc != 0) {
-                run->fail(RK_ERR_VERIFY, i, "seal failed verification");
-                return;
-            }
+        if (run->verify) {  // host work: handed to the verifier thread so this context goes straight on
+            std::lock_guard<std::mutex> l(run->mu);
+            run->to_verify.push_back(i);
+            run->cv.notify_all();
+        }
+    }
+}
+
+void prover_thread(rk_ctx* ctx, Run* run) {
+    prover(ctx, run);
+    std::lock_guard<std::mutex> l(run->mu);
+    run->provers_left--;
+    run->cv.notify_all();
+}
+
+// rk_verify_segment of every finished seal (~9 ms of host time at S20, against ~26 ms per proof)
+void verifier(Run* run) {
+    for (;;) {
+        size_t i;
+        {
+            std::unique_lock<std::mutex> l(run->mu);
+            run->cv.wait(l, [&] { return !run->to_verify.empty() || run->provers_left == 0 || run->status != RK_OK; });
+            if (run->status != RK_OK) return;
+            if (run->to_verify.empty()) return;  // all provers done, nothing left
+            i = run->to_verify.front();
+            run->to_verify.pop_front();
+        }
+        if (rk_verify_segment(&run->segs[i], run->h_seals[i], run->words[i]) != 0) {
+            run->fail(RK_ERR_VERIFY, i, "seal failed verification");
+            return;
         }
     }
 }
@@ -236,9 +262,11 @@ int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t
     // with nothing to hide behind (upload_ahead == 0) the ring still needs one slot per prover
     const size_t n_slots = (size_t)opts->upload_ahead + workers;
     for (size_t k = 0; k < pool->ring.size() && k < n_slots; k++) run.free_slots.push_back(pool->ring[k]);
+    run.provers_left = workers;
     std::vector<std::thread> threads;
     if (any_host) threads.emplace_back(stager, pool, &run, n_slots);
-    for (size_t w = 0; w < workers; w++) threads.emplace_back(prover, pool->provers[w], &run);
+    for (size_t w = 0; w < workers; w++) threads.emplace_back(prover_thread, pool->provers[w], &run);
+    if (run.verify) threads.emplace_back(verifier, &run);
     for (auto& t : threads) t.join();
     if (run.status != RK_OK) {
         if (failed_index) *failed_index = run.failed;

@@ -209,7 +209,7 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
                   device_inputs=None):
     """Seals of all `segments`, in order, through rk_prove_session: `inflight` proofs in flight on
     the GPU, host-resident traces staged `upload_ahead` segments ahead on a separate stream, every
-    seal verified by the thread that produced it (raiko_amd/csrc/session.hip).  Raises RkError with
+    seal verified on a host thread of its own (raiko_amd/csrc/session.hip).  Raises RkError with
     `.status` (RK_ERR_VERIFY = -7 for a seal that does not verify) and `.segment` = failing index."""
     lib = _lib.load()
     n = len(segments)

@@ -195,7 +195,7 @@ def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inf
     mine = rdist.shard_indices(len(session.segments), rank, world)
     # rk_prove_session (raiko_amd/csrc/session.hip): `inflight` proofs in flight, uploads staged ahead
     # on their own stream, and -- the `receipt.verify()` of the reference's tests (lib.rs:136) -- every
-    # seal verified by the thread that produced it.  The library serialises sessions per device and
+    # seal verified on a host thread while the GPU goes on.  The library serialises sessions per device and
     # keeps its contexts for the life of the process.
     from . import _lib
     from .hal import prove_session
