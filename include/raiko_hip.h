@@ -114,7 +114,8 @@ typedef struct {
 
 typedef struct {
     uint32_t po2;                  /* segment has 2^po2 rows */
-    uint32_t on_device;            /* 1: group[] and check are device pointers, 0: host pointers */
+    uint32_t on_device;            /* 0: group[] and check are host pointers; 1: device pointers, left untouched
+                                    * (the prover works on a copy); 2: device pointers the prover may overwrite */
     rk_taps taps;
     const uint32_t* group[3];      /* trace evaluations, column-major 2^po2 x group_size[g] */
     const uint32_t* check;         /* eval_check output: 4 x 4*2^po2 evaluations (CircuitHal::eval_check) */

@@ -79,6 +79,7 @@ void hash_elems(const p2::Consts& k, const uint32_t* in, size_t n, uint32_t* dig
 struct DevBuf {
     rk_ctx* ctx = nullptr;
     void* p = nullptr;
+    bool borrowed = false;  // caller-owned memory used in place (rk_segment.on_device == 2)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -88,9 +89,16 @@ struct DevBuf {
         ctx = c;
         return rk::dev_alloc(c, bytes, &p);
     }
+    void adopt(rk_ctx* c, void* ptr) {
+        release();
+        ctx = c;
+        p = ptr;
+        borrowed = true;
+    }
     void release() {
-        if (p) rk::dev_free(ctx, p);
+        if (p && !borrowed) rk::dev_free(ctx, p);
         p = nullptr;
+        borrowed = false;
     }
     uint32_t* u32() const { return (uint32_t*)p; }
 };
@@ -302,6 +310,10 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     }
 
     auto load_trace = [&](DevBuf& dst, const uint32_t* src, size_t words) -> int {
+        if (seg->on_device == 2) {  // the caller gave the buffer up: transform it in place
+            dst.adopt(ctx, (void*)src);
+            return RK_OK;
+        }
         RK_TRY(dst.alloc(ctx, words * 4));
         RK_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, words * 4,
                                        seg->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
@@ -597,7 +609,7 @@ size_t rk_seal_bound_words(const rk_segment* seg) {
 }
 
 int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t cap, size_t* seal_words) {
-    if (!ctx || !seg || !seal_words) return RK_ERR_INVALID;
+    if (!ctx || !seg || !seal_words || seg->on_device > 2) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<uint32_t> seal;
     int st = prove_segment(ctx, seg, seal);

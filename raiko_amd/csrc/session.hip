@@ -168,7 +168,7 @@ void prover(rk_ctx* ctx, Run* run) {
             if (run->status != RK_OK) return;
             slot = run->ready[i];
             run->ready.erase(i);
-            seg.on_device = 1;
+            seg.on_device = 2;  // the staged copy is ours: no second copy inside the prover
             for (int g = 0; g < 3; g++) seg.group[g] = (const uint32_t*)slot->group[g];
             seg.check = (const uint32_t*)slot->check;
         }

@@ -175,10 +175,13 @@ class HipHal:
         return rem
 
     # ---- whole segment ----
-    def prove_segment(self, seg: Segment, device_inputs=None) -> np.ndarray:
+    def prove_segment(self, seg: Segment, device_inputs=None, consume_inputs: bool = False) -> np.ndarray:
         """Seal (uint32 transcript) of one segment.  `device_inputs` = (groups[3], check) of device
-        buffers / tensors to prove from HBM-resident inputs; otherwise the host arrays are uploaded."""
+        buffers / tensors to prove from HBM-resident inputs; otherwise the host arrays are uploaded.
+        `consume_inputs`: the device buffers may be overwritten (no private copy inside the prover)."""
         c_seg, keep = make_c_segment(seg, device_inputs)
+        if consume_inputs and device_inputs is not None:
+            c_seg.on_device = 2
         cap = int(self._lib.rk_seal_bound_words(C.byref(c_seg)))
         seal = np.empty(cap, dtype=np.uint32)
         words = C.c_size_t(0)

@@ -173,3 +173,23 @@ def test_native_session_reports_the_failing_segment(hal):
     # the pool survives a failed session
     good = prove_session(segs[:2], inflight=2)
     assert np.array_equal(good[1], hal.prove_segment(segs[1]))
+
+
+def test_consumed_device_inputs(hal):
+    """on_device = 2: the prover transforms the caller's buffers in place (what rk_prove_session does
+    with its staged uploads); the seal is the same, the buffers no longer hold the trace"""
+    seg = synthetic_segment(12, (4, 4, 24), seed=4711)
+    want = hal.prove_segment(seg)
+    groups = [hal.copy_from_elem(g) for g in seg.groups]
+    check = hal.copy_from_elem(seg.check)
+    got = hal.prove_segment(seg, device_inputs=(groups, check), consume_inputs=True)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(groups[2].to_host().reshape(seg.groups[2].shape), seg.groups[2])
+    seg.po2 = seg.po2  # the segment object itself is untouched
+    bad = hal._lib.rk_prove_segment
+    from raiko_amd.hal import make_c_segment
+    import ctypes as C
+    c, keep = make_c_segment(seg, (groups, check))
+    c.on_device = 3
+    words = C.c_size_t(0)
+    assert bad(hal._ctx, C.byref(c), None, 0, C.byref(words)) == -1
