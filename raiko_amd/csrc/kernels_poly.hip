@@ -113,16 +113,29 @@ __global__ void bit_reverse_ext_kernel(uint32_t* io, size_t total, size_t size, 
 
 // partial[e][blk] = sum over this block's slice of coeffs[which[e]][k] * pw[sel[e]][k]
 constexpr int DOT_BLOCKS = 64;
-__global__ __launch_bounds__(TPB) void eval_dot_kernel(uint32_t* partial, const uint32_t* coeffs, size_t size,
-                                                       const uint32_t* which, const uint32_t* pw,
-                                                       const uint32_t* sel) {
+__global__ __launch_bounds__(TPB) void eval_dot_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
+                                                       size_t size, const uint32_t* __restrict__ which,
+                                                       const uint32_t* __restrict__ pw, const uint32_t* __restrict__ sel) {
     __shared__ uint32_t red[TPB * 4];
     size_t e = blockIdx.y;
     const uint32_t* c = coeffs + (size_t)which[e] * size;
     const uint32_t* p = pw + (size_t)sel[e] * size * 4;
     Ext acc = bb::ext_zero();
-    for (size_t k = (size_t)blockIdx.x * TPB + threadIdx.x; k < size; k += (size_t)DOT_BLOCKS * TPB)
-        acc = bb::add(acc, bb::scale(load_ext(p + k * 4), c[k]));
+    // four independent (coefficient, table element) loads in flight per lane
+    constexpr size_t STEP = (size_t)DOT_BLOCKS * TPB;
+    size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
+    for (; k + 3 * STEP < size; k += 4 * STEP) {
+        uint32_t v[4];
+        Ext t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            v[u] = c[k + u * STEP];
+            t[u] = load_ext(p + (k + u * STEP) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = bb::add(acc, bb::scale(t[u], v[u]));
+    }
+    for (; k < size; k += STEP) acc = bb::add(acc, bb::scale(load_ext(p + k * 4), c[k]));
 #pragma unroll
     for (int j = 0; j < 4; j++) red[threadIdx.x * 4 + j] = acc.c[j];
     __syncthreads();
@@ -145,9 +158,14 @@ __global__ void eval_reduce_kernel(uint32_t* out, const uint32_t* partial, size_
     out[i] = acc;
 }
 
-// one grid.y slot per distinct combo: out[combo][idx] += sum_t pows[t] * in[cols[t]][idx]
-__global__ void mix_kernel(uint32_t* out, const uint32_t* in, size_t count, const uint32_t* slot_combo,
-                           const uint32_t* slot_off, const uint32_t* cols, const uint32_t* pows) {
+// one grid.y slot per distinct combo: out[combo][idx] += sum_t pows[t] * in[cols[t]][idx].
+// A slot can hold a couple of hundred columns (every register read at the current row only); the
+// loads of eight of them are issued together so that a lane keeps eight coefficient loads in
+// flight instead of one.
+__global__ void mix_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t count,
+                           const uint32_t* __restrict__ slot_combo, const uint32_t* __restrict__ slot_off,
+                           const uint32_t* __restrict__ cols, const uint32_t* __restrict__ pows) {
+    constexpr unsigned U = 8;
     unsigned slot = blockIdx.y;
     size_t combo = slot_combo[slot];
     unsigned t0 = slot_off[slot], t1 = slot_off[slot + 1];
@@ -155,7 +173,15 @@ __global__ void mix_kernel(uint32_t* out, const uint32_t* in, size_t count, cons
     for (; idx < count; idx += st) {
         uint32_t* o = out + (combo * count + idx) * 4;
         Ext acc = load_ext(o);
-        for (unsigned t = t0; t < t1; t++) {
+        unsigned t = t0;
+        for (; t + U <= t1; t += U) {
+            uint32_t v[U];
+#pragma unroll
+            for (unsigned u = 0; u < U; u++) v[u] = in[(size_t)cols[t + u] * count + idx];
+#pragma unroll
+            for (unsigned u = 0; u < U; u++) acc = bb::add(acc, bb::scale(load_ext(pows + (size_t)(t + u) * 4), v[u]));
+        }
+        for (; t < t1; t++) {
             Ext pw = load_ext(pows + (size_t)t * 4);
             acc = bb::add(acc, bb::scale(pw, in[(size_t)cols[t] * count + idx]));
         }
