@@ -102,6 +102,14 @@ class HipHal:
     def sync(self):
         self._ck(self._lib.rk_sync(self._ctx))
 
+    def set_poseidon2_params(self, rc_ext: np.ndarray, rc_int: np.ndarray, diag: np.ndarray):
+        """Replace the Poseidon2 instance of this context: 192 external and 21 internal round
+        constants and the 24 internal-diagonal entries, Montgomery form (rk_set_poseidon2_params)."""
+        a = [np.ascontiguousarray(x, dtype=np.uint32).reshape(-1) for x in (rc_ext, rc_int, diag)]
+        if [x.size for x in a] != [192, 21, 24]:
+            raise ValueError("expected 192 + 21 + 24 constants")
+        self._ck(self._lib.rk_set_poseidon2_params(self._ctx, _u32p(a[0]), _u32p(a[1]), _u32p(a[2])))
+
     # ---- Hal operators ----
     def batch_interpolate_ntt(self, io, count: int, size: Optional[int] = None):
         size = size if size is not None else io.size() // count

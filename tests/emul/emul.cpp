@@ -189,6 +189,15 @@ void emul_poseidon2_permute(uint32_t* cells) {
     p2::Consts k = consts();
     p2::permute(cells, k);
 }
+// the same permutation with caller-supplied constants (Montgomery form): rk_set_poseidon2_params' path
+void emul_poseidon2_permute_with(uint32_t* cells, const uint32_t* rc_ext, const uint32_t* rc_int, const uint32_t* diag) {
+    static p2::Consts k;  // ~12 KiB
+    std::memcpy(k.rc_ext, rc_ext, sizeof k.rc_ext);
+    std::memcpy(k.rc_int, rc_int, sizeof k.rc_int);
+    std::memcpy(k.diag, diag, sizeof k.diag);
+    p2::derive(k);
+    p2::permute(cells, k);
+}
 uint32_t emul_mul(uint32_t a, uint32_t b) { return bb::mul(a, b); }
 uint32_t emul_add(uint32_t a, uint32_t b) { return bb::add(a, b); }
 uint32_t emul_sub(uint32_t a, uint32_t b) { return bb::sub(a, b); }

@@ -106,6 +106,8 @@ def emul():
         lib.emul_ntt_forward.argtypes = [vp, vp, sz, sz, C.c_uint, C.c_uint, C.c_uint]
         lib.emul_poseidon2_permute.restype = None
         lib.emul_poseidon2_permute.argtypes = [vp]
+        lib.emul_poseidon2_permute_with.restype = None
+        lib.emul_poseidon2_permute_with.argtypes = [vp, vp, vp, vp]
         for n in ("emul_mul", "emul_add", "emul_sub"):
             getattr(lib, n).restype = u32
             getattr(lib, n).argtypes = [u32, u32]

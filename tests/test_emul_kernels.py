@@ -128,3 +128,51 @@ def test_field_and_poseidon2_host_code(orc, emu):
         orc.or_fp4_inv(a.ctypes.data_as(o.u32p), r1.ctypes.data_as(o.u32p))
         emu.emul_ext_inv(a.ctypes.data, r2.ctypes.data)
         assert np.array_equal(r1, r2)
+
+
+def _py_permute(s, ext, internal, diag):
+    """Poseidon2 (t = 24, x^7, 4 + 21 + 4 rounds) with explicit matrices, any constants, plain integers"""
+    P = o.P
+    M4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
+
+    def m_ext(v):
+        out = [0] * 24
+        for bi in range(6):
+            for bj in range(6):
+                mult = 2 if bi == bj else 1
+                for i in range(4):
+                    for j in range(4):
+                        out[4 * bi + i] += mult * M4[i][j] * v[4 * bj + j]
+        return [x % P for x in out]
+
+    s = m_ext(s)
+    for r in range(4):
+        s = m_ext([pow((s[i] + ext[r * 24 + i]) % P, 7, P) for i in range(24)])
+    for r in range(21):
+        s[0] = pow((s[0] + internal[r]) % P, 7, P)
+        tot = sum(s)
+        s = [(tot + diag[i] * s[i]) % P for i in range(24)]
+    for r in range(4, 8):
+        s = m_ext([pow((s[i] + ext[r * 24 + i]) % P, 7, P) for i in range(24)])
+    return s
+
+
+def test_poseidon2_with_other_constants(emu):
+    """rk_set_poseidon2_params path: every derived table (scaled round constants, the constant stream of
+    the closed-form partial rounds, the block scale factors) must follow arbitrary constants, including
+    extreme ones"""
+    rng = np.random.default_rng(77)
+    P = o.P
+    for case in range(4):
+        if case == 0:
+            ext, internal, diag = [P - 1] * 192, [P - 1] * 21, [P - 1] * 24
+        elif case == 1:
+            ext, internal, diag = [0] * 192, [0] * 21, [0] * 24
+        else:
+            ext, internal, diag = ([int(x) for x in rng.integers(0, P, n)] for n in (192, 21, 24))
+        m = [o.to_mont(np.array(x, dtype=np.uint64)) for x in (ext, internal, diag)]
+        for _ in range(3):
+            c = [int(x) for x in rng.integers(0, P, 24)]
+            st = o.to_mont(np.array(c, dtype=np.uint64))
+            emu.emul_poseidon2_permute_with(st.ctypes.data, m[0].ctypes.data, m[1].ctypes.data, m[2].ctypes.data)
+            assert [int(x) for x in o.from_mont(st)] == _py_permute(c, ext, internal, diag)

@@ -199,3 +199,33 @@ def test_invalid_arguments_return_errors(hal):
         hal.batch_interpolate_ntt(buf, 1, size=12)  # not a power of two
     with pytest.raises(RkError):
         hal.hash_fold(buf, 5, 2)  # input_size != 2*output_size
+
+
+def test_hash_rows_with_other_poseidon2_constants():
+    """rk_set_poseidon2_params on a context of its own: the device kernels must follow the new instance
+    (round constants, diagonal -> the scalar-register constant stream), checked against a pure-Python
+    sponge; the session-wide context keeps the default instance"""
+    from raiko_amd.hal import HipHal
+    from test_emul_kernels import _py_permute
+    rng = np.random.default_rng(123)
+    ext, internal, diag = ([int(x) for x in rng.integers(0, P, n)] for n in (192, 21, 24))
+    h = HipHal(0)
+    try:
+        h.set_poseidon2_params(*[o.to_mont(np.array(x, dtype=np.uint64)) for x in (ext, internal, diag)])
+        rows, cols = 70, 40
+        plain = rng.integers(0, P, (cols, rows), dtype=np.uint64)
+        mat = h.copy_from_elem(o.to_mont(plain).reshape(cols, rows))
+        out = h.alloc_elem(rows * 8)
+        h.hash_rows(out, mat, rows, cols)
+        got = o.from_mont(out.to_host()).reshape(rows, 8)
+        for r in (0, 1, 33, 69):
+            st = [0] * 24
+            vals = [int(plain[c, r]) for c in range(cols)]
+            for blk in range(0, cols, 16):
+                chunk = vals[blk:blk + 16]
+                for i in range(16):
+                    st[i] = chunk[i] if i < len(chunk) else 0
+                st = _py_permute(st, ext, internal, diag)
+            assert [int(x) for x in got[r]] == st[:8], r
+    finally:
+        h.close()

@@ -193,3 +193,32 @@ def test_consumed_device_inputs(hal):
     c.on_device = 3
     words = C.c_size_t(0)
     assert bad(hal._ctx, C.byref(c), None, 0, C.byref(words)) == -1
+
+
+def test_native_session_capacity_error_names_the_segment(hal):
+    """a seal buffer that is too small: RK_ERR_CAPACITY with the index of that segment, other seals intact"""
+    import ctypes as C
+    from raiko_amd import _lib
+    from raiko_amd.hal import make_c_segment, _u32p
+    lib = _lib.load()
+    segs = [synthetic_segment(8, (2, 2, 4), seed=800 + i) for i in range(4)]
+    n = len(segs)
+    c_segs = (_lib.RkSegment * n)()
+    keep = []
+    for i, s in enumerate(segs):
+        c, k = make_c_segment(s)
+        C.memmove(C.byref(c_segs[i]), C.byref(c), C.sizeof(_lib.RkSegment))
+        keep.append((c, k))
+    caps = (C.c_size_t * n)()
+    words = (C.c_size_t * n)()
+    ptrs = (_lib.u32p * n)()
+    bufs = []
+    for i in range(n):
+        caps[i] = 16 if i == 2 else int(lib.rk_seal_bound_words(C.byref(c_segs[i])))
+        bufs.append(np.zeros(caps[i], dtype=np.uint32))
+        ptrs[i] = _u32p(bufs[i])
+    opts = _lib.RkSessionOpts(device=0, inflight=1, upload_ahead=1, verify=1)
+    failed = C.c_size_t(0)
+    st = lib.rk_prove_session(C.byref(opts), c_segs, n, ptrs, caps, words, C.byref(failed))
+    assert st == -5 and failed.value == 2
+    assert np.array_equal(bufs[0][: words[0]], hal.prove_segment(segs[0]))
