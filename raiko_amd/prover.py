@@ -101,6 +101,26 @@ class Risc0Param:
         return out
 
 
+def encode_journal_b256(h: bytes) -> bytes:
+    """The journal the guest commits (`env::commit(&hash)`, provers/risc0/guest/src/main.rs:28) as the
+    reference decodes it (`receipt.journal.decode::<B256>()`, bonsai.rs:157): risc0's word serde writes
+    a `[u8; 32]` as 32 little-endian u32 words, one byte each (recalled from risc0-zkvm 1.0.1, whose
+    source is not in the reference tree) -- 128 bytes."""
+    if len(h) != 32:
+        raise ValueError("B256 is 32 bytes")
+    return b"".join(struct.pack("<I", b) for b in h)
+
+
+def decode_journal_b256(journal: bytes) -> Optional[bytes]:
+    """inverse of encode_journal_b256; None if the bytes are not a word-serialised B256"""
+    if len(journal) != 128:
+        return None
+    words = struct.unpack("<32I", journal)
+    if any(w > 0xFF for w in words):
+        return None
+    return bytes(words)
+
+
 @dataclass
 class Session:
     """What `ExecutorImpl::run()` returns (bonsai.rs:267-269): the executed segments and the journal."""
@@ -242,8 +262,10 @@ class HipProver:
             receipt = prove_locally(param.execution_po2, session, device=device, inflight=inflight)
             if receipt.seals:
                 save_receipt(label, receipt)
-        # bonsai.rs:157-162: a journal mismatch is logged, not fatal
-        HipProver.last_journal_matches = receipt.journal == expected
+        # bonsai.rs:157-162: the journal is decoded and compared with the expected output; a mismatch
+        # is logged, not fatal.  (A session whose journal is not word-serialised is compared raw.)
+        decoded = decode_journal_b256(receipt.journal)
+        HipProver.last_journal_matches = (decoded if decoded is not None else receipt.journal) == expected
         return Proof(proof=receipt.journal.hex(), quote=None, kzg_proof=None)
 
     last_journal_matches = None

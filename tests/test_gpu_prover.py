@@ -94,17 +94,18 @@ def test_hip_prover_run_end_to_end(hal):
     import types
     from raiko_amd import prover as pv
     segs = [synthetic_segment(10, (4, 4, 12), seed=s) for s in (1, 2, 3, 4, 5)]
-    journal = bytes(range(32))
+    block_hash = bytes(range(32))
+    journal = pv.encode_journal_b256(block_hash)  # what the guest commits (guest/src/main.rs:28)
     sess = pv.Session(segments=segs, journal=journal, image_id=b"\x07" * 32)
     inp = types.SimpleNamespace(session=sess, chain_spec=types.SimpleNamespace(chain_id=167009))
-    out = types.SimpleNamespace(hash=journal)
+    out = types.SimpleNamespace(hash=block_hash)
     cfg = {"proof_type": "risc0", "risc0": {"bonsai": False, "snark": False, "profile": True, "execution_po2": 18},
            "hip": {"device": 0, "inflight": 2}}
     proof = pv.HipProver.run(inp, out, cfg)
     assert proof.to_json() == {"proof": journal.hex(), "quote": None, "kzg_proof": None}
     assert pv.HipProver.last_journal_matches is True
     import hashlib
-    rec = pv.load_receipt(sess.image_id.hex() + "-" + hashlib.sha3_256(journal).hexdigest())
+    rec = pv.load_receipt(sess.image_id.hex() + "-" + hashlib.sha3_256(block_hash).hexdigest())
     assert rec is not None and len(rec.seals) == 5
     for s, seal in zip(segs, rec.seals):
         assert np.array_equal(seal, o.oracle_prove(s))

@@ -191,3 +191,14 @@ def test_pipeline_upload_error_surfaces():
     pipe.upload_ahead, pipe._uploader = 1, _FakeUploader(fail_at=3)
     with pytest.raises(RuntimeError, match="upload failed"):
         pipe.prove(segs)
+
+
+def test_journal_word_serde_roundtrip():
+    h = bytes(range(200, 232))
+    j = pv.encode_journal_b256(h)
+    assert len(j) == 128 and j[:8] == bytes([200, 0, 0, 0, 201, 0, 0, 0])
+    assert pv.decode_journal_b256(j) == h
+    assert pv.decode_journal_b256(j[:-1]) is None
+    assert pv.decode_journal_b256(b"\x00\x01\x00\x00" * 32) is None  # a word above 0xff is not a byte
+    with pytest.raises(ValueError):
+        pv.encode_journal_b256(b"short")
