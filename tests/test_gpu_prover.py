@@ -223,3 +223,17 @@ def test_native_session_capacity_error_names_the_segment(hal):
     st = lib.rk_prove_session(C.byref(opts), c_segs, n, ptrs, caps, words, C.byref(failed))
     assert st == -5 and failed.value == 2
     assert np.array_equal(bufs[0][: words[0]], hal.prove_segment(segs[0]))
+
+
+@pytest.mark.parametrize("po2", [2, 3])
+@pytest.mark.parametrize("widths", [(1, 1, 1), (16, 16, 17)])
+def test_tiny_segments(hal, po2, widths):
+    """four- and eight-row segments (every tile, scan and tree degenerates): still the oracle's seal;
+    two rows cannot hold the tap set's two-rows-back reads and are refused by both"""
+    from raiko_amd._lib import RkError
+    seg = synthetic_segment(po2, widths, seed=10 * po2 + widths[2])
+    got = hal.prove_segment(seg)
+    assert np.array_equal(got, o.oracle_prove(seg))
+    assert o.oracle_verify(seg, got) == 0
+    with pytest.raises(RkError):
+        hal.prove_segment(synthetic_segment(1, widths, seed=1))
