@@ -12,7 +12,9 @@
  * Rules of the ABI: plain pointers and sizes only; every function returns
  * RK_OK (0) or a negative rk_status and never aborts; `d_` pointers are device
  * memory of the ctx's GPU; work is asynchronous on the ctx stream unless the
- * function returns data to the host (those synchronise the stream).
+ * function returns data to the host (those synchronise the stream).  A ctx is
+ * used by one thread at a time; different ctxs, also of one GPU, run concurrently
+ * (rk_prove_session does exactly that).
  * All field elements are BabyBear Montgomery residues (u32 < p = 15*2^27+1);
  * extension elements are 4 consecutive u32; digests are 8 consecutive u32.
  * Matrices are column-major: element (row r, column c) at c*rows + r.
