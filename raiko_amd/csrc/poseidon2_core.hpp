@@ -185,19 +185,26 @@ RK_HD void m_ext_redc(uint32_t* s) {
 }
 
 // The same layer on signed-lazy cells |y| < p (S-box outputs), exact in int64 (|w| < 112 p), then
-// r[i] = w[i] * 2^-32 (mod p) as a signed value, |r| <= p/2 + 53.  Sums like a + b do not fit 32
-// bits here, so every term is its own mad: 14 per four cells instead of 10 + 2 additions, which
-// is less than the two instructions per cell a canonicalisation of the inputs would cost.
+// r[i] = w[i] * 2^-32 (mod p) as a signed value, |r| <= p/2 + 53.  M4 follows the Poseidon2 paper's
+// add / double schedule: the first two sums and the two doublings take the 32-bit cells through
+// v_mad_i64_i32 (sums like a + b do not fit 32 bits here), the rest are 64-bit shift-adds
+// (v_lshl_add_u64) -- ten instructions per four cells, against two per CELL for a canonicalisation
+// that would let the unsigned form above be used.
 RK_HD void m_ext_redc_s(const int32_t* y, int32_t* r) {
     int64_t w[CELLS];
 #pragma unroll
     for (int i = 0; i < CELLS; i += 4) {
         int32_t a = y[i], b = y[i + 1], c = y[i + 2], d = y[i + 3];
-        int64_t u1 = smadk<1>(d, smadk<1>(c, smadk<6>(b, smulk<4>(a))));  // 4a + 6b +  c +  d
-        int64_t u0 = smadk<2>(d, smadk<1>(b, smadk<1>(a, u1)));           // 5a + 7b +  c + 3d
-        int64_t u3 = smadk<1>(b, smadk<1>(a, smadk<6>(d, smulk<4>(c))));  //  a +  b + 4c + 6d
-        int64_t u2 = smadk<2>(b, smadk<1>(d, smadk<1>(c, u3)));           //  a + 3b + 5c + 7d
-        w[i] = u0; w[i + 1] = u1; w[i + 2] = u2; w[i + 3] = u3;
+        int64_t t0 = smadk<1>(b, smulk<1>(a));  //  a +  b
+        int64_t t1 = smadk<1>(d, smulk<1>(c));  //  c +  d
+        int64_t t2 = smadk<2>(b, t1);           // 2b +  c +  d
+        int64_t t3 = smadk<2>(d, t0);           //  a +  b + 2d
+        int64_t t4 = (t1 << 2) + t3;            //  a +  b + 4c + 6d
+        int64_t t5 = (t0 << 2) + t2;            // 4a + 6b +  c +  d
+        w[i] = t3 + t5;                         // 5a + 7b +  c + 3d
+        w[i + 1] = t5;
+        w[i + 2] = t2 + t4;                     //  a + 3b + 5c + 7d
+        w[i + 3] = t4;
     }
     int64_t t[4];
 #pragma unroll
