@@ -7,7 +7,7 @@ the last levels of every Merkle tree are single-workgroup kernels, so a lone pro
 MI355X partly idle.  Segments are independent, so this module keeps `inflight` prover contexts on
 the GPU -- each with its own HIP stream, scratch pool and host thread -- and hands them segments
 from a shared queue: the latency-bound parts of one proof overlap the throughput-bound parts of
-the others (33.5 ms -> 26 ms per 2^20-cycle segment at three in flight).
+the others (32 ms -> 25 ms per 2^20-cycle segment at three in flight).
 A context holds ~7 GiB of HBM at that size; 288 GB leaves room for far more than pays off.
 
 Host-resident traces (what an executor hands over: `Segment.groups` as numpy arrays) are uploaded
