@@ -36,7 +36,8 @@ typedef enum {
     RK_ERR_NODEVICE = -4,
     RK_ERR_CAPACITY = -5,  /* caller-provided output buffer too small */
     RK_ERR_INTERNAL = -6,  /* a prover invariant failed (non-zero remainder in the DEEP division) */
-    RK_ERR_VERIFY = -7     /* rk_prove_session: a produced seal did not pass rk_verify_segment */
+    RK_ERR_VERIFY = -7,    /* rk_prove_session: a produced seal did not pass rk_verify_segment */
+    RK_ERR_CALLBACK = -8   /* a circuit hook (rk_circuit_hooks) returned non-zero */
 } rk_status;
 
 typedef struct rk_ctx rk_ctx;
@@ -94,6 +95,16 @@ int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_c
 /* Hal::gather_sample: dst[g] = src[g*stride + idx], g < size. */
 int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
 
+/* Hal::prefix_products: in-place inclusive running product of `count` extension elements
+ * (io[i] = io[0] * ... * io[i]); the grand-product accumulator of the accum group. */
+int rk_prefix_products(rk_ctx* ctx, uint32_t* d_io_ext, size_t count);
+/* Hal::scatter: for cycle c < n_cycles and k in [h_index[c], h_index[c+1]):
+ * d_into[h_offsets[k]] = h_values[k] (witness-generation helper; index has n_cycles + 1 entries,
+ * the host arrays are copied before the call returns; a later entry wins over an earlier one
+ * with the same offset).  Offsets >= into_words are rejected with RK_ERR_INVALID. */
+int rk_scatter(rk_ctx* ctx, uint32_t* d_into, size_t into_words, const uint32_t* h_index, size_t n_cycles,
+               const uint32_t* h_offsets, const uint32_t* h_values);
+
 /* ---- fused building blocks (no single Hal counterpart) ---- */
 /* MerkleTreeProver::new (risc0-zkp prove/merkle.rs): hash_rows + every hash_fold level into
  * d_nodes (2*rows digests, heap order, root at index 1). */
@@ -114,6 +125,39 @@ typedef struct {
     const uint32_t* combo_backs;
 } rk_taps;
 
+/* ---- circuit hooks: the two places where a segment proof depends on Fiat-Shamir randomness that
+ * exists only after earlier groups are committed (risc0-circuit-rv32im 1.0.1 prove/mod.rs
+ * prove_segment + risc0-zkp prove/prover.rs finalize; CircuitHal::accumulate / eval_check) ----
+ *   1. after code and data are committed the prover draws n_accum_mix field elements and calls
+ *      `accumulate`, which fills the accum group from them and the witness;
+ *   2. after accum is committed it draws poly_mix and calls `eval_check`, which evaluates the
+ *      circuit's mixed constraint polynomial over the 4N-point LDE domain.
+ * Hooks run on the thread that called rk_prove_segment (a prover thread of rk_prove_session),
+ * may call rk_* operators on view->ctx, must enqueue their device work on view->stream and must
+ * not synchronise other streams; they return 0 or non-zero (-> RK_ERR_CALLBACK). */
+typedef struct {
+    rk_ctx* ctx;
+    void* stream;                  /* hipStream_t of ctx */
+    uint32_t po2;
+    uint32_t group_size[3];        /* 0 accum, 1 code, 2 data */
+    const uint32_t* d_trace[3];    /* device, column-major 2^po2 x group_size[g]: the witness as handed in
+                                    * ([1], [2]; valid in `accumulate` only, NULL otherwise) */
+    const uint32_t* d_lde[3];      /* device, column-major 4*2^po2 x group_size[g]: evaluations on the coset
+                                    * 3*w^i, natural order (PolyGroup::evaluated); NULL until committed */
+    const uint32_t* globals;       /* host */
+    uint32_t n_globals;
+    const uint32_t* mix;           /* host: the n_accum_mix elements drawn before the accum commit */
+    uint32_t n_mix;
+} rk_circuit_view;
+typedef struct {
+    void* user;
+    /* CircuitHal::accumulate: write the accum group, column-major 2^po2 x group_size[0], to d_accum */
+    int (*accumulate)(void* user, const rk_circuit_view* view, uint32_t* d_accum);
+    /* CircuitHal::eval_check: write 4 x 4*2^po2 values (component e of point i at e*4*2^po2 + i):
+     * sum_k poly_mix^k * constraint_k at x_i = 3*w^i, divided by (x_i^(2^po2) - 1) */
+    int (*eval_check)(void* user, const rk_circuit_view* view, const uint32_t poly_mix[4], uint32_t* d_check);
+} rk_circuit_hooks;
+
 typedef struct {
     uint32_t po2;                  /* segment has 2^po2 rows */
     uint32_t on_device;            /* 0: group[] and check are host pointers; 1: device pointers, left untouched
@@ -126,6 +170,9 @@ typedef struct {
     uint32_t n_accum_mix;          /* Fiat-Shamir elements drawn before the accum group is committed */
     uint8_t proof_system_info[16];
     uint8_t circuit_info[16];
+    const rk_circuit_hooks* hooks; /* NULL: group[0] and check are taken as given (pre-computed stand-ins).
+                                    * A non-NULL `accumulate` replaces group[0], a non-NULL `eval_check`
+                                    * replaces check (the replaced pointer is ignored and may be NULL) */
 } rk_segment;
 
 /* Produces the seal (the u32 Fiat-Shamir transcript) of one segment. */
@@ -138,6 +185,24 @@ int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_
  * malformed arguments, a positive reason code otherwise (see verify.hip).  The circuit's
  * constraint identity is NOT checked (no rv32im circuit in this repo). */
 int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_words);
+/* The same with options.  p2_*: the Poseidon2 instance the seal was produced under (all three or
+ * none; none = the compiled-in defaults, which is what rk_verify_segment assumes).  poly_ext:
+ * CircuitDef::poly_ext -- the circuit's mixed constraint polynomial on the tap openings; when
+ * given, the verifier also checks the constraint identity
+ *     poly_ext(poly_mix, eval_u, globals, mix) == check(z) * ((3z)^(2^po2) - 1)
+ * (reason code 70 on mismatch).  eval_u holds one extension element per tap, registers in
+ * (group, offset) order, each register's backs in combo order: the value of the register's
+ * polynomial at 3*z*w^-back. */
+typedef int (*rk_poly_ext_fn)(void* user, const rk_segment* pub, const uint32_t poly_mix[4], const uint32_t* eval_u_ext,
+                              size_t n_taps, const uint32_t* mix, uint32_t n_mix, uint32_t out_ext[4]);
+typedef struct {
+    const uint32_t* p2_rc_ext;     /* 192 */
+    const uint32_t* p2_rc_int;     /* 21 */
+    const uint32_t* p2_diag;       /* 24 */
+    rk_poly_ext_fn poly_ext;
+    void* user;
+} rk_verify_opts;
+int rk_verify_segment_ex(const rk_segment* pub, const rk_verify_opts* opts, const uint32_t* seal, size_t seal_words);
 /* Upper bound on the seal size for a given shape. */
 size_t rk_seal_bound_words(const rk_segment* seg);
 
@@ -155,10 +220,16 @@ size_t rk_seal_bound_words(const rk_segment* seg);
  * `Prover` has no `self`: lib/src/prover.rs:52-62); concurrent calls for one device are
  * serialised.  rk_session_release frees them. */
 typedef struct {
-    int device;
-    int inflight;      /* 1..16; 3 is where an MI355X saturates at 2^20-cycle segments */
-    int upload_ahead;  /* 0..16 staged segments waiting for a prover; 2 hides a 20 ms upload */
+    int device;        /* the GPU, when n_devices == 0 */
+    int inflight;      /* per GPU, 1..16; 3 is where an MI355X saturates at 2^20-cycle segments */
+    int upload_ahead;  /* per GPU, 0..16 staged segments waiting for a prover; 2 hides a 20 ms upload */
     int verify;
+    const int* devices; /* optional list of distinct GPUs of this node: every GPU's prover contexts take
+                         * segments from ONE shared index (a work queue: a short last segment or a slower
+                         * GPU does not stall the others), seals land in the caller's host buffers, so a
+                         * single-process host needs no collective */
+    int n_devices;      /* 0: use `device` */
+    const rk_verify_opts* verify_opts; /* optional, for verify != 0 */
 } rk_session_opts;
 int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n, uint32_t* const* h_seals,
                      const size_t* seal_capacity_words, size_t* seal_words, size_t* failed_index);
@@ -166,7 +237,7 @@ const char* rk_session_last_error(int device);
 int rk_session_release(void);
 
 /* per-stage device time of the last rk_prove_segment on this ctx, milliseconds (hipEvent) */
-typedef struct { float ntt, hash, deep, fri, query, total; } rk_timing;
+typedef struct { float ntt, hash, deep, fri, query, total, circuit /* time inside rk_circuit_hooks */; } rk_timing;
 int rk_last_timing(rk_ctx* ctx, rk_timing* out);
 
 /* ---- per-kernel-class timing (for bench.py's roofline object) ----
@@ -185,6 +256,10 @@ typedef struct { uint64_t launches; double ms; double bytes; } rk_kernel_stat;
 int rk_set_kernel_timing(rk_ctx* ctx, int enabled);   /* also resets the counters */
 int rk_kernel_stats(rk_ctx* ctx, int kclass, rk_kernel_stat* out);
 const char* rk_kernel_class_name(int kclass);
+/* the same for the prover contexts rk_prove_session keeps for `device`: enable / reset, then the
+ * totals over all of them (what bench.py reads after timing the drop-in entry point) */
+int rk_session_set_kernel_timing(int device, int enabled);
+int rk_session_kernel_stats(int device, int kclass, rk_kernel_stat* out);
 
 #ifdef __cplusplus
 }

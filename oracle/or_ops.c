@@ -10,6 +10,18 @@
 #include <omp.h>
 #endif
 
+/* or_fast.c: the optimised forms used for the timed CPU baseline (bit-identical results) */
+extern int g_or_fast;
+void or_fast_hash_rows(uint32_t* out, const fp* matrix, size_t rows, size_t cols);
+void or_fast_hash_fold(uint32_t* nodes, size_t output_size);
+void or_fast_batch_interpolate_ntt(fp* io, size_t size, size_t count);
+void or_fast_batch_expand_into_evaluate_ntt(fp* out, const fp* in, size_t in_size, size_t count, unsigned expand_bits);
+void or_fast_zk_shift(fp* io, size_t size, size_t count);
+void or_fast_batch_evaluate_any(const fp* coeffs, size_t size, const uint32_t* which, const fp4* xs, size_t eval_count,
+                                fp4* out);
+void or_fast_mix_poly_coeffs(fp4* out, const uint32_t* mix_start, const uint32_t* mix, const fp* in,
+                             const uint32_t* combos, size_t input_size, size_t count);
+
 /* ------------------------------------------------------------------ roots */
 static fp g_rou_fwd[28], g_rou_rev[28];
 static int g_rou_ready = 0;
@@ -181,6 +193,7 @@ void or_hash_pair(const uint32_t* a, const uint32_t* b, uint32_t* out) {
 /* --------------------------------------------------------------- hal/cpu.rs */
 void or_batch_interpolate_ntt(fp* io, size_t size, size_t count) {
     rou_init();
+    if (g_or_fast) { or_fast_batch_interpolate_ntt(io, size, count); return; }
 #pragma omp parallel for schedule(dynamic)
     for (size_t c = 0; c < count; c++) or_interpolate_ntt(io + c * size, size);
 }
@@ -190,6 +203,7 @@ void or_batch_evaluate_ntt(fp* io, size_t size, size_t count, unsigned expand_bi
     for (size_t c = 0; c < count; c++) or_evaluate_ntt(io + c * size, size, expand_bits);
 }
 void or_zk_shift(fp* io, size_t size, size_t count) {
+    if (g_or_fast) { or_fast_zk_shift(io, size, count); return; }
     unsigned bits = log2_exact(size);
     fp three = fp_from_u32(3);
     /* 3^rev(pos): table of 3^(2^j) */
@@ -207,6 +221,7 @@ void or_zk_shift(fp* io, size_t size, size_t count) {
 }
 void or_batch_expand_into_evaluate_ntt(fp* out, const fp* in, size_t in_size, size_t count, unsigned expand_bits) {
     rou_init();
+    if (g_or_fast) { or_fast_batch_expand_into_evaluate_ntt(out, in, in_size, count, expand_bits); return; }
     size_t out_size = in_size << expand_bits;
 #pragma omp parallel for schedule(dynamic)
     for (size_t c = 0; c < count; c++) {
@@ -221,11 +236,13 @@ void or_batch_bit_reverse(fp* io, size_t size, size_t count) {
     for (size_t c = 0; c < count; c++) or_bit_reverse(io + c * size, size);
 }
 void or_hash_rows(uint32_t* out, const fp* matrix, size_t rows, size_t cols) {
+    if (g_or_fast) { or_fast_hash_rows(out, matrix, rows, cols); return; }
 #pragma omp parallel for schedule(static)
     for (size_t r = 0; r < rows; r++) or_hash_elem_slice(matrix + r, cols, rows, out + r * OR_DIGEST_WORDS);
 }
 void or_hash_fold(uint32_t* nodes, size_t input_size, size_t output_size) {
     (void)input_size; /* == 2*output_size; heap layout: children of i are 2i, 2i+1 */
+    if (g_or_fast) { or_fast_hash_fold(nodes, output_size); return; }
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < output_size; i++) {
         size_t idx = output_size + i;
@@ -235,6 +252,7 @@ void or_hash_fold(uint32_t* nodes, size_t input_size, size_t output_size) {
 }
 void or_batch_evaluate_any(const fp* coeffs, size_t size, const uint32_t* which, const fp4* xs,
                            size_t eval_count, fp4* out) {
+    if (g_or_fast) { or_fast_batch_evaluate_any(coeffs, size, which, xs, eval_count, out); return; }
 #pragma omp parallel for schedule(dynamic)
     for (size_t e = 0; e < eval_count; e++) {
         const fp* c = coeffs + (size_t)which[e] * size;
@@ -245,6 +263,7 @@ void or_batch_evaluate_any(const fp* coeffs, size_t size, const uint32_t* which,
 }
 void or_mix_poly_coeffs(fp4* out, const uint32_t* mix_start, const uint32_t* mix, const fp* in,
                         const uint32_t* combos, size_t input_size, size_t count) {
+    if (g_or_fast) { or_fast_mix_poly_coeffs(out, mix_start, mix, in, combos, input_size, count); return; }
     fp4 ms, mx; memcpy(&ms, mix_start, 16); memcpy(&mx, mix, 16);
 #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < count; idx++) {
@@ -289,6 +308,16 @@ void or_fri_fold(fp* out, const fp* in, size_t count, const uint32_t* mix) {
 }
 void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t stride) {
     for (size_t g = 0; g < size; g++) dst[g] = src[g * stride + idx];
+}
+
+/* hal/cpu.rs prefix_products: sequential running product */
+void or_prefix_products(fp4* io, size_t count) {
+    for (size_t i = 1; i < count; i++) io[i] = fp4_mul(io[i], io[i - 1]);
+}
+/* hal/cpu.rs scatter: per-cycle ranges [index[c], index[c+1]) of (offset, value) pairs, in order */
+void or_scatter(fp* into, const uint32_t* index, size_t n_cycles, const uint32_t* offsets, const fp* values) {
+    for (size_t c = 0; c < n_cycles; c++)
+        for (uint32_t k = index[c]; k < index[c + 1]; k++) into[offsets[k]] = values[k];
 }
 
 /* ------------------------------------------------------------------ poly.rs */

@@ -225,16 +225,44 @@ int or_prove_segment(const or_segment* seg, uint32_t** seal, size_t* seal_words,
     polygroup groups[3];
     commit_group(&groups[1], &iop, seg->group[1], taps->group_size[1], N); /* code */
     commit_group(&groups[2], &iop, seg->group[2], taps->group_size[2], N); /* data */
-    for (uint32_t i = 0; i < seg->n_accum_mix; i++) (void)or_iop_random_elem(&iop);
-    commit_group(&groups[0], &iop, seg->group[0], taps->group_size[0], N); /* accum */
+    /* rv32im prove_segment: the accum mix is drawn once code and data are bound */
+    fp* accum_mix = (fp*)malloc((seg->n_accum_mix + 1) * sizeof(fp));
+    for (uint32_t i = 0; i < seg->n_accum_mix; i++) accum_mix[i] = or_iop_random_elem(&iop);
+    or_circuit_view view;
+    memset(&view, 0, sizeof view);
+    view.po2 = seg->po2;
+    for (int g = 0; g < 3; g++) view.group_size[g] = taps->group_size[g];
+    view.globals = seg->globals; view.n_globals = seg->n_globals;
+    view.mix = accum_mix; view.n_mix = seg->n_accum_mix;
+    const or_circuit_hooks* hooks = seg->hooks;
+    fp* accum_buf = NULL;
+    const fp* accum_trace = seg->group[0];
+    if (hooks && hooks->accumulate) { /* CircuitHal::accumulate */
+        accum_buf = (fp*)malloc((size_t)taps->group_size[0] * N * sizeof(fp));
+        view.trace[1] = seg->group[1]; view.trace[2] = seg->group[2];
+        view.lde[1] = groups[1].evaluated; view.lde[2] = groups[2].evaluated;
+        if (hooks->accumulate(hooks->user, &view, accum_buf) != 0) { or_iop_free(&iop); return -3; }
+        accum_trace = accum_buf;
+        view.trace[1] = view.trace[2] = NULL;
+    }
+    commit_group(&groups[0], &iop, accum_trace, taps->group_size[0], N); /* accum */
+    free(accum_buf);
 
     /* finalize */
-    fp4 poly_mix = or_iop_random_ext(&iop); (void)poly_mix; /* consumed by eval_check */
+    fp4 poly_mix = or_iop_random_ext(&iop);
     double t0 = now_s();
     fp* check_poly = (fp*)malloc(OR_EXT * D * sizeof(fp));
-    or_eltwise_copy_elem(check_poly, seg->check, OR_EXT * D);
+    if (hooks && hooks->eval_check) { /* CircuitHal::eval_check over the LDE domain */
+        for (int g = 0; g < 3; g++) view.lde[g] = groups[g].evaluated;
+        if (hooks->eval_check(hooks->user, &view, poly_mix.c, check_poly) != 0) { or_iop_free(&iop); return -3; }
+    } else {
+        or_eltwise_copy_elem(check_poly, seg->check, OR_EXT * D); /* pre-computed stand-in */
+    }
+    free(accum_mix);
+    /* 4 x D evaluations at 3*w^i -> 4 x D bit-reversed coefficients = 16 columns of N (quarter c of
+     * component e = coefficients n with n mod 4 = bitrev2(c)).  No zk_shift: these already are the
+     * coefficients of y -> check(3y), the form every PolyGroup is kept in. */
     or_batch_interpolate_ntt(check_poly, D, OR_EXT);
-    or_zk_shift(check_poly, N, OR_CHECK_SIZE);
     g_timing.ntt += now_s() - t0;
     polygroup check;
     polygroup_new(&check, check_poly, OR_CHECK_SIZE, N);

@@ -1,0 +1,170 @@
+/* TEST INFRASTRUCTURE -- CPU oracle (see oracle.h header: parity unpinned).
+ *
+ * The toy circuit: a complete, small AIR that exercises the two Fiat-Shamir hand-backs of a
+ * segment proof -- CircuitHal::accumulate (accum columns from the mix drawn after code/data are
+ * committed) and CircuitHal::eval_check (constraint polynomial from poly_mix drawn after accum is
+ * committed) -- and the verifier's constraint identity (CircuitDef::poly_ext).  It stands where
+ * risc0-circuit-rv32im 1.0.1 stands behind `session.prove()` (reference
+ * provers/risc0/driver/src/bonsai.rs:271); that crate is not in the container, so this is NOT the
+ * rv32im circuit, only the same interface.  examples/toy_circuit/toy_circuit.hip is the GPU
+ * implementation this file is the independent CPU restatement of.
+ *
+ * Columns (group: code c*, data d*, accum a*; widths Wc >= 3, Wd >= 4, Wa >= 4; n_mix >= 4):
+ *   c0 = 1 on row 0, c1 = 1 on row 1, c2 = 1 on the last row, 0 elsewhere; other columns free.
+ *   A = (a0, a1, a2, a3) is one extension element, m = (mix0..mix3) too.
+ * Constraints, all rows i (cyclic: x[-k] is row i-k mod N), mixed as sum_k poly_mix^k * K_k:
+ *   K0 = (1 - c0 - c1) * (d0 - d0[-1] - d0[-2])                  Fibonacci from row 2 on
+ *   K1 = d1 - d0 * d0[-1]
+ *   K2 = A * (m + d3) - ((1 - c0) * A[-1] + c0) * (m + d2)       running product of (m+d2)/(m+d3)
+ *   K3 = c2 * (A - 1)                                            d3 is a permutation of d2
+ *   K(4+j) = a(4+j) - mix[(4+j) % n_mix] * d[(4+j) % Wd],  j < Wa - 4
+ * Taps needed: d0 at back 0,1,2; a0..a3 at back 0,1; everything else at back 0
+ * (raiko_amd.segment.synthetic_tapset provides a superset). */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static fp4 ext_of(const fp* p) { fp4 r; memcpy(&r, p, 16); return r; }
+static fp4 ext_add_fp(fp4 a, fp b) { a.c[0] = fp_add(a.c[0], b); return a; }
+
+static int toy_shape_ok(const uint32_t* gs, uint32_t n_mix) { return gs[0] >= 4 && gs[1] >= 3 && gs[2] >= 4 && n_mix >= 4; }
+
+static int toy_accumulate(void* user, const or_circuit_view* v, fp* accum) {
+    (void)user;
+    if (!toy_shape_ok(v->group_size, v->n_mix)) return 1;
+    size_t N = (size_t)1 << v->po2;
+    const fp* data = v->trace[2];
+    fp4 m = ext_of(v->mix);
+    fp4* t = (fp4*)malloc(N * sizeof(fp4));
+    for (size_t i = 0; i < N; i++) {
+        fp4 num = ext_add_fp(m, data[2 * N + i]);
+        fp4 den = ext_add_fp(m, data[3 * N + i]);
+        t[i] = fp4_mul(num, fp4_inv(den));
+    }
+    or_prefix_products(t, N);
+    for (size_t i = 0; i < N; i++)
+        for (int e = 0; e < 4; e++) accum[(size_t)e * N + i] = t[i].c[e];
+    free(t);
+    for (uint32_t k = 4; k < v->group_size[0]; k++) {
+        fp mk = v->mix[k % v->n_mix];
+        const fp* col = data + (size_t)(k % v->group_size[2]) * N;
+        for (size_t i = 0; i < N; i++) accum[(size_t)k * N + i] = fp_mul(mk, col[i]);
+    }
+    return 0;
+}
+
+/* the mixed constraint polynomial from the values of one point: shared by eval_check (values of
+ * the LDE) and poly_ext (tap openings), like risc0's generated poly_fp / poly_ext pair */
+typedef struct {
+    fp4 c0, c1, c2, d0, d0b1, d0b2, d1, d2, d3, A, Ab1;
+} toy_point;
+static fp4 toy_mix(const toy_point* p, fp4 poly_mix, fp4 m, const fp4* extra_a, const fp4* extra_d, const fp* mix,
+                   uint32_t n_mix, uint32_t wa, uint32_t wd) {
+    fp4 one = fp4_one();
+    fp4 tot = fp4_zero(), pw = fp4_one();
+    fp4 k0 = fp4_mul(fp4_sub(fp4_sub(one, p->c0), p->c1), fp4_sub(fp4_sub(p->d0, p->d0b1), p->d0b2));
+    tot = fp4_add(tot, fp4_mul(pw, k0)); pw = fp4_mul(pw, poly_mix);
+    fp4 k1 = fp4_sub(p->d1, fp4_mul(p->d0, p->d0b1));
+    tot = fp4_add(tot, fp4_mul(pw, k1)); pw = fp4_mul(pw, poly_mix);
+    fp4 prev = fp4_add(fp4_mul(fp4_sub(one, p->c0), p->Ab1), p->c0);
+    fp4 k2 = fp4_sub(fp4_mul(p->A, fp4_add(m, p->d3)), fp4_mul(prev, fp4_add(m, p->d2)));
+    tot = fp4_add(tot, fp4_mul(pw, k2)); pw = fp4_mul(pw, poly_mix);
+    fp4 k3 = fp4_mul(p->c2, fp4_sub(p->A, one));
+    tot = fp4_add(tot, fp4_mul(pw, k3)); pw = fp4_mul(pw, poly_mix);
+    for (uint32_t k = 4; k < wa; k++) {
+        fp4 kk = fp4_sub(extra_a[k - 4], fp4_scale(extra_d[k - 4], mix[k % n_mix]));
+        tot = fp4_add(tot, fp4_mul(pw, kk)); pw = fp4_mul(pw, poly_mix);
+    }
+    (void)wd;
+    return tot;
+}
+
+static int toy_eval_check(void* user, const or_circuit_view* v, const fp* poly_mix, fp* check) {
+    (void)user;
+    if (!toy_shape_ok(v->group_size, v->n_mix)) return 1;
+    size_t N = (size_t)1 << v->po2, D = N * OR_INV_RATE;
+    const fp *acc = v->lde[0], *code = v->lde[1], *data = v->lde[2];
+    uint32_t wa = v->group_size[0], wd = v->group_size[2];
+    fp4 pm = ext_of(poly_mix), m = ext_of(v->mix);
+    /* x_i^N for x_i = 3*w_D^i takes 4 values: 3^N * w_4^(i mod 4) */
+    fp inv_den[4];
+    fp three_n = fp_pow(fp_from_u32(3), N), w4 = or_rou_fwd(2);
+    for (int r = 0; r < 4; r++) inv_den[r] = fp_inv(fp_sub(fp_mul(three_n, fp_pow(w4, r)), fp_from_u32(1)));
+    int bad = 0;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < D; i++) {
+        size_t b1 = (i + D - OR_INV_RATE) % D, b2 = (i + D - 2 * OR_INV_RATE) % D;
+        toy_point p;
+        p.c0 = fp4_from_fp(code[i]); p.c1 = fp4_from_fp(code[D + i]); p.c2 = fp4_from_fp(code[2 * D + i]);
+        p.d0 = fp4_from_fp(data[i]); p.d0b1 = fp4_from_fp(data[b1]); p.d0b2 = fp4_from_fp(data[b2]);
+        p.d1 = fp4_from_fp(data[D + i]); p.d2 = fp4_from_fp(data[2 * D + i]); p.d3 = fp4_from_fp(data[3 * D + i]);
+        for (int e = 0; e < 4; e++) { p.A.c[e] = acc[(size_t)e * D + i]; p.Ab1.c[e] = acc[(size_t)e * D + b1]; }
+        fp4 ea[64], ed[64];
+        if (wa - 4 > 64) { bad = 1; continue; }
+        for (uint32_t k = 4; k < wa; k++) {
+            ea[k - 4] = fp4_from_fp(acc[(size_t)k * D + i]);
+            ed[k - 4] = fp4_from_fp(data[(size_t)(k % wd) * D + i]);
+        }
+        fp4 tot = toy_mix(&p, pm, m, ea, ed, v->mix, v->n_mix, wa, wd);
+        tot = fp4_scale(tot, inv_den[i & 3]);
+        for (int e = 0; e < 4; e++) check[(size_t)e * D + i] = tot.c[e];
+    }
+    return bad;
+}
+
+/* index of (group, offset, back) in eval_u: registers in (group, offset) order, backs in combo order */
+static long tap_index(const or_taps* t, uint32_t group, uint32_t offset, uint32_t back) {
+    size_t pos = 0;
+    for (uint32_t r = 0; r < t->n_regs; r++) {
+        uint32_t cb = t->reg_combo[r];
+        uint32_t b0 = t->combo_off[cb], b1 = t->combo_off[cb + 1];
+        if (t->reg_group[r] == group && t->reg_offset[r] == offset) {
+            for (uint32_t b = b0; b < b1; b++)
+                if (t->combo_backs[b] == back) return (long)(pos + (b - b0));
+            return -1;
+        }
+        pos += b1 - b0;
+    }
+    return -1;
+}
+
+int or_toy_poly_ext(void* user, const or_segment* pub, const fp* poly_mix, const fp4* eval_u, size_t n_taps,
+                    const fp* mix, uint32_t n_mix, fp* out) {
+    (void)user; (void)n_taps;
+    const or_taps* t = &pub->taps;
+    if (!toy_shape_ok(t->group_size, n_mix)) return 1;
+    uint32_t wa = t->group_size[0], wd = t->group_size[2];
+    if (wa - 4 > 64) return 1;
+    long ix[16];
+    ix[0] = tap_index(t, 1, 0, 0); ix[1] = tap_index(t, 1, 1, 0); ix[2] = tap_index(t, 1, 2, 0);
+    ix[3] = tap_index(t, 2, 0, 0); ix[4] = tap_index(t, 2, 0, 1); ix[5] = tap_index(t, 2, 0, 2);
+    ix[6] = tap_index(t, 2, 1, 0); ix[7] = tap_index(t, 2, 2, 0); ix[8] = tap_index(t, 2, 3, 0);
+    for (int k = 0; k < 9; k++) if (ix[k] < 0) return 2;
+    toy_point p;
+    p.c0 = eval_u[ix[0]]; p.c1 = eval_u[ix[1]]; p.c2 = eval_u[ix[2]];
+    p.d0 = eval_u[ix[3]]; p.d0b1 = eval_u[ix[4]]; p.d0b2 = eval_u[ix[5]];
+    p.d1 = eval_u[ix[6]]; p.d2 = eval_u[ix[7]]; p.d3 = eval_u[ix[8]];
+    /* A = sum_e a_e * basis_e: the opened a_e are extension elements themselves off the trace domain */
+    p.A = fp4_zero(); p.Ab1 = fp4_zero();
+    for (int e = 0; e < 4; e++) {
+        long i0 = tap_index(t, 0, (uint32_t)e, 0), i1 = tap_index(t, 0, (uint32_t)e, 1);
+        if (i0 < 0 || i1 < 0) return 2;
+        fp4 basis = fp4_zero();
+        basis.c[e] = fp_from_u32(1);
+        p.A = fp4_add(p.A, fp4_mul(eval_u[i0], basis));
+        p.Ab1 = fp4_add(p.Ab1, fp4_mul(eval_u[i1], basis));
+    }
+    fp4 ea[64], ed[64];
+    for (uint32_t k = 4; k < wa; k++) {
+        long ia = tap_index(t, 0, k, 0), id = tap_index(t, 2, k % wd, 0);
+        if (ia < 0 || id < 0) return 2;
+        ea[k - 4] = eval_u[ia];
+        ed[k - 4] = eval_u[id];
+    }
+    fp4 tot = toy_mix(&p, ext_of(poly_mix), ext_of(mix), ea, ed, mix, n_mix, wa, wd);
+    memcpy(out, &tot, 16);
+    return 0;
+}
+
+static const or_circuit_hooks g_toy_hooks = {NULL, toy_accumulate, toy_eval_check};
+const or_circuit_hooks* or_toy_hooks(void) { return &g_toy_hooks; }

@@ -1,10 +1,9 @@
 /* TEST INFRASTRUCTURE -- CPU oracle (see oracle.h header: parity unpinned).
  * Restates risc0-zkp 1.0.1 verify/{mod,fri,merkle,read_iop}.rs for the flow of
- * or_prove_segment.  The circuit's constraint identity (check polynomial vs
- * the rv32im constraint system evaluated at the tap openings) is NOT checked:
- * risc0-circuit-rv32im is absent from the container.  Everything else is:
- * transcript binding, Merkle openings, DEEP quotient consistency, FRI folds
- * and the final low-degree polynomial. */
+ * or_prove_segment: transcript binding, Merkle openings, DEEP quotient
+ * consistency, FRI folds, the final low-degree polynomial and, given the
+ * circuit's poly_ext, the constraint identity on the tap openings (the rv32im
+ * constraint system itself is absent from the container; or_toy.c is the toy one). */
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
@@ -49,6 +48,10 @@ static int mv_verify(const mverifier* m, riop* r, size_t idx, fp* out) {
 }
 
 int or_verify_segment(const or_segment* seg, const uint32_t* seal, size_t seal_words) {
+    return or_verify_segment_circuit(seg, seal, seal_words, NULL, NULL);
+}
+int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_t seal_words,
+                              or_poly_ext_fn poly_ext, void* user) {
     const or_taps* taps = &seg->taps;
     riop r; memset(&r, 0, sizeof r);
     r.p = seal; r.len = seal_words;
@@ -72,9 +75,10 @@ int or_verify_segment(const or_segment* seg, const uint32_t* seal, size_t seal_w
     mverifier mg[3], mcheck;
     mv_new(&mg[1], &r, D, taps->group_size[1], OR_QUERIES);
     mv_new(&mg[2], &r, D, taps->group_size[2], OR_QUERIES);
-    for (uint32_t i = 0; i < seg->n_accum_mix; i++) (void)or_iop_random_elem(&r.rng);
+    fp* accum_mix = (fp*)malloc((seg->n_accum_mix + 1) * sizeof(fp));
+    for (uint32_t i = 0; i < seg->n_accum_mix; i++) accum_mix[i] = or_iop_random_elem(&r.rng);
     mv_new(&mg[0], &r, D, taps->group_size[0], OR_QUERIES);
-    (void)or_iop_random_ext(&r.rng); /* poly_mix */
+    fp4 poly_mix = or_iop_random_ext(&r.rng);
     mv_new(&mcheck, &r, D, OR_CHECK_SIZE, OR_QUERIES);
     fp4 z = or_iop_random_ext(&r.rng);
     fp back_one = or_rou_rev(po2);
@@ -86,7 +90,38 @@ int or_verify_segment(const or_segment* seg, const uint32_t* seal, size_t seal_w
     fp4* coeff_u = (fp4*)malloc(n_coeff_u * sizeof(fp4));
     r_read(&r, (uint32_t*)coeff_u, n_coeff_u * 4);
     or_hash_elem_slice((const fp*)coeff_u, n_coeff_u * 4, 1, digest); or_iop_commit(&r.rng, digest);
-    /* (circuit constraint identity would be checked here) */
+    int identity_rc = 0;
+    if (poly_ext && !r.err) {
+        /* verify/mod.rs: U polynomials -> evaluations, circuit polynomial on them, against
+         * check(z) * ((3z)^N - 1), check(z) = sum_i z^i * (ext element from check columns remap[i] + 4e) */
+        fp4* eval_u = (fp4*)malloc((tot_taps + 1) * sizeof(fp4));
+        size_t pos = 0;
+        for (uint32_t i = 0; i < taps->n_regs; i++) {
+            uint32_t cb = taps->reg_combo[i];
+            size_t sz = taps->combo_off[cb + 1] - taps->combo_off[cb];
+            for (size_t j = 0; j < sz; j++) {
+                fp4 x = fp4_scale(z, fp_pow(back_one, taps->combo_backs[taps->combo_off[cb] + j]));
+                or_poly_eval(coeff_u + pos, sz, x.c, eval_u[pos + j].c);
+            }
+            pos += sz;
+        }
+        fp4 result;
+        if (poly_ext(user, seg, poly_mix.c, eval_u, tot_taps, accum_mix, seg->n_accum_mix, result.c) != 0) identity_rc = 71;
+        static const int remap[4] = {0, 2, 1, 3};
+        fp4 check = fp4_zero(), zi = fp4_one();
+        for (int i = 0; i < 4; i++) {
+            for (int e = 0; e < 4; e++) {
+                fp4 basis = fp4_zero();
+                basis.c[e] = fp_from_u32(1);
+                check = fp4_add(check, fp4_mul(fp4_mul(coeff_u[tot_taps + remap[i] + 4 * e], zi), basis));
+            }
+            zi = fp4_mul(zi, z);
+        }
+        fp4 vanish = fp4_sub(fp4_pow(fp4_scale(z, fp_from_u32(3)), N), fp4_one());
+        if (!identity_rc && !fp4_eq(fp4_mul(check, vanish), result)) identity_rc = 70;
+        free(eval_u);
+    }
+    free(accum_mix);
     fp4 mix = or_iop_random_ext(&r.rng);
     fp4* combo_u = (fp4*)calloc(tot_combo_backs + 1, sizeof(fp4));
     {
@@ -108,7 +143,7 @@ int or_verify_segment(const or_segment* seg, const uint32_t* seal, size_t seal_w
     fp4 z_pow = fp4_pow(z, OR_EXT);
 
     /* ---- fri_verify ---- */
-    int rc = 0;
+    int rc = identity_rc;
     size_t degree = N, domain = D, orig_domain = D;
     struct { size_t domain; mverifier m; fp4 mix; } rounds[16];
     int n_rounds = 0;

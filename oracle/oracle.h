@@ -74,6 +74,8 @@ void or_eltwise_copy_elem(fp* out, const fp* in, size_t n);
 void or_eltwise_zeroize_elem(fp* io, size_t n);
 void or_fri_fold(fp* out, const fp* in, size_t out_count, const uint32_t* mix);
 void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t stride);
+void or_prefix_products(fp4* io, size_t count);              /* io[i] *= io[i-1], sequential */
+void or_scatter(fp* into, const uint32_t* index, size_t n_cycles, const uint32_t* offsets, const fp* values);
 
 /* ---- risc0-zkp core/poly.rs ---- */
 void or_poly_interpolate(fp4* out, const fp4* x, const fp4* fx, size_t n);
@@ -114,6 +116,23 @@ typedef struct {
     const uint32_t* combo_backs;
 } or_taps;
 
+/* CircuitHal::accumulate / eval_check (risc0-circuit-rv32im prove/mod.rs, risc0-zkp prove/prover.rs
+ * finalize) as host callbacks: all pointers are host memory.  trace = the witness (N rows), lde =
+ * PolyGroup::evaluated (4N rows, natural order), both column-major and indexed by group id. */
+typedef struct {
+    uint32_t po2;
+    uint32_t group_size[3];
+    const fp* trace[3];
+    const fp* lde[3];
+    const fp* globals; uint32_t n_globals;
+    const fp* mix; uint32_t n_mix;
+} or_circuit_view;
+typedef struct {
+    void* user;
+    int (*accumulate)(void* user, const or_circuit_view* v, fp* accum /* N x group_size[0] */);
+    int (*eval_check)(void* user, const or_circuit_view* v, const fp* poly_mix /*4*/, fp* check /* 4 x 4N */);
+} or_circuit_hooks;
+
 typedef struct {
     uint32_t po2;
     or_taps taps;
@@ -123,7 +142,11 @@ typedef struct {
     uint32_t n_accum_mix;          /* elements drawn before the accum commit */
     uint8_t proof_system_info[16];
     uint8_t circuit_info[16];
+    const or_circuit_hooks* hooks; /* NULL: group[0] / check are taken as given */
 } or_segment;
+/* CircuitDef::poly_ext for the verifier: the mixed constraint polynomial on the tap openings */
+typedef int (*or_poly_ext_fn)(void* user, const or_segment* pub, const fp* poly_mix, const fp4* eval_u, size_t n_taps,
+                              const fp* mix, uint32_t n_mix, fp* out /*4*/);
 
 /* risc0-zkp prove/prover.rs + circuit/rv32im prove/mod.rs (prove_segment):
  * returns malloc'd seal (u32 transcript). threads>0 sets the OpenMP team size. */
@@ -131,8 +154,20 @@ int or_prove_segment(const or_segment* seg, uint32_t** seal, size_t* seal_words,
 /* risc0-zkp verify/mod.rs restated for the same flow, minus the circuit's
  * constraint identity (no rv32im circuit available): 0 = accept. */
 int or_verify_segment(const or_segment* pub_only, const uint32_t* seal, size_t seal_words);
+/* the same plus the constraint identity poly_ext(...) == check(z) * ((3z)^N - 1) (rc 70) */
+int or_verify_segment_circuit(const or_segment* pub_only, const uint32_t* seal, size_t seal_words,
+                              or_poly_ext_fn poly_ext, void* user);
+
+/* ---- toy circuit (oracle/or_toy.c): CPU restatement of examples/toy_circuit ---- */
+const or_circuit_hooks* or_toy_hooks(void);
+int or_toy_poly_ext(void* user, const or_segment* pub, const fp* poly_mix, const fp4* eval_u, size_t n_taps,
+                    const fp* mix, uint32_t n_mix, fp* out);
 void or_free(void* p);
 int or_max_threads(void);
+/* or_fast.c: route the hot operators (NTT, zk_shift, Poseidon2 rows/folds, tap evaluation, DEEP mix)
+ * through their AVX2 / table-driven forms -- the timed cpu_baseline; results are bit-identical */
+void or_set_fast(int on);
+int or_get_fast(void);
 
 /* stage timing of the last or_prove_segment call, seconds */
 typedef struct { double ntt, hash, deep, fri, query, total; } or_timing;

@@ -48,14 +48,47 @@ class RkSegment(C.Structure):
         ("n_accum_mix", C.c_uint32),
         ("proof_system_info", C.c_uint8 * 16),
         ("circuit_info", C.c_uint8 * 16),
+        ("hooks", C.c_void_p),
     ]
 
 
+class RkCircuitView(C.Structure):
+    _fields_ = [
+        ("ctx", C.c_void_p),
+        ("stream", C.c_void_p),
+        ("po2", C.c_uint32),
+        ("group_size", C.c_uint32 * 3),
+        ("d_trace", C.c_void_p * 3),
+        ("d_lde", C.c_void_p * 3),
+        ("globals", u32p),
+        ("n_globals", C.c_uint32),
+        ("mix", u32p),
+        ("n_mix", C.c_uint32),
+    ]
+
+
+ACCUMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(RkCircuitView), C.c_void_p)
+EVAL_CHECK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(RkCircuitView), u32p, C.c_void_p)
+POLY_EXT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(RkSegment), u32p, u32p, C.c_size_t, u32p, C.c_uint32, u32p)
+
+
+class RkCircuitHooks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("accumulate", ACCUMULATE_FN), ("eval_check", EVAL_CHECK_FN)]
+
+
+class RkVerifyOpts(C.Structure):
+    _fields_ = [("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p), ("poly_ext", POLY_EXT_FN),
+                ("user", C.c_void_p)]
+
+
 class RkSessionOpts(C.Structure):
-    _fields_ = [("device", C.c_int), ("inflight", C.c_int), ("upload_ahead", C.c_int), ("verify", C.c_int)]
+    _fields_ = [("device", C.c_int), ("inflight", C.c_int), ("upload_ahead", C.c_int), ("verify", C.c_int),
+                ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("verify_opts", C.POINTER(RkVerifyOpts))]
 
 
+RK_ERR_INVALID = -1
 RK_ERR_VERIFY = -7
+RK_ERR_CALLBACK = -8
 
 
 class RkKernelStat(C.Structure):
@@ -66,7 +99,7 @@ KCLASS_COUNT = 5
 
 
 class RkTiming(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("ntt", "hash", "deep", "fri", "query", "total")]
+    _fields_ = [(n, C.c_float) for n in ("ntt", "hash", "deep", "fri", "query", "total", "circuit")]
 
 
 # every symbol include/raiko_hip.h declares: name -> (restype, argtypes)
@@ -107,11 +140,16 @@ SYMBOLS = {
     "rk_poly_divide": (C.c_int, [_vp, _vp, _sz, u32p, u32p]),
     "rk_prove_segment": (C.c_int, [_vp, C.POINTER(RkSegment), u32p, _sz, C.POINTER(_sz)]),
     "rk_verify_segment": (C.c_int, [C.POINTER(RkSegment), u32p, _sz]),
+    "rk_verify_segment_ex": (C.c_int, [C.POINTER(RkSegment), C.POINTER(RkVerifyOpts), u32p, _sz]),
+    "rk_prefix_products": (C.c_int, [_vp, _vp, _sz]),
+    "rk_scatter": (C.c_int, [_vp, _vp, _sz, u32p, _sz, u32p, u32p]),
     "rk_seal_bound_words": (_sz, [C.POINTER(RkSegment)]),
     "rk_last_timing": (C.c_int, [_vp, C.POINTER(RkTiming)]),
     "rk_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "rk_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(RkKernelStat)]),
     "rk_kernel_class_name": (C.c_char_p, [C.c_int]),
+    "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
+    "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),
 }
 
 _lib = None

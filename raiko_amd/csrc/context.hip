@@ -123,7 +123,7 @@ static int build_tables(rk_ctx* ctx) {
 
 extern "C" {
 
-int rk_abi_version(void) { return 1; }
+int rk_abi_version(void) { return 2; }
 
 const char* rk_strerror(int s) {
     switch (s) {
@@ -135,6 +135,7 @@ const char* rk_strerror(int s) {
         case RK_ERR_CAPACITY: return "output buffer too small";
         case RK_ERR_INTERNAL: return "prover invariant violated";
         case RK_ERR_VERIFY: return "a produced seal failed verification";
+        case RK_ERR_CALLBACK: return "a circuit hook failed";
         default: return "unknown status";
     }
 }
@@ -152,6 +153,7 @@ int rk_device_count(int* count) {
 }
 
 int rk_ctx_create(int device, void* stream, rk_ctx** out) {
+    RK_GUARD_BEGIN
     if (!out) return RK_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -186,6 +188,7 @@ int rk_ctx_create(int device, void* stream, rk_ctx** out) {
     }
     *out = ctx;
     return RK_OK;
+    RK_GUARD_END
 }
 
 int rk_ctx_destroy(rk_ctx* ctx) {
@@ -213,12 +216,15 @@ int rk_sync(rk_ctx* ctx) {
     return RK_OK;
 }
 int rk_alloc(rk_ctx* ctx, size_t bytes, void** d_ptr) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_ptr) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::dev_alloc(ctx, bytes, d_ptr);
+    RK_GUARD_END
 }
 int rk_free(rk_ctx* ctx, void* d_ptr) {
     if (!ctx) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the block may still be in use by queued work on the stream
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return rk::dev_free(ctx, d_ptr);

@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/raiko_hip.h"
+#include "taps.hpp"
 #include "bb.hpp"
 #include "ntt_core.hpp"
 #include "poseidon2_core.hpp"
@@ -60,6 +62,12 @@ struct rk_ctx {
             return RK_ERR_HIP;                                                                  \
         }                                                                                       \
     } while (0)
+// extern "C" bodies never let a C++ exception cross the ABI ("never aborts")
+#define RK_GUARD_BEGIN try {
+#define RK_GUARD_END                                   \
+    }                                                  \
+    catch (const std::bad_alloc&) { return RK_ERR_NOMEM; } \
+    catch (...) { return RK_ERR_INTERNAL; }
 #define RK_TRY(expr)                \
     do {                            \
         int _s = (expr);            \
@@ -126,6 +134,9 @@ int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& 
 // by (x - h_z[i]) in one batch of launches; remainders to h_rems (may be null)
 int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size_t* h_offsets, const bb::Ext* h_z,
                      size_t n_items, bb::Ext* h_rems);
+int prefix_products(rk_ctx* ctx, uint32_t* d_io_ext, size_t count);
+int scatter(rk_ctx* ctx, uint32_t* d_into, size_t into_words, const uint32_t* h_index, size_t n_cycles,
+            const uint32_t* h_offsets, const uint32_t* h_values);
 // d_ext[idx[i]] -= delta[i]
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n);
 

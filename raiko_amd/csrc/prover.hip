@@ -8,8 +8,11 @@
 // polynomial, query openings).  The Fiat-Shamir transcript forces a handful
 // of stream synchronisations per segment (one per commitment).
 //
-// Circuit-specific steps (witness generation, accum construction, eval_check)
-// are inputs here: rk_segment carries their outputs.
+// Circuit-specific steps are the caller's: witness generation hands in code and data, and the
+// two steps that depend on Fiat-Shamir randomness (accum construction after the accum mix is
+// drawn, eval_check after poly_mix is drawn) are rk_circuit_hooks called back from the proof
+// (CircuitHal::accumulate / eval_check).  Without hooks their outputs are taken as given
+// (the synthetic S20 stand-in of SURVEY.md section 8d).
 #include "internal.hpp"
 
 #include <algorithm>
@@ -236,25 +239,6 @@ struct Stopwatch {
     }
 };
 
-int check_taps(const rk_taps& t) {
-    if (!t.reg_group || !t.reg_offset || !t.reg_combo || !t.combo_off || !t.combo_backs) return RK_ERR_INVALID;
-    if ((size_t)t.group_size[0] + t.group_size[1] + t.group_size[2] != t.n_regs) return RK_ERR_INVALID;
-    uint32_t r = 0;
-    for (uint32_t g = 0; g < 3; g++)
-        for (uint32_t o = 0; o < t.group_size[g]; o++, r++) {
-            if (t.reg_group[r] != g || t.reg_offset[r] != o) return RK_ERR_INVALID;
-            if (t.reg_combo[r] >= t.n_combos) return RK_ERR_INVALID;
-        }
-    if (t.combo_off[0] != 0) return RK_ERR_INVALID;
-    for (uint32_t c = 0; c < t.n_combos; c++) {
-        if (t.combo_off[c + 1] <= t.combo_off[c]) return RK_ERR_INVALID;
-        // backs of a combo are distinct (each is divided out once) and increasing, as TapSet builds them
-        for (uint32_t b = t.combo_off[c] + 1; b < t.combo_off[c + 1]; b++)
-            if (t.combo_backs[b] <= t.combo_backs[b - 1]) return RK_ERR_INVALID;
-    }
-    return RK_OK;
-}
-
 // core/poly.rs poly_interpolate for the handful of taps of one register
 void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n) {
     std::vector<Ext> num(n + 1);
@@ -278,11 +262,16 @@ void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n) {
 
 int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& seal) {
     const rk_taps& taps = seg->taps;
-    RK_TRY(check_taps(taps));
+    RK_TRY(rk::check_taps(taps));
     if (seg->po2 < 1 || seg->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
-    for (int g = 0; g < 3; g++)
-        if (!seg->group[g] || taps.group_size[g] == 0) return RK_ERR_INVALID;
-    if (!seg->check || (seg->n_globals && !seg->globals)) return RK_ERR_INVALID;
+    const rk_circuit_hooks* hooks = seg->hooks;
+    const bool hook_accum = hooks && hooks->accumulate, hook_check = hooks && hooks->eval_check;
+    for (int g = 0; g < 3; g++) {
+        if (taps.group_size[g] == 0) return RK_ERR_INVALID;
+        if (!seg->group[g] && !(g == 0 && hook_accum)) return RK_ERR_INVALID;
+    }
+    if ((!seg->check && !hook_check) || (seg->n_globals && !seg->globals)) return RK_ERR_INVALID;
+    if (seg->n_accum_mix > (1u << 16)) return RK_ERR_INVALID;
 
     const size_t N = (size_t)1 << seg->po2, D = N * 4;
     const size_t QUERIES = 50, FRI_FOLD = 16, FRI_MIN_DEGREE = 256, CHECK_SIZE = 16;
@@ -322,9 +311,27 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         // true DMA that overlaps the kernels already queued
         return RK_OK;
     };
-    // Prover::commit_group
-    auto commit_group = [&](PolyGroup& pg, const uint32_t* trace, size_t count) -> int {
-        RK_TRY(load_trace(pg.coeffs, trace, count * N));
+    // With an `accumulate` hook the witness of code and data must outlive their commitment (risc0's
+    // commit_group works on a copy for the same reason): device inputs are then copied, not consumed,
+    // and host inputs are uploaded once into `raw` and copied from there.
+    DevBuf raw[3];
+    const uint32_t* d_raw[3] = {nullptr, nullptr, nullptr};
+    auto load_group = [&](int g, DevBuf& dst, const uint32_t* src, size_t words) -> int {
+        if (!hook_accum || g == 0) return load_trace(dst, src, words);
+        if (seg->on_device) {
+            d_raw[g] = src;
+        } else {
+            RK_TRY(raw[g].alloc(ctx, words * 4));
+            RK_HIP_TRY(ctx, hipMemcpyAsync(raw[g].p, src, words * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_raw[g] = raw[g].u32();
+        }
+        RK_TRY(dst.alloc(ctx, words * 4));
+        RK_HIP_TRY(ctx, hipMemcpyAsync(dst.p, d_raw[g], words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return RK_OK;
+    };
+    // Prover::commit_group; `preloaded`: pg.coeffs already holds the trace (written by a hook)
+    auto commit_group = [&](int g, PolyGroup& pg, const uint32_t* trace, size_t count, bool preloaded = false) -> int {
+        if (!preloaded) RK_TRY(load_group(g, pg.coeffs, trace, count * N));
         sw.start();
         RK_TRY(rk::ntt_reverse(ctx, pg.coeffs.u32(), N, count, /*fuse_zk_shift=*/true));
         RK_TRY(pg.build(ctx, count, N));
@@ -336,17 +343,64 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     };
 
     PolyGroup groups[3], check;
-    RK_TRY(commit_group(groups[1], seg->group[1], taps.group_size[1]));  // code
-    RK_TRY(commit_group(groups[2], seg->group[2], taps.group_size[2]));  // data
-    for (uint32_t i = 0; i < seg->n_accum_mix; i++) (void)iop.random_elem();
-    RK_TRY(commit_group(groups[0], seg->group[0], taps.group_size[0]));  // accum
+    RK_TRY(commit_group(1, groups[1], seg->group[1], taps.group_size[1]));  // code
+    RK_TRY(commit_group(2, groups[2], seg->group[2], taps.group_size[2]));  // data
+    // the accum mix: drawn once code and data are bound (rv32im prove_segment)
+    std::vector<uint32_t> accum_mix(seg->n_accum_mix);
+    for (uint32_t i = 0; i < seg->n_accum_mix; i++) accum_mix[i] = iop.random_elem();
+    rk_circuit_view view{};
+    view.ctx = ctx;
+    view.stream = (void*)ctx->stream;
+    view.po2 = seg->po2;
+    for (int g = 0; g < 3; g++) view.group_size[g] = taps.group_size[g];
+    view.globals = seg->globals;
+    view.n_globals = seg->n_globals;
+    view.mix = accum_mix.data();
+    view.n_mix = seg->n_accum_mix;
+    if (hook_accum) {
+        // CircuitHal::accumulate: the hook writes the accum witness straight into the buffer the
+        // interpolation then transforms in place
+        RK_TRY(groups[0].coeffs.alloc(ctx, (size_t)taps.group_size[0] * N * 4));
+        view.d_trace[1] = d_raw[1];
+        view.d_trace[2] = d_raw[2];
+        view.d_lde[1] = groups[1].evaluated.u32();
+        view.d_lde[2] = groups[2].evaluated.u32();
+        sw.start();
+        if (hooks->accumulate(hooks->user, &view, groups[0].coeffs.u32()) != 0) {
+            ctx->last_error = "circuit hook `accumulate` failed";
+            return RK_ERR_CALLBACK;
+        }
+        sw.stop(&ctx->timing.circuit);
+        RK_TRY(commit_group(0, groups[0], nullptr, taps.group_size[0], true));
+        raw[1].release();
+        raw[2].release();
+        view.d_trace[1] = view.d_trace[2] = nullptr;
+    } else {
+        RK_TRY(commit_group(0, groups[0], seg->group[0], taps.group_size[0]));  // accum
+    }
 
     // Prover::finalize
-    (void)iop.random_ext();  // poly_mix: consumed by CircuitHal::eval_check, whose output is seg->check
-    RK_TRY(load_trace(check.coeffs, seg->check, 4 * D));
+    const Ext poly_mix = iop.random_ext();
+    if (hook_check) {
+        // CircuitHal::eval_check over the LDE domain, into the buffer that becomes the check group
+        RK_TRY(check.coeffs.alloc(ctx, 4 * D * 4));
+        for (int g = 0; g < 3; g++) view.d_lde[g] = groups[g].evaluated.u32();
+        sw.start();
+        if (hooks->eval_check(hooks->user, &view, poly_mix.c, check.coeffs.u32()) != 0) {
+            ctx->last_error = "circuit hook `eval_check` failed";
+            return RK_ERR_CALLBACK;
+        }
+        sw.stop(&ctx->timing.circuit);
+    } else {
+        RK_TRY(load_trace(check.coeffs, seg->check, 4 * D));  // pre-computed stand-in
+    }
     sw.start();
+    // 4 x D evaluations -> 4 x D bit-reversed coefficients = 16 columns of N: quarter c of plane e
+    // holds the coefficients n with n mod 4 = bitrev2(c) of component e, i.e. check(x) =
+    // sum_j x^j g_j(x^4) with g_j in column 4e + bitrev2(j) (the verifier's remap [0,2,1,3]).
+    // No zk_shift here: the hook evaluates at x_i = 3*w^i, so these already are the coefficients
+    // of y -> check(3y), the form every PolyGroup is kept in (recalled items).
     RK_TRY(rk::ntt_reverse(ctx, check.coeffs.u32(), D, 4, false));
-    RK_TRY(rk::zk_shift(ctx, check.coeffs.u32(), N, CHECK_SIZE));
     RK_TRY(check.build(ctx, CHECK_SIZE, N));
     sw.stop(&ctx->timing.ntt);
     sw.start();
@@ -585,30 +639,10 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
 
 extern "C" {
 
-size_t rk_seal_bound_words(const rk_segment* seg) {
-    if (!seg || seg->po2 > 24) return 0;
-    const rk_taps& t = seg->taps;
-    size_t N = (size_t)1 << seg->po2, D = 4 * N;
-    size_t layers = log2u(D);
-    size_t words = seg->n_globals + 1;
-    size_t tot_taps = 0;
-    if (t.reg_combo && t.combo_off)
-        for (uint32_t r = 0; r < t.n_regs; r++) tot_taps += t.combo_off[t.reg_combo[r] + 1] - t.combo_off[t.reg_combo[r]];
-    size_t w_all = (size_t)t.group_size[0] + t.group_size[1] + t.group_size[2] + 16;
-    words += 4 * 32 * 8;                      // top layers of the four trace trees
-    words += (tot_taps + 16) * 4;             // coeff_u
-    words += 50 * (w_all + 4 * layers * 8);   // trace openings
-    size_t size = N;
-    while (size > 256) {
-        size_t domain = size * 4;
-        words += 32 * 8 + 50 * (64 + log2u(domain / 16) * 8);
-        size /= 16;
-    }
-    words += size * 4;
-    return words + 64;
-}
+size_t rk_seal_bound_words(const rk_segment* seg) { return rk::seal_bound_words(seg); }
 
 int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t cap, size_t* seal_words) {
+    RK_GUARD_BEGIN
     if (!ctx || !seg || !seal_words || seg->on_device > 2) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<uint32_t> seal;
@@ -621,6 +655,7 @@ int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_
     if (!h_seal || seal.size() > cap) return RK_ERR_CAPACITY;
     std::memcpy(h_seal, seal.data(), seal.size() * 4);
     return RK_OK;
+    RK_GUARD_END
 }
 
 }  // extern "C"

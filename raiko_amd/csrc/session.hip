@@ -1,19 +1,25 @@
-// rk_prove_session: all segments of a session, several in flight on one GPU.
+// rk_prove_session: all segments of a session, several in flight per GPU, over one or more GPUs.
 //
 // The reference proves a session's segments one after the other (`session.prove()`,
 // provers/risc0/driver/src/bonsai.rs:271).  One proof is a chain of ~120 dependent launches with a
 // host round trip at every Merkle root, so a lone proof leaves an MI355X partly idle; segments are
-// independent, so this entry point runs `inflight` prover contexts (one HIP stream, scratch pool and
-// host thread each) over a shared index, and one more context + thread stages host-resident traces
-// `upload_ahead` segments ahead into a ring of device buffers, so the PCIe upload of segment i+1
-// runs under the proof of segment i.  Each seal is verified (rk_verify_segment, host code) by one
-// more thread while the GPU goes on.  Contexts and staging buffers are
-// kept per device for the life of the process (rk_session_release frees them): the `Prover` trait
-// of the reference has no `self`, a backend's state is process-global (lib/src/prover.rs:52-62).
+// independent, so this entry point runs `inflight` prover contexts per GPU (one HIP stream, scratch
+// pool and host thread each).  Per GPU one more context + thread (the feeder) claims segments from
+// the session-wide work queue -- one claim flag per segment, shared by all GPUs, so a slower GPU or a
+// short last segment never stalls the others -- and stages host-resident traces up to
+// `upload_ahead` segments ahead into a ring of device buffers: the PCIe upload of segment i+1 runs
+// under the proof of segment i.  Seals land in the caller's host buffers (no inter-GPU traffic, no
+// collective: a single-process host such as raiko's, core/src/interfaces.rs:187-193, needs none) and
+// are verified (rk_verify_segment_ex, host code) by one more thread while the GPUs go on.
+// Contexts and staging buffers are kept per device for the life of the process
+// (rk_session_release frees them): the `Prover` trait of the reference has no `self`, a backend's
+// state is process-global (lib/src/prover.rs:52-62).
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -28,18 +34,6 @@ struct Slot {
     size_t words[4] = {0, 0, 0, 0};
 };
 
-struct DevicePool {
-    int device = 0;
-    std::vector<rk_ctx*> provers;
-    rk_ctx* uploader = nullptr;
-    std::vector<Slot*> ring;
-    std::mutex busy;  // one session at a time per device (`run` may be entered from many threads)
-    std::string last_error;
-};
-
-std::mutex g_mu;
-std::map<int, DevicePool*> g_pools;
-
 void free_slot(rk_ctx* up, Slot* s) {
     for (int g = 0; g < 3; g++) {
         if (s->group[g]) (void)rk_free(up, s->group[g]);
@@ -50,17 +44,51 @@ void free_slot(rk_ctx* up, Slot* s) {
     for (auto& w : s->words) w = 0;
 }
 
-void destroy_pool(DevicePool* p) {
-    if (p->uploader) {
-        for (Slot* s : p->ring) {
-            free_slot(p->uploader, s);
-            delete s;
+struct DevicePool {
+    int device = 0;
+    std::vector<rk_ctx*> provers;
+    rk_ctx* uploader = nullptr;
+    std::vector<Slot*> ring;
+    std::mutex busy;  // one session at a time per device (`run` may be entered from many threads)
+    std::string last_error;
+    bool ktime_on = false;  // applied to contexts created later
+    void clear() {
+        if (uploader) {
+            for (Slot* s : ring) {
+                free_slot(uploader, s);
+                delete s;
+            }
+            (void)rk_ctx_destroy(uploader);
         }
-        (void)rk_ctx_destroy(p->uploader);
+        ring.clear();
+        uploader = nullptr;
+        for (rk_ctx* c : provers) (void)rk_ctx_destroy(c);
+        provers.clear();
     }
-    for (rk_ctx* c : p->provers) (void)rk_ctx_destroy(c);
-    delete p;
-}
+    ~DevicePool() { clear(); }
+};
+
+std::mutex g_mu;
+// shared ownership: a session that looked its pool up keeps it alive even if rk_session_release
+// drops it from the map before the session locks `busy`
+std::map<int, std::shared_ptr<DevicePool>> g_pools;
+
+struct Item {
+    size_t idx;
+    Slot* slot;
+};
+
+struct DevRun {
+    DevicePool* pool = nullptr;
+    std::deque<Item> ready;       // claimed (and staged) segments not yet taken by a prover
+    std::deque<Slot*> free_slots;
+    size_t outstanding = 0;       // claimed, proof not finished
+    size_t max_outstanding = 1;
+    size_t n_slots = 1;
+    size_t cursor = 0;
+    size_t provers_left = 0;
+    bool feeder_done = false;
+};
 
 // shared state of one rk_prove_session call
 struct Run {
@@ -70,15 +98,15 @@ struct Run {
     const size_t* caps;
     size_t* words;
     int verify;
+    const rk_verify_opts* verify_opts;
 
-    std::atomic<size_t> next{0};
+    std::unique_ptr<std::atomic<unsigned char>[]> claimed;
+    std::vector<int> owner;          // device a device-resident segment lives on (-1: host-resident, any GPU)
+    std::vector<DevRun> devs;
     std::mutex mu;
     std::condition_variable cv;
-    std::map<size_t, Slot*> ready;   // staged segments not yet taken by a prover
-    std::deque<Slot*> free_slots;
     std::deque<size_t> to_verify;    // finished seals waiting for the verifier thread
     size_t provers_left = 0;
-    bool stop = false;               // stager finished or the run is aborted
     int status = RK_OK;              // first failure
     size_t failed = (size_t)-1;
     std::string detail;
@@ -90,114 +118,141 @@ struct Run {
             failed = idx;
             detail = text ? text : "";
         }
-        stop = true;
         cv.notify_all();
     }
-    bool aborted() {
-        std::lock_guard<std::mutex> l(mu);
-        return status != RK_OK;
+    // next unclaimed segment device `dev` may take, scanning from its cursor (mu held)
+    bool claim(size_t d, size_t* out) {
+        DevRun& dr = devs[d];
+        for (size_t i = dr.cursor; i < n; i++) {
+            if (owner[i] >= 0 && owner[i] != dr.pool->device) continue;
+            if (claimed[i].exchange(1)) {
+                if (i == dr.cursor) dr.cursor++;
+                continue;
+            }
+            if (i == dr.cursor) dr.cursor++;
+            *out = i;
+            return true;
+        }
+        return false;
     }
 };
 
 bool needs_staging(const rk_segment& s) { return s.on_device == 0; }
+bool hook_accum(const rk_segment& s) { return s.hooks && s.hooks->accumulate; }
+bool hook_check(const rk_segment& s) { return s.hooks && s.hooks->eval_check; }
 
-void stager(DevicePool* pool, Run* run, size_t n_slots) {
-    rk_ctx* up = pool->uploader;
-    for (size_t i = 0; i < run->n; i++) {
-        const rk_segment& seg = run->segs[i];
-        if (!needs_staging(seg)) continue;
+// claims segments for one GPU and stages the host-resident ones
+void feeder(Run* run, size_t d) {
+    DevRun& dr = run->devs[d];
+    rk_ctx* up = dr.pool->uploader;
+    for (;;) {
+        size_t i = 0;
         Slot* slot = nullptr;
         {
             std::unique_lock<std::mutex> l(run->mu);
-            for (;;) {
-                if (run->status != RK_OK) return;
-                if (!run->free_slots.empty()) {
-                    slot = run->free_slots.front();
-                    run->free_slots.pop_front();
-                    break;
-                }
-                if (pool->ring.size() < n_slots) {  // grow the ring before waiting for a proof to end
+            run->cv.wait(l, [&] { return run->status != RK_OK || dr.outstanding < dr.max_outstanding; });
+            if (run->status != RK_OK || !run->claim(d, &i)) break;
+            dr.outstanding++;
+            if (needs_staging(run->segs[i])) {
+                if (!dr.free_slots.empty()) {
+                    slot = dr.free_slots.front();
+                    dr.free_slots.pop_front();
+                } else {  // outstanding < n_slots: the ring has room to grow
                     slot = new Slot();
-                    pool->ring.push_back(slot);
-                    break;
+                    dr.pool->ring.push_back(slot);
                 }
-                run->cv.wait(l);
             }
         }
-        const size_t rows = (size_t)1 << seg.po2;
-        const size_t want[4] = {rows * seg.taps.group_size[0], rows * seg.taps.group_size[1],
-                                rows * seg.taps.group_size[2], rows * 16};
-        if (want[0] != slot->words[0] || want[1] != slot->words[1] || want[2] != slot->words[2] ||
-            want[3] != slot->words[3]) {
-            free_slot(up, slot);
+        if (slot) {
+            const rk_segment& seg = run->segs[i];
+            const size_t rows = (size_t)1 << seg.po2;
+            const size_t want[4] = {hook_accum(seg) ? 0 : rows * seg.taps.group_size[0], rows * seg.taps.group_size[1],
+                                    rows * seg.taps.group_size[2], hook_check(seg) ? 0 : rows * 16};
             int st = RK_OK;
-            for (int g = 0; g < 3 && st == RK_OK; g++) st = rk_alloc(up, want[g] * 4, &slot->group[g]);
-            if (st == RK_OK) st = rk_alloc(up, want[3] * 4, &slot->check);
+            if (want[0] != slot->words[0] || want[1] != slot->words[1] || want[2] != slot->words[2] ||
+                want[3] != slot->words[3]) {
+                free_slot(up, slot);
+                for (int g = 0; g < 3 && st == RK_OK; g++)
+                    if (want[g]) st = rk_alloc(up, want[g] * 4, &slot->group[g]);
+                if (st == RK_OK && want[3]) st = rk_alloc(up, want[3] * 4, &slot->check);
+                if (st == RK_OK)
+                    for (int k = 0; k < 4; k++) slot->words[k] = want[k];
+            }
+            for (int g = 0; g < 3 && st == RK_OK; g++) {
+                if (!want[g]) continue;
+                st = seg.group[g] ? rk_h2d(up, slot->group[g], seg.group[g], want[g] * 4) : RK_ERR_INVALID;
+            }
+            if (st == RK_OK && want[3]) st = seg.check ? rk_h2d(up, slot->check, seg.check, want[3] * 4) : RK_ERR_INVALID;
+            if (st == RK_OK) st = rk_sync(up);  // the buffers change hands after this
             if (st != RK_OK) {
                 run->fail(st, i, rk_last_error(up));
-                return;
+                break;
             }
-            for (int k = 0; k < 4; k++) slot->words[k] = want[k];
-        }
-        int st = RK_OK;
-        for (int g = 0; g < 3 && st == RK_OK; g++) {
-            if (!seg.group[g] && want[g]) st = RK_ERR_INVALID;
-            else if (want[g]) st = rk_h2d(up, slot->group[g], seg.group[g], want[g] * 4);
-        }
-        if (st == RK_OK) st = seg.check ? rk_h2d(up, slot->check, seg.check, want[3] * 4) : RK_ERR_INVALID;
-        if (st == RK_OK) st = rk_sync(up);  // the buffers change hands after this
-        if (st != RK_OK) {
-            run->fail(st, i, rk_last_error(up));
-            return;
         }
         std::lock_guard<std::mutex> l(run->mu);
-        run->ready[i] = slot;
+        dr.ready.push_back(Item{i, slot});
         run->cv.notify_all();
     }
+    std::lock_guard<std::mutex> l(run->mu);
+    dr.feeder_done = true;
+    run->cv.notify_all();
 }
 
-void prover(rk_ctx* ctx, Run* run) {
+void prover(rk_ctx* ctx, Run* run, size_t d) {
+    DevRun& dr = run->devs[d];
     for (;;) {
-        size_t i = run->next.fetch_add(1);
-        if (i >= run->n || run->aborted()) return;
-        rk_segment seg = run->segs[i];
-        Slot* slot = nullptr;
-        if (needs_staging(seg)) {
+        Item it{};
+        {
             std::unique_lock<std::mutex> l(run->mu);
-            run->cv.wait(l, [&] { return run->ready.count(i) || run->status != RK_OK; });
-            if (run->status != RK_OK) return;
-            slot = run->ready[i];
-            run->ready.erase(i);
+            run->cv.wait(l, [&] { return run->status != RK_OK || !dr.ready.empty() || dr.feeder_done; });
+            if (run->status != RK_OK || dr.ready.empty()) return;
+            it = dr.ready.front();
+            dr.ready.pop_front();
+        }
+        const size_t i = it.idx;
+        rk_segment seg = run->segs[i];
+        if (it.slot) {
             seg.on_device = 2;  // the staged copy is ours: no second copy inside the prover
-            for (int g = 0; g < 3; g++) seg.group[g] = (const uint32_t*)slot->group[g];
-            seg.check = (const uint32_t*)slot->check;
+            for (int g = 0; g < 3; g++) seg.group[g] = (const uint32_t*)it.slot->group[g];
+            seg.check = (const uint32_t*)it.slot->check;
         }
         int st = rk_prove_segment(ctx, &seg, run->h_seals[i], run->caps[i], &run->words[i]);
-        if (slot) {
+        {
             std::lock_guard<std::mutex> l(run->mu);
-            run->free_slots.push_back(slot);
+            if (it.slot) dr.free_slots.push_back(it.slot);
+            dr.outstanding--;
+            if (st == RK_OK && run->verify) run->to_verify.push_back(i);  // host work for the verifier thread
             run->cv.notify_all();
         }
         if (st != RK_OK) {
             run->fail(st, i, rk_last_error(ctx));
             return;
         }
-        if (run->verify) {  // host work: handed to the verifier thread so this context goes straight on
-            std::lock_guard<std::mutex> l(run->mu);
-            run->to_verify.push_back(i);
-            run->cv.notify_all();
-        }
     }
 }
 
-void prover_thread(rk_ctx* ctx, Run* run) {
-    prover(ctx, run);
+void prover_thread(rk_ctx* ctx, Run* run, size_t d) {
+    try {
+        prover(ctx, run, d);
+    } catch (...) {
+        run->fail(RK_ERR_INTERNAL, (size_t)-1, "exception in a prover thread");
+    }
     std::lock_guard<std::mutex> l(run->mu);
     run->provers_left--;
     run->cv.notify_all();
 }
+void feeder_thread(Run* run, size_t d) {
+    try {
+        feeder(run, d);
+    } catch (...) {
+        run->fail(RK_ERR_INTERNAL, (size_t)-1, "exception in a feeder thread");
+        std::lock_guard<std::mutex> l(run->mu);
+        run->devs[d].feeder_done = true;
+        run->cv.notify_all();
+    }
+}
 
-// rk_verify_segment of every finished seal (~9 ms of host time at S20, against ~26 ms per proof)
+// rk_verify_segment_ex of every finished seal (~9 ms of host time at S20, against ~26 ms per proof)
 void verifier(Run* run) {
     for (;;) {
         size_t i;
@@ -209,11 +264,119 @@ void verifier(Run* run) {
             i = run->to_verify.front();
             run->to_verify.pop_front();
         }
-        if (rk_verify_segment(&run->segs[i], run->h_seals[i], run->words[i]) != 0) {
-            run->fail(RK_ERR_VERIFY, i, "seal failed verification");
+        int v = RK_ERR_INTERNAL;
+        try {
+            v = rk_verify_segment_ex(&run->segs[i], run->verify_opts, run->h_seals[i], run->words[i]);
+        } catch (...) {
+        }
+        if (v != 0) {
+            std::string why = "seal failed verification (reason " + std::to_string(v) + ")";
+            run->fail(RK_ERR_VERIFY, i, why.c_str());
             return;
         }
     }
+}
+
+int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n, uint32_t* const* h_seals,
+                  const size_t* seal_capacity_words, size_t* seal_words, size_t* failed_index) {
+    if (failed_index) *failed_index = (size_t)-1;
+    if (!opts || (n && (!segs || !h_seals || !seal_capacity_words || !seal_words))) return RK_ERR_INVALID;
+    if (opts->inflight < 1 || opts->inflight > 16 || opts->upload_ahead < 0 || opts->upload_ahead > 16) return RK_ERR_INVALID;
+    if (opts->n_devices < 0 || opts->n_devices > 64 || (opts->n_devices > 0 && !opts->devices)) return RK_ERR_INVALID;
+    std::vector<int> devices;
+    if (opts->n_devices > 0) devices.assign(opts->devices, opts->devices + opts->n_devices);
+    else devices.push_back(opts->device);
+    std::sort(devices.begin(), devices.end());  // pools are locked in ascending order: no lock cycles
+    if (std::adjacent_find(devices.begin(), devices.end()) != devices.end()) return RK_ERR_INVALID;
+    if (n == 0) return RK_OK;
+    int n_gpus = 0;
+    if (hipGetDeviceCount(&n_gpus) != hipSuccess || n_gpus <= 0) return RK_ERR_NODEVICE;
+    for (int d : devices)
+        if (d < 0 || d >= n_gpus) return RK_ERR_INVALID;
+
+    std::vector<std::shared_ptr<DevicePool>> pools;
+    {
+        std::lock_guard<std::mutex> l(g_mu);
+        for (int d : devices) {
+            auto& sp = g_pools[d];
+            if (!sp) {
+                sp = std::make_shared<DevicePool>();
+                sp->device = d;
+            }
+            pools.push_back(sp);
+        }
+    }
+    std::vector<std::unique_lock<std::mutex>> sessions;
+    for (auto& p : pools) sessions.emplace_back(p->busy);
+
+    Run run;
+    run.segs = segs;
+    run.n = n;
+    run.h_seals = h_seals;
+    run.caps = seal_capacity_words;
+    run.words = seal_words;
+    run.verify = opts->verify;
+    run.verify_opts = opts->verify_opts;
+    run.claimed.reset(new std::atomic<unsigned char>[n]);
+    for (size_t i = 0; i < n; i++) run.claimed[i].store(0);
+    run.owner.assign(n, -1);
+    bool any_host = false;
+    for (size_t i = 0; i < n; i++) {
+        if (segs[i].on_device > 2) return RK_ERR_INVALID;
+        if (needs_staging(segs[i])) {
+            any_host = true;
+        } else if (devices.size() == 1) {
+            run.owner[i] = devices[0];
+        } else {  // device-resident input: only the GPU holding it can prove it
+            hipPointerAttribute_t attr{};
+            if (!segs[i].group[1] || hipPointerGetAttributes(&attr, segs[i].group[1]) != hipSuccess) {
+                (void)hipGetLastError();
+                return RK_ERR_INVALID;
+            }
+            run.owner[i] = attr.device;
+            if (std::find(devices.begin(), devices.end(), attr.device) == devices.end()) {
+                if (failed_index) *failed_index = i;
+                return RK_ERR_INVALID;
+            }
+        }
+    }
+    const size_t workers = std::min<size_t>((size_t)opts->inflight, n);
+    run.devs.resize(devices.size());
+    for (size_t d = 0; d < devices.size(); d++) {
+        DevicePool* pool = pools[d].get();
+        while (pool->provers.size() < workers) {
+            rk_ctx* c = nullptr;
+            int st = rk_ctx_create(pool->device, nullptr, &c);
+            if (st != RK_OK) return st;
+            if (pool->ktime_on) (void)rk_set_kernel_timing(c, 1);
+            pool->provers.push_back(c);
+        }
+        if (any_host && !pool->uploader) {
+            int st = rk_ctx_create(pool->device, nullptr, &pool->uploader);
+            if (st != RK_OK) return st;
+        }
+        DevRun& dr = run.devs[d];
+        dr.pool = pool;
+        // with nothing to hide behind (upload_ahead == 0) the ring still needs one slot per prover
+        dr.n_slots = (size_t)opts->upload_ahead + workers;
+        dr.max_outstanding = dr.n_slots;
+        for (size_t k = 0; k < pool->ring.size() && k < dr.n_slots; k++) dr.free_slots.push_back(pool->ring[k]);
+        dr.provers_left = workers;
+    }
+    run.provers_left = workers * devices.size();
+    std::vector<std::thread> threads;
+    for (size_t d = 0; d < devices.size(); d++) {
+        threads.emplace_back(feeder_thread, &run, d);
+        for (size_t w = 0; w < workers; w++) threads.emplace_back(prover_thread, pools[d]->provers[w], &run, d);
+    }
+    if (run.verify) threads.emplace_back(verifier, &run);
+    for (auto& t : threads) t.join();
+    if (run.status != RK_OK) {
+        if (failed_index) *failed_index = run.failed;
+        std::lock_guard<std::mutex> l(g_mu);
+        for (auto& p : pools) p->last_error = run.detail;
+    }
+    return run.status;
 }
 
 }  // namespace
@@ -222,75 +385,81 @@ extern "C" {
 
 int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n, uint32_t* const* h_seals,
                      const size_t* seal_capacity_words, size_t* seal_words, size_t* failed_index) {
-    if (failed_index) *failed_index = (size_t)-1;
-    if (!opts || (n && (!segs || !h_seals || !seal_capacity_words || !seal_words))) return RK_ERR_INVALID;
-    if (opts->inflight < 1 || opts->inflight > 16 || opts->upload_ahead < 0 || opts->upload_ahead > 16) return RK_ERR_INVALID;
-    if (n == 0) return RK_OK;
-    DevicePool* pool = nullptr;
-    {
-        std::lock_guard<std::mutex> l(g_mu);
-        auto it = g_pools.find(opts->device);
-        if (it == g_pools.end()) {
-            pool = new DevicePool();
-            pool->device = opts->device;
-            g_pools[opts->device] = pool;
-        } else {
-            pool = it->second;
-        }
-    }
-    std::lock_guard<std::mutex> session(pool->busy);
-    while ((int)pool->provers.size() < opts->inflight) {
-        rk_ctx* c = nullptr;
-        int st = rk_ctx_create(opts->device, nullptr, &c);
-        if (st != RK_OK) return st;
-        pool->provers.push_back(c);
-    }
-    bool any_host = false;
-    for (size_t i = 0; i < n; i++) any_host |= needs_staging(segs[i]);
-    if (any_host && !pool->uploader) {
-        int st = rk_ctx_create(opts->device, nullptr, &pool->uploader);
-        if (st != RK_OK) return st;
-    }
-    Run run;
-    run.segs = segs;
-    run.n = n;
-    run.h_seals = h_seals;
-    run.caps = seal_capacity_words;
-    run.words = seal_words;
-    run.verify = opts->verify;
-    const size_t workers = std::min<size_t>((size_t)opts->inflight, n);
-    // with nothing to hide behind (upload_ahead == 0) the ring still needs one slot per prover
-    const size_t n_slots = (size_t)opts->upload_ahead + workers;
-    for (size_t k = 0; k < pool->ring.size() && k < n_slots; k++) run.free_slots.push_back(pool->ring[k]);
-    run.provers_left = workers;
-    std::vector<std::thread> threads;
-    if (any_host) threads.emplace_back(stager, pool, &run, n_slots);
-    for (size_t w = 0; w < workers; w++) threads.emplace_back(prover_thread, pool->provers[w], &run);
-    if (run.verify) threads.emplace_back(verifier, &run);
-    for (auto& t : threads) t.join();
-    if (run.status != RK_OK) {
-        if (failed_index) *failed_index = run.failed;
-        pool->last_error = run.detail;
-    }
-    return run.status;
+    RK_GUARD_BEGIN
+    return prove_session(opts, segs, n, h_seals, seal_capacity_words, seal_words, failed_index);
+    RK_GUARD_END
 }
 
+// the text is copied into storage of the calling thread: a later session cannot change it under the caller
 const char* rk_session_last_error(int device) {
+    thread_local std::string text;
+    try {
+        std::shared_ptr<DevicePool> p;
+        {
+            std::lock_guard<std::mutex> l(g_mu);
+            auto it = g_pools.find(device);
+            if (it != g_pools.end()) p = it->second;
+        }
+        if (!p) return "";
+        std::lock_guard<std::mutex> l(g_mu);
+        text = p->last_error;
+        return text.c_str();
+    } catch (...) {
+        return "";
+    }
+}
+
+static std::shared_ptr<DevicePool> pool_of(int device, bool create) {
     std::lock_guard<std::mutex> l(g_mu);
     auto it = g_pools.find(device);
-    if (it == g_pools.end()) return "";
-    return it->second->last_error.c_str();
+    if (it != g_pools.end()) return it->second;
+    if (!create) return nullptr;
+    auto sp = std::make_shared<DevicePool>();
+    sp->device = device;
+    g_pools[device] = sp;
+    return sp;
+}
+int rk_session_set_kernel_timing(int device, int enabled) {
+    RK_GUARD_BEGIN
+    if (device < 0) return RK_ERR_INVALID;
+    auto p = pool_of(device, true);
+    std::lock_guard<std::mutex> s(p->busy);
+    p->ktime_on = enabled != 0;
+    for (rk_ctx* c : p->provers) RK_TRY(rk_set_kernel_timing(c, enabled));
+    return RK_OK;
+    RK_GUARD_END
+}
+int rk_session_kernel_stats(int device, int kclass, rk_kernel_stat* out) {
+    RK_GUARD_BEGIN
+    if (!out || kclass < 0 || kclass >= RK_KCLASS_COUNT) return RK_ERR_INVALID;
+    *out = rk_kernel_stat{0, 0.0, 0.0};
+    auto p = pool_of(device, false);
+    if (!p) return RK_OK;
+    std::lock_guard<std::mutex> s(p->busy);
+    for (rk_ctx* c : p->provers) {
+        rk_kernel_stat st{};
+        RK_TRY(rk_kernel_stats(c, kclass, &st));
+        out->launches += st.launches;
+        out->ms += st.ms;
+        out->bytes += st.bytes;
+    }
+    return RK_OK;
+    RK_GUARD_END
 }
 
 int rk_session_release(void) {
-    std::lock_guard<std::mutex> l(g_mu);
-    for (auto& kv : g_pools) {
-        kv.second->busy.lock();  // wait for a running session of this device
-        kv.second->busy.unlock();
-        destroy_pool(kv.second);
+    RK_GUARD_BEGIN
+    std::map<int, std::shared_ptr<DevicePool>> pools;
+    {
+        std::lock_guard<std::mutex> l(g_mu);
+        pools.swap(g_pools);
     }
-    g_pools.clear();
+    for (auto& kv : pools) {
+        std::lock_guard<std::mutex> s(kv.second->busy);  // wait for a running session of this device
+        kv.second->clear();
+    }
     return RK_OK;
+    RK_GUARD_END
 }
 
 }  // extern "C"

@@ -3,10 +3,10 @@
 // restating risc0-zkp 1.0.1 verify/{mod,fri,merkle,read_iop}.rs for the flow of
 // rk_prove_segment.  Pure CPU code (no GPU needed): a host can check seals produced elsewhere.
 //
-// Not checked: the circuit's constraint identity (check polynomial against the rv32im
-// constraint system evaluated on the tap openings) -- risc0-circuit-rv32im is not available,
-// see DESIGN.md section 6.  Everything else is: transcript binding, Merkle openings, the DEEP
-// quotient at every query, FRI folds and the final low-degree polynomial.
+// Checked: transcript binding, Merkle openings, the DEEP quotient at every query, FRI folds, the
+// final low-degree polynomial and -- when the caller supplies the circuit's `poly_ext`
+// (rk_verify_opts) -- the constraint identity on the tap openings.  The rv32im constraint system
+// itself (risc0-circuit-rv32im) is not in this repo; examples/toy_circuit shows a complete one.
 #include "internal.hpp"
 #include "poseidon2_consts.inc"
 
@@ -142,21 +142,35 @@ Ext poly_eval(const Ext* c, size_t n, const Ext& x) {
     return acc;
 }
 
-}  // namespace
-
-extern "C" {
-
 // 0: the seal is a valid proof for the public data of `pub` (po2, taps, globals, infos);
 // RK_ERR_INVALID: malformed arguments; otherwise a positive reason code:
 //   10 header mismatch, 2x group opening failed (x = group id, 3 = check), 3x FRI round opening,
-//   4x fold inconsistency, 50 final polynomial mismatch, 60 seal too short, 61 trailing words
-int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_words) {
+//   4x fold inconsistency, 50 final polynomial mismatch, 60 seal too short, 61 trailing words,
+//   70 constraint identity (only with opts->poly_ext), 71 poly_ext callback failed
+int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint32_t* seal, size_t seal_words) {
     if (!pub || !seal) return RK_ERR_INVALID;
     const rk_taps& taps = pub->taps;
-    if (!taps.reg_group || !taps.reg_offset || !taps.reg_combo || !taps.combo_off || !taps.combo_backs)
-        return RK_ERR_INVALID;
+    if (rk::check_taps(taps) != RK_OK) return RK_ERR_INVALID;
     if (pub->po2 < 1 || pub->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
-    const p2::Consts& k = default_consts();
+    if (pub->n_globals && !pub->globals) return RK_ERR_INVALID;
+    if (pub->n_accum_mix > (1u << 16)) return RK_ERR_INVALID;
+    p2::Consts custom;
+    const p2::Consts* kp = &default_consts();
+    if (opts && (opts->p2_rc_ext || opts->p2_rc_int || opts->p2_diag)) {
+        if (!opts->p2_rc_ext || !opts->p2_rc_int || !opts->p2_diag) return RK_ERR_INVALID;
+        for (size_t i = 0; i < sizeof custom.rc_ext / 4; i++)
+            if (opts->p2_rc_ext[i] >= bb::P) return RK_ERR_INVALID;
+        for (int i = 0; i < p2::ROUNDS_PARTIAL; i++)
+            if (opts->p2_rc_int[i] >= bb::P) return RK_ERR_INVALID;
+        for (int i = 0; i < p2::CELLS; i++)
+            if (opts->p2_diag[i] >= bb::P) return RK_ERR_INVALID;
+        std::memcpy(custom.rc_ext, opts->p2_rc_ext, sizeof custom.rc_ext);
+        std::memcpy(custom.rc_int, opts->p2_rc_int, sizeof custom.rc_int);
+        std::memcpy(custom.diag, opts->p2_diag, sizeof custom.diag);
+        p2::derive(custom);
+        kp = &custom;
+    }
+    const p2::Consts& k = *kp;
     const size_t QUERIES = 50, FOLD = 16, MIN_DEGREE = 256, CHECK = 16;
     Reader r{seal, seal_words};
     Sponge rng(k);
@@ -182,9 +196,10 @@ int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_w
     TreeVerifier tg[3], tcheck;
     tg[1].init(k, r, rng, D, taps.group_size[1], QUERIES);
     tg[2].init(k, r, rng, D, taps.group_size[2], QUERIES);
-    for (uint32_t i = 0; i < pub->n_accum_mix; i++) (void)rng.elem();
+    std::vector<uint32_t> accum_mix(pub->n_accum_mix);
+    for (uint32_t i = 0; i < pub->n_accum_mix; i++) accum_mix[i] = rng.elem();
     tg[0].init(k, r, rng, D, taps.group_size[0], QUERIES);
-    (void)rng.ext();  // poly_mix
+    const Ext poly_mix = rng.ext();
     tcheck.init(k, r, rng, D, CHECK, QUERIES);
     const Ext z = rng.ext();
     const uint32_t w27 = bb::encode(137);
@@ -192,17 +207,45 @@ int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_w
 
     size_t tot_taps = 0;
     const size_t tot_backs = taps.combo_off[taps.n_combos];
-    for (uint32_t i = 0; i < taps.n_regs; i++) {
-        if (taps.reg_combo[i] >= taps.n_combos || taps.reg_group[i] > 2 ||
-            taps.reg_offset[i] >= taps.group_size[taps.reg_group[i]])
-            return RK_ERR_INVALID;
+    for (uint32_t i = 0; i < taps.n_regs; i++)
         tot_taps += taps.combo_off[taps.reg_combo[i] + 1] - taps.combo_off[taps.reg_combo[i]];
-    }
     std::vector<Ext> coeff_u(tot_taps + CHECK);
     r.read((uint32_t*)coeff_u.data(), coeff_u.size() * 4);
     hash_slice(k, (const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
     rng.mix(digest);
-    // (the circuit's constraint identity on the tap openings would be checked here)
+    if (r.short_read) return 60;
+    if (opts && opts->poly_ext) {
+        // verify/mod.rs: U polynomials back to evaluation form, the circuit's mixed constraint
+        // polynomial on them, against check(z) * ((3z)^N - 1) with check(z) = sum_i z^i * g_i(z^4),
+        // g_i = the extension element whose component e is opened in check column 4e + remap[i]
+        std::vector<Ext> eval_u(tot_taps);
+        size_t pos = 0;
+        for (uint32_t i = 0; i < taps.n_regs; i++) {
+            uint32_t cb = taps.reg_combo[i];
+            size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
+            for (size_t j = 0; j < sz; j++) {
+                Ext x = bb::scale(z, bb::pow(back_one, taps.combo_backs[taps.combo_off[cb] + j]));
+                eval_u[pos + j] = poly_eval(&coeff_u[pos], sz, x);
+            }
+            pos += sz;
+        }
+        Ext result;
+        if (opts->poly_ext(opts->user, pub, poly_mix.c, (const uint32_t*)eval_u.data(), tot_taps, accum_mix.data(),
+                           pub->n_accum_mix, result.c) != 0)
+            return 71;
+        static const int remap[4] = {0, 2, 1, 3};
+        Ext check = bb::ext_zero(), zi = bb::ext_one();
+        for (int i = 0; i < 4; i++) {
+            for (int e = 0; e < 4; e++) {
+                Ext basis = bb::ext_zero();
+                basis.c[e] = bb::ONE;
+                check = bb::add(check, bb::mul(bb::mul(coeff_u[tot_taps + remap[i] + 4 * e], zi), basis));
+            }
+            zi = bb::mul(zi, z);
+        }
+        Ext vanish = bb::sub(bb::pow(bb::scale(z, bb::encode(3)), N), bb::ext_one());
+        if (!bb::eq(bb::mul(check, vanish), result)) return 70;
+    }
     const Ext mix = rng.ext();
     std::vector<Ext> combo_u(tot_backs + 1, bb::ext_zero());
     {
@@ -315,6 +358,20 @@ int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_w
     if (r.short_read) return 60;
     if (r.pos != r.len) return 61;
     return RK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_verify_segment_ex(const rk_segment* pub, const rk_verify_opts* opts, const uint32_t* seal, size_t seal_words) {
+    RK_GUARD_BEGIN
+    return verify_segment(pub, opts, seal, seal_words);
+    RK_GUARD_END
+}
+// the compiled-in Poseidon2 instance, no constraint identity
+int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_words) {
+    return rk_verify_segment_ex(pub, nullptr, seal, seal_words);
 }
 
 }  // extern "C"

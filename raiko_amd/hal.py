@@ -191,6 +191,8 @@ class HipHal:
         if consume_inputs and device_inputs is not None:
             c_seg.on_device = 2
         cap = int(self._lib.rk_seal_bound_words(C.byref(c_seg)))
+        if cap == 0:  # malformed shape / tap set: nothing is allocated for it
+            raise _lib.RkError(_lib.RK_ERR_INVALID, "invalid argument (segment shape or tap set)")
         seal = np.empty(cap, dtype=np.uint32)
         words = C.c_size_t(0)
         self._ck(self._lib.rk_prove_segment(self._ctx, C.byref(c_seg), _u32p(seal), cap, C.byref(words)))
@@ -217,10 +219,11 @@ class HipHal:
 
 
 def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: int = 2, verify: bool = True,
-                  device_inputs=None):
+                  device_inputs=None, devices: Optional[Sequence[int]] = None, poly_ext=None, poseidon2=None):
     """Seals of all `segments`, in order, through rk_prove_session: `inflight` proofs in flight on
-    the GPU, host-resident traces staged `upload_ahead` segments ahead on a separate stream, every
-    seal verified on a host thread of its own (raiko_amd/csrc/session.hip).  Raises RkError with
+    each GPU (`devices`: several GPUs of the node share one work queue of segments), host-resident
+    traces staged `upload_ahead` segments ahead on a separate stream, every seal verified on a host
+    thread of its own (raiko_amd/csrc/session.hip; `poly_ext` / `poseidon2` as in verify_segment).  Raises RkError with
     `.status` (RK_ERR_VERIFY = -7 for a seal that does not verify) and `.segment` = failing index."""
     lib = _lib.load()
     n = len(segments)
@@ -238,10 +241,23 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
     seals = []
     for i in range(n):
         caps[i] = int(lib.rk_seal_bound_words(C.byref(c_segs[i])))
+        if caps[i] == 0:
+            e = _lib.RkError(_lib.RK_ERR_INVALID, "invalid argument (segment %d: shape or tap set)" % i)
+            e.segment = i
+            raise e
         buf = np.empty(caps[i], dtype=np.uint32)
         seals.append(buf)
         ptrs[i] = _u32p(buf)
     opts = _lib.RkSessionOpts(device=device, inflight=inflight, upload_ahead=upload_ahead, verify=1 if verify else 0)
+    if devices is not None:
+        dev_arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        opts.devices = dev_arr
+        opts.n_devices = len(devices)
+        keep.append(dev_arr)
+    if poly_ext is not None or poseidon2 is not None:
+        vopts, vkeep = make_verify_opts(poly_ext, poseidon2)
+        opts.verify_opts = C.pointer(vopts)
+        keep.append((vopts, vkeep))
     failed = C.c_size_t(0)
     st = lib.rk_prove_session(C.byref(opts), c_segs, n, ptrs, caps, words, C.byref(failed))
     del keep
@@ -255,7 +271,42 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
     return [seals[i][: words[i]].copy() for i in range(n)]
 
 
-def verify_segment(seg: Segment, seal: np.ndarray) -> int:
+def session_set_kernel_timing(device: int, enabled: bool):
+    """hipEvent brackets around every launch class of rk_prove_session's contexts of `device`"""
+    lib = _lib.load()
+    _lib.check(None, lib.rk_session_set_kernel_timing(device, 1 if enabled else 0))
+
+
+def session_kernel_stats(device: int) -> dict:
+    """{kernel class name: {launches, ms, bytes}} summed over the session contexts of `device`"""
+    lib = _lib.load()
+    out = {}
+    for k in range(_lib.KCLASS_COUNT):
+        st = _lib.RkKernelStat()
+        _lib.check(None, lib.rk_session_kernel_stats(device, k, C.byref(st)))
+        out[lib.rk_kernel_class_name(k).decode()] = {"launches": int(st.launches), "ms": float(st.ms), "bytes": float(st.bytes)}
+    return out
+
+
+def make_verify_opts(poly_ext=None, poseidon2=None):
+    """rk_verify_opts: `poly_ext` = a _lib.POLY_EXT_FN (the circuit's constraint polynomial: the
+    verifier then checks the constraint identity); `poseidon2` = (rc_ext[192], rc_int[21], diag[24])
+    the seal was produced under (default: the compiled-in instance).  Returns (opts, keepalive)."""
+    o = _lib.RkVerifyOpts()
+    keep = []
+    if poseidon2 is not None:
+        a = [np.ascontiguousarray(x, dtype=np.uint32).reshape(-1) for x in poseidon2]
+        if [x.size for x in a] != [192, 21, 24]:
+            raise ValueError("expected 192 + 21 + 24 constants")
+        o.p2_rc_ext, o.p2_rc_int, o.p2_diag = _u32p(a[0]), _u32p(a[1]), _u32p(a[2])
+        keep.append(a)
+    if poly_ext is not None:
+        o.poly_ext = poly_ext
+        keep.append(poly_ext)
+    return o, keep
+
+
+def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None) -> int:
     """Host-side check of a seal against the public data of `seg` (no GPU needed): 0 = valid,
     positive = reason code of the first failed check (raiko_amd/csrc/verify.hip)."""
     lib = _lib.load()
@@ -271,7 +322,12 @@ def verify_segment(seg: Segment, seal: np.ndarray) -> int:
         c.proof_system_info[i] = seg.proof_system_info[i]
         c.circuit_info[i] = seg.circuit_info[i]
     s = np.ascontiguousarray(seal, dtype=np.uint32)
-    return int(lib.rk_verify_segment(C.byref(c), _u32p(s), s.size))
+    if poly_ext is None and poseidon2 is None:
+        return int(lib.rk_verify_segment(C.byref(c), _u32p(s), s.size))
+    opts, k2 = make_verify_opts(poly_ext, poseidon2)
+    rc = int(lib.rk_verify_segment_ex(C.byref(c), C.byref(opts), _u32p(s), s.size))
+    del k2
+    return rc
 
 
 def fill_c_taps(c_taps, taps: TapSet, keep: list):
@@ -287,29 +343,40 @@ def fill_c_taps(c_taps, taps: TapSet, keep: list):
     c_taps.n_combos = taps.n_combos
 
 
+def hooks_address(seg: Segment) -> int:
+    h = getattr(seg, "hooks", None)
+    if h is None:
+        return 0
+    return int(h() if callable(h) else h)
+
+
 def make_c_segment(seg: Segment, device_inputs=None):
     keep = []
     c = _lib.RkSegment()
     c.po2 = seg.po2
     fill_c_taps(c.taps, seg.taps, keep)
+    c.hooks = hooks_address(seg) or None
     if device_inputs is not None:
         groups, check = device_inputs
         c.on_device = 1
         for g in range(3):
-            c.group[g] = _ptr(groups[g])
-        c.check = _ptr(check)
+            c.group[g] = _ptr(groups[g]) if groups[g] is not None else None
+        c.check = _ptr(check) if check is not None else None
         keep.append(device_inputs)
     else:
         c.on_device = 0
         for g in range(3):
+            if seg.groups[g] is None:  # produced by the accumulate hook
+                continue
             a = np.ascontiguousarray(seg.groups[g], dtype=np.uint32)
             assert a.shape == (seg.taps.group_size[g], seg.rows)
             keep.append(a)
             c.group[g] = a.ctypes.data
-        chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
-        assert chk.shape == (4, 4 * seg.rows)
-        keep.append(chk)
-        c.check = chk.ctypes.data
+        if seg.check is not None:
+            chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
+            assert chk.shape == (4, 4 * seg.rows)
+            keep.append(chk)
+            c.check = chk.ctypes.data
     gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)
     keep.append(gl)
     c.globals = _u32p(gl)

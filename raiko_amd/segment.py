@@ -10,7 +10,7 @@ accum register groups), the check polynomial evaluations, the globals and the
 circuit's tap set.
 """
 from dataclasses import dataclass, field
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -99,6 +99,9 @@ class Segment:
     n_accum_mix: int = 40
     proof_system_info: bytes = PROOF_SYSTEM_INFO
     circuit_info: bytes = CIRCUIT_INFO
+    # address of an rk_circuit_hooks (or a callable returning it): accum (groups[0]) and check are then
+    # produced inside the proof by CircuitHal::accumulate / eval_check and may be None here
+    hooks: object = None
 
     @property
     def rows(self) -> int:

@@ -45,7 +45,7 @@ class OrTaps(C.Structure):
 class OrSegment(C.Structure):
     _fields_ = [("po2", C.c_uint32), ("taps", OrTaps), ("group", C.c_void_p * 3), ("check", C.c_void_p),
                 ("globals", u32p), ("n_globals", C.c_uint32), ("n_accum_mix", C.c_uint32),
-                ("proof_system_info", C.c_uint8 * 16), ("circuit_info", C.c_uint8 * 16)]
+                ("proof_system_info", C.c_uint8 * 16), ("circuit_info", C.c_uint8 * 16), ("hooks", C.c_void_p)]
 
 
 class OrTiming(C.Structure):
@@ -84,6 +84,11 @@ def oracle():
             "or_poly_eval": (None, [vp, sz, vp, vp]),
             "or_prove_segment": (C.c_int, [C.POINTER(OrSegment), C.POINTER(u32p), C.POINTER(sz), C.c_int]),
             "or_verify_segment": (C.c_int, [C.POINTER(OrSegment), u32p, sz]),
+            "or_verify_segment_circuit": (C.c_int, [C.POINTER(OrSegment), u32p, sz, vp, vp]),
+            "or_toy_hooks": (vp, []),
+            "or_set_fast": (None, [C.c_int]), "or_get_fast": (C.c_int, []),
+            "or_prefix_products": (None, [vp, sz]),
+            "or_scatter": (None, [vp, vp, sz, vp, vp]),
             "or_free": (None, [vp]), "or_max_threads": (C.c_int, []),
             "or_last_timing": (None, [C.POINTER(OrTiming)]),
         }
@@ -158,14 +163,19 @@ def make_or_segment(seg):
         setattr(c.taps, name, a.ctypes.data_as(u32p))
     for g in range(3):
         c.taps.group_size[g] = int(t.group_size[g])
+        if seg.groups[g] is None:
+            continue
         a = np.ascontiguousarray(seg.groups[g], dtype=np.uint32)
         keep.append(a)
         c.group[g] = a.ctypes.data
     c.taps.n_regs = t.n_regs
     c.taps.n_combos = t.n_combos
-    chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
-    keep.append(chk)
-    c.check = chk.ctypes.data
+    if seg.check is not None:
+        chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
+        keep.append(chk)
+        c.check = chk.ctypes.data
+    if getattr(seg, "hooks", None) is not None:  # the toy circuit is the only one: its CPU restatement
+        c.hooks = oracle().or_toy_hooks()
     gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)
     keep.append(gl)
     c.globals = gl.ctypes.data_as(u32p)
@@ -177,25 +187,33 @@ def make_or_segment(seg):
     return c, keep
 
 
-def oracle_prove(seg, threads=0):
+def oracle_prove(seg, threads=0, fast=False):
+    """fast: the optimised operator forms of oracle/or_fast.c (cpu_baseline); same seal"""
     lib = oracle()
+    lib.or_set_fast(1 if fast else 0)
     c, keep = make_or_segment(seg)
     seal = u32p()
     n = C.c_size_t(0)
     rc = lib.or_prove_segment(C.byref(c), C.byref(seal), C.byref(n), threads)
     if rc != 0:
         raise RuntimeError(f"or_prove_segment failed: {rc}")
+    lib.or_set_fast(0)
     out = np.ctypeslib.as_array(seal, shape=(n.value,)).copy()
     lib.or_free(seal)
     del keep
     return out
 
 
-def oracle_verify(seg, seal) -> int:
+def oracle_verify(seg, seal, toy_identity=False) -> int:
+    """toy_identity: also check the toy circuit's constraint identity (or_toy_poly_ext)"""
     lib = oracle()
     c, keep = make_or_segment(seg)
     s = np.ascontiguousarray(seal, dtype=np.uint32)
-    rc = lib.or_verify_segment(C.byref(c), s.ctypes.data_as(u32p), s.size)
+    if toy_identity:
+        fn = C.cast(lib.or_toy_poly_ext, C.c_void_p)
+        rc = lib.or_verify_segment_circuit(C.byref(c), s.ctypes.data_as(u32p), s.size, fn, None)
+    else:
+        rc = lib.or_verify_segment(C.byref(c), s.ctypes.data_as(u32p), s.size)
     del keep
     return rc
 

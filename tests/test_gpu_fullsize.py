@@ -123,3 +123,21 @@ def test_po2_22_segment_verifies(hal):
     seg = synthetic_segment(22, (4, 4, 24), seed=2222)
     seal = hal.prove_segment(seg)
     assert o.oracle_verify(seg, seal) == 0
+
+
+@pytest.mark.parametrize("name", ["S18_po2_18_w16_16_224", "S20_po2_20_w16_16_224"])
+def test_baseline_size_seal_bit_exact(hal, name):
+    """BASELINE config 2 (S20: one 2^20-cycle segment, 16/16/224 columns, seed 20240807) and the
+    script's po2 = 18 (script/prove-block.sh:71), word for word against the CPU oracle run on this
+    box's host cores, and against the digest committed by tests/golden/make_seal_digests.py --large."""
+    import json
+    from test_oracle_prover import LARGE_CASES, LARGE_GOLDEN, digest
+    from raiko_amd.segment import synthetic_segment
+    po2, widths, seed = LARGE_CASES[name]
+    seg = synthetic_segment(po2, widths, seed=seed)
+    got = hal.prove_segment(seg)
+    want = o.oracle_prove(seg)
+    assert got.size == want.size and np.array_equal(got, want)
+    with open(LARGE_GOLDEN) as f:
+        golden = json.load(f)
+    assert golden[name] == {"words": int(got.size), "sha256": digest(got)}
