@@ -4,10 +4,14 @@
 A "step" is one full segment proof on one GPU: three trace groups (16 / 16 / 224 columns x 2^20
 rows) through iNTT -> zk-shift -> 4x LDE -> Poseidon2 Merkle commit, the 16-column check group,
 DEEP mixing + division, FRI (arity 16 down to degree 256) and 50 query openings, producing the
-seal.  Inputs are generated on the device before the timed region (the PCIe upload of a host
-trace is reported separately in DESIGN.md).  With N > 1 ranks every rank proves `steps` segments
-of its own (segments are independent: weak scaling) and the seals are gathered to rank 0 with one
-RCCL all_gather inside the timed region.
+seal.  The timed region is ONE call of the drop-in entry point, `rk_prove_session` (what replaces
+`session.prove()`, reference provers/risc0/driver/src/bonsai.rs:271): `steps` segments, `--inflight`
+of them in flight, every seal verified by the library's host-side verifier inside the region.
+`value` has the inputs resident in HBM when the clock starts; `value_with_h2d` is the same session
+from host-resident arrays through the library's staging ring (PCIe upload inside the region).
+With N > 1 ranks every rank proves `steps` segments of its own (segments are independent: weak
+scaling) and the seals are gathered to rank 0 with one RCCL all_gather inside the timed region;
+`--total-segments S` fixes the total instead (strong scaling: one block's segment list).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
@@ -30,17 +34,20 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,16,224", help="accum,code,data column counts")
-    ap.add_argument("--cpu-po2", type=int, default=18, help="segment size of the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-po2", type=int, default=None,
+                    help="segment size of the all-threads CPU sample (default: --po2, the GPU line's size)")
+    ap.add_argument("--cpu-po2-1t", type=int, default=16, help="segment size of the 1-thread CPU sample")
     ap.add_argument("--inflight", type=int, default=3,
                     help="segments proven concurrently per GPU (one prover context + HIP stream each); "
                          "the latency-bound parts of one proof (Merkle tops, transcript round trips) "
                          "overlap the throughput-bound parts of the other")
-    ap.add_argument("--pinned", action="store_true", help="with --host-inputs: page-locked host arrays")
-    ap.add_argument("--host-inputs", action="store_true",
-                    help="prove from pageable host arrays (PCIe upload inside the timed region); not the contract "
-                         "configuration, used for the PCIe-inclusive rate quoted in DESIGN.md")
+    ap.add_argument("--upload-ahead", type=int, default=2)
+    ap.add_argument("--total-segments", type=int, default=0,
+                    help="strong scaling: this many segments in all, sharded round-robin over the ranks "
+                         "(--steps is then ignored); default 0 = every rank proves --steps segments (weak)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (value_with_h2d) run")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="leave rk_verify_segment out of the timed region")
     return ap.parse_args()
 
 
@@ -59,6 +66,19 @@ def device_segment(torch, seg_mod, po2, widths, seed, device):
     return seg, groups, check
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     args = parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
@@ -70,8 +90,8 @@ def main():
     import torch
     import torch.distributed as dist
     from raiko_amd import segment as seg_mod
-    from raiko_amd.pipeline import SegmentPipeline
-    from raiko_amd.dist import gather_seals
+    from raiko_amd.dist import gather_seals, shard_indices
+    from raiko_amd.hal import HipHal, prove_session, session_kernel_stats, session_set_kernel_timing, verify_segment
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -89,106 +109,97 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-    # the product's own multi-context pipeline (raiko_amd/pipeline.py), the same object
-    # HipProver.run proves a session's segments with
-    n_ctx = max(1, min(args.inflight, args.steps))
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_ctx)]
-    pipe = SegmentPipeline(gpu_index, n_ctx, streams=[st.cuda_stream for st in streams])
-    hals = pipe.hals
-    hal = hals[0]
+
+    strong = args.total_segments > 0
+    total_segments = args.total_segments if strong else args.steps * world
+    my_steps = len(shard_indices(total_segments, rank, world))
+    inflight = max(1, min(args.inflight, max(my_steps, 1)))
 
     # two distinct resident segments per rank, alternated, so no step sees data it just proved
     segs = [device_segment(torch, seg_mod, args.po2, widths, 20240807 + 1000 * rank + i, device) for i in range(2)]
     torch.cuda.synchronize()
 
-    host_segs = None
-    if args.host_inputs:
-        host_segs = []
-        def to_host(t):
-            h = t.cpu()
-            if args.pinned:
-                h = h.pin_memory()
-            host_keep.append(h)
-            return h.numpy().view(np.uint32)
-
-        host_keep = []
-        for seg, groups, check in segs:
-            host_segs.append(seg_mod.Segment(po2=seg.po2, taps=seg.taps, groups=[to_host(g) for g in groups],
-                                             check=to_host(check), globals_=seg.globals_))
-
-    def job(i):
-        """(segment, device inputs) of step i"""
-        if host_segs is not None:
-            return host_segs[i % 2], None
-        seg, groups, check = segs[i % 2]
-        return seg, (groups, check)
-
-    def prove(i):
-        seg, dev = job(i)
-        return hal.prove_segment(seg, device_inputs=dev)
-
-    def prove_many(indices):
-        """prove the given step indices through the pipeline, n_ctx at a time"""
-        stage = {}
-        jobs = [job(i) for i in indices]
-
-        def on_done(j, h, seal):
-            for k, v in h.last_timing().items():
-                stage[(j, k)] = v
-
-        dev = None if host_segs is not None else [d for _, d in jobs]
-        return pipe.prove([sg for sg, _ in jobs], device_inputs=dev, on_done=on_done), stage
+    def session(n, host=None, verify=not args.no_verify):
+        """n segments through rk_prove_session: device-resident inputs (left untouched: on_device = 1)
+        or the host copies `host` through the staging ring"""
+        if n == 0:
+            return []
+        if host is not None:
+            return prove_session([host[i % 2] for i in range(n)], device=gpu_index, inflight=inflight,
+                                 upload_ahead=args.upload_ahead, verify=verify)
+        return prove_session([segs[i % 2][0] for i in range(n)], device=gpu_index, inflight=inflight,
+                             upload_ahead=args.upload_ahead, verify=verify,
+                             device_inputs=[(segs[i % 2][1], segs[i % 2][2]) for i in range(n)])
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # One serial calibration proof (also a warm-up): with a single stream the hipEvent brackets
-    # are pure kernel time, which picks the dominant kernel class; under concurrency a bracket
-    # also contains time spent queued behind the other context's kernels.
-    prove(0)  # cold: first-touch allocations, table uploads
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    # One serial calibration proof on a context of its own (also a warm-up): with a single stream
+    # the hipEvent brackets are pure kernel time, which picks the dominant kernel class; under
+    # concurrency a bracket also contains time spent queued behind the other contexts' kernels.
+    hal = HipHal(gpu_index)
+    hal.prove_segment(segs[0][0], device_inputs=(segs[0][1], segs[0][2]))  # cold: first-touch allocations, tables
     hal.set_kernel_timing(True)
-    prove(1)
+    hal.prove_segment(segs[1][0], device_inputs=(segs[1][1], segs[1][2]))
     calib = hal.kernel_stats()
+    serial_stage = hal.last_timing()
     hal.set_kernel_timing(False)
+    hal.close()
     dom_name = max(calib.items(), key=lambda kv: kv[1]["ms"])[0]
     if args.warmup:
-        warm, _ = prove_many(list(range(max(args.warmup, n_ctx))))
+        warm = session(max(args.warmup, inflight), verify=False)
         if world > 1:
             # the first collective of each kind builds RCCL's channels: keep that out of the timed
             # region, like the other one-time costs (same shapes as the timed gather)
-            pad = [warm[i % len(warm)] for i in range(args.steps)]
-            gather_seals(pad, args.steps * world, device=coll_device)
-    for h in hals:
-        h.set_kernel_timing(True)
+            pad = [warm[i % len(warm)] for i in range(my_steps)]
+            gather_seals(pad, total_segments, device=coll_device)
+    session_set_kernel_timing(gpu_index, True)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    seals, stage = prove_many(list(range(args.steps)))
-    stage_ms = {}
-    for (i, k), v in stage.items():
-        stage_ms[k] = stage_ms.get(k, 0.0) + v
+    seals = session(my_steps)
     if world > 1:
         # rank r proved global segments r, r+world, ...: gather in that order (one collective)
-        gather_seals(seals, args.steps * world, device=coll_device)
+        gather_seals(seals, total_segments, device=coll_device)
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kstats = {}
-    for h in hals:
-        for name, st in h.kernel_stats().items():
-            acc = kstats.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0})
-            for f in acc:
-                acc[f] += st[f]
-        h.set_kernel_timing(False)
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    kstats = session_kernel_stats(gpu_index)
+    session_set_kernel_timing(gpu_index, False)
+
+    # the same session from host-resident arrays: PCIe upload through the staging ring inside the region
+    elapsed_h2d = None
+    if not args.no_h2d:
+        host = []
+        for seg, groups, check in segs:
+            host.append(seg_mod.Segment(po2=seg.po2, taps=seg.taps,
+                                        groups=[g.cpu().numpy().view(np.uint32) for g in groups],
+                                        check=check.cpu().numpy().view(np.uint32), globals_=seg.globals_))
+        session(min(my_steps, inflight + args.upload_ahead), host=host, verify=False)  # staging ring warm-up
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        seals_h = session(my_steps, host=host)
+        if world > 1:
+            gather_seals(seals_h, total_segments, device=coll_device)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed_h2d = max_over_ranks(time.perf_counter() - t1)
+        same = all(np.array_equal(a, b) for a, b in zip(seals, seals_h))
+        del host
 
     if rank == 0:
-        cycles = world * args.steps * (1 << args.po2)
+        cycles = total_segments * (1 << args.po2)
         value = cycles / elapsed
+        per_step = elapsed / max(my_steps, 1)
         # dominant kernel = the class with the most device time in a serial proof (see above);
         # its numbers below are from the hipEvent brackets of the timed region
         dom = kstats[dom_name]
@@ -206,7 +217,7 @@ def main():
         if dom_name == "hash_rows_kernel" and dom["ms"] > 0:
             # the bound that actually applies: VALU issue.  peak = 256 CUs x 4 SIMDs x 16 lanes/clk x
             # 2.4 GHz (profiles/r01_ubench_isa.txt: every VALU op except plain add/sub issues at that rate)
-            perms = seg_mod.poseidon2_permutations(args.po2, widths)["hash_rows"] * args.steps
+            perms = seg_mod.poseidon2_permutations(args.po2, widths)["hash_rows"] * my_steps
             alu_peak = 256 * 4 * 16 * 2.4e9 / 1e12
             alu = perms * seg_mod.P2_VALU_PER_PERMUTATION / (dom["ms"] * 1e-3) / 1e12
             roofline["alu"] = {"achieved": round(alu, 2), "peak": round(alu_peak, 2), "unit": "T lane-instr/s",
@@ -214,7 +225,7 @@ def main():
                                "permutations_per_s": round(perms / (dom["ms"] * 1e-3) / 1e9, 3),
                                # same kernel alone on the GPU (the serial calibration proof): launches of
                                # concurrent contexts share the CUs, which stretches each bracket
-                               "serial_frac": round(perms / args.steps * seg_mod.P2_VALU_PER_PERMUTATION /
+                               "serial_frac": round(perms / max(my_steps, 1) * seg_mod.P2_VALU_PER_PERMUTATION /
                                                     (calib[dom_name]["ms"] * 1e-3) / 1e12 / alu_peak, 4),
                                "valu_per_permutation": seg_mod.P2_VALU_PER_PERMUTATION}
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -224,55 +235,65 @@ def main():
                     tr = json.load(f)
                 if tr.get("kernel") == dom_name:
                     roofline["traffic"] = tr.get("bytes_per_launch")
+                    roofline["traffic_source"] = ("profiles/hbm_traffic.json: PMC FETCH_SIZE/WRITE_SIZE of an earlier "
+                                                  "rocprofv3 run of this kernel (%s), not measured in this run" % tr.get("source", "see file"))
             except Exception:
                 pass
-        kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] / args.steps,
+        kernels = {k: {"ms_per_step": round(v["ms"] / max(my_steps, 1), 3), "launches_per_step": v["launches"] / max(my_steps, 1),
                        "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
                    for k, v in kstats.items()}
         algo = seg_mod.algorithmic_bytes(args.po2, widths)
         out = {
             "metric": "proven RISC-V cycles/sec", "value": round(value, 1), "unit": "cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)",
-            "data": "synthetic" + (" (host-resident inputs, PCIe upload timed)" if args.host_inputs else ""),
+            "ms_per_step": round(per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
             "config": {"workload": "S%d: one 2^%d-cycle segment proof, W=%s (accum/code/data) + 16 check columns, "
                                    "blow-up 4, Poseidon2 Merkle, FRI arity 16, 50 queries" % (args.po2, args.po2, args.widths),
-                       "segments_per_gpu_per_step": 1, "segments_in_flight_per_gpu": n_ctx,
-                       "parallelism": "segment-parallel x%d" % world},
+                       "entry_point": "rk_prove_session (on_device = 1 inputs, verify = %d)" % (0 if args.no_verify else 1),
+                       "segments_per_gpu_per_step": 1, "segments_in_flight_per_gpu": inflight,
+                       "total_segments": total_segments, "parallelism": "segment-parallel x%d" % world},
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_segment": algo["total"],
-                         "hbm_frac_end_to_end": round(algo["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-                         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+                         "hbm_frac_end_to_end": round(algo["total"] / per_step / 1e9 / HBM_PEAK_GBS, 5),
+                         "serial_stage_ms": {k: round(v, 3) for k, v in serial_stage.items()},
                          "kernels": kernels},
         }
-        if not args.no_verify:
-            # outside the timed region: the last seal must pass the product's host-side verifier
-            # (rk_verify_segment; it needs only the public data of the segment)
-            from raiko_amd.hal import verify_segment
-            seg, groups, check = segs[(args.steps - 1) % 2]
-            out["seal_verified"] = verify_segment(seg, seals[-1]) == 0
+        if elapsed_h2d is not None:
+            out["value_with_h2d"] = round(cycles / elapsed_h2d, 1)
+            out["ms_per_step_with_h2d"] = round(elapsed_h2d / max(my_steps, 1) * 1e3, 3)
+            out["h2d_seals_identical"] = bool(same)
+        if seals:
+            # every seal was verified inside the timed region unless --no-verify; check the last one here too
+            out["seal_verified"] = verify_segment(segs[(my_steps - 1) % 2][0], seals[-1]) == 0
             out["seal_words"] = int(seals[-1].size)
         if not args.no_cpu and world == 1:
-            # the cpu_baseline leg is the only place bench.py touches oracle/ (test infrastructure)
+            # the cpu_baseline leg is the only place bench.py touches oracle/ (test infrastructure):
+            # its optimised operator forms (oracle/or_fast.c), the same seal as the plain restatement
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
-            cseg = seg_mod.synthetic_segment(args.cpu_po2, widths, seed=1)
-            threads = oracle_lib.oracle().or_max_threads()
+            cores = usable_cores()
+            cpu_po2 = args.cpu_po2 if args.cpu_po2 is not None else args.po2
+            cseg = seg_mod.synthetic_segment(cpu_po2, widths, seed=20240807)
             t1 = time.perf_counter()
-            oracle_lib.oracle_prove(cseg, threads=threads)
+            oracle_lib.oracle_prove(cseg, threads=cores, fast=True)
             dt = time.perf_counter() - t1
+            cseg1 = seg_mod.synthetic_segment(args.cpu_po2_1t, widths, seed=20240807)
+            t1 = time.perf_counter()
+            oracle_lib.oracle_prove(cseg1, threads=1, fast=True)
+            dt1 = time.perf_counter() - t1
             out["cpu_baseline"] = {
-                "value": round((1 << args.cpu_po2) / dt, 1), "unit": "cycles/s", "cores": threads, "kind": "port",
-                "sample": "one 2^%d-cycle segment of the same column layout proven by oracle/ (OpenMP, %d threads) "
-                          "in %.2f s; the risc0 binary itself cannot be built here (no Rust toolchain)" % (args.cpu_po2, threads, dt),
+                "value": round((1 << cpu_po2) / dt, 1), "unit": "cycles/s", "cores": cores, "kind": "port",
+                "value_1_thread": round((1 << args.cpu_po2_1t) / dt1, 1),
+                "sample": "one 2^%d-cycle segment of the same column layout proven by oracle/ with its AVX2 / table-driven "
+                          "operator forms (or_fast.c; OpenMP, %d threads = the cores this process may use) in %.2f s; "
+                          "1 thread: one 2^%d-cycle segment in %.2f s.  The risc0 binary itself cannot be built here "
+                          "(no Rust toolchain)" % (cpu_po2, cores, dt, args.cpu_po2_1t, dt1),
             }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for h in hals:
-        h.close()
 
 
 if __name__ == "__main__":

@@ -200,7 +200,7 @@ def load_receipt(label: str) -> Optional[Receipt]:
 def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inflight: int = 3) -> Receipt:
     """bonsai.rs:230-272 from the point the executor has produced the session: prove every
     segment (this rank's shard when torch.distributed is initialised), `inflight` at a time on
-    the GPU (raiko_amd/pipeline.py), and assemble the receipt."""
+    the GPU (rk_prove_session), and assemble the receipt."""
     from . import dist as rdist
     for s in session.segments:
         if s.po2 > segment_limit_po2:

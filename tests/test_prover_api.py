@@ -67,52 +67,6 @@ def test_receipt_roundtrip_and_cache(tmp_path, monkeypatch):
     assert pv.HipProver.last_journal_matches is True
 
 
-class _FakeHal:
-    """stands in for HipHal in the scheduling logic of SegmentPipeline (no GPU in the CPU suite)"""
-
-    def __init__(self, delay=0.0, fail_on=None):
-        self.delay, self.fail_on, self.seen = delay, fail_on, []
-
-    def prove_segment(self, seg, device_inputs=None):
-        import time
-        time.sleep(self.delay)
-        if seg == self.fail_on:
-            raise RuntimeError("boom %s" % seg)
-        self.seen.append(seg)
-        return np.array([seg, 0 if device_inputs is None else device_inputs], dtype=np.uint32)
-
-    def close(self):
-        pass
-
-
-def _fake_pipeline(hals):
-    from raiko_amd.pipeline import SegmentPipeline
-    p = SegmentPipeline.__new__(SegmentPipeline)
-    p.device, p.hals, p.upload_ahead, p._uploader, p._ring = 0, hals, 0, None, []
-    return p
-
-
-def test_pipeline_keeps_segment_order_and_balances():
-    slow, fast = _FakeHal(0.02), _FakeHal(0.0)
-    pipe = _fake_pipeline([slow, fast])
-    done = []
-    seals = pipe.prove(list(range(12)), device_inputs=[10 + i for i in range(12)], on_done=lambda i, h, seal: done.append((i, int(seal[0]))))
-    assert [int(s[0]) for s in seals] == list(range(12))
-    assert [int(s[1]) for s in seals] == [10 + i for i in range(12)]
-    assert sorted(done) == [(i, i) for i in range(12)]
-    # shared queue, not a static split: the fast context takes most of the work
-    assert len(fast.seen) > len(slow.seen)
-
-
-def test_pipeline_single_segment_and_errors():
-    pipe = _fake_pipeline([_FakeHal(), _FakeHal()])
-    assert [int(s[0]) for s in pipe.prove([7])] == [7]
-    assert pipe.prove([]) == []
-    bad = _fake_pipeline([_FakeHal(fail_on=3), _FakeHal(fail_on=3)])
-    with pytest.raises(RuntimeError, match="boom 3"):
-        bad.prove(list(range(8)))
-
-
 def test_permutation_count_of_s20():
     from raiko_amd.segment import poseidon2_permutations
     c = poseidon2_permutations(20, (16, 16, 224))
@@ -122,75 +76,6 @@ def test_permutation_count_of_s20():
     assert c["hash_fold"] == 4 * (d - 1) + sum(x - 1 for x in fri_leaves)
     # ragged widths round up to whole sponge blocks
     assert poseidon2_permutations(10, (3, 5, 33))["hash_rows"] == (1 << 12) * (1 + 1 + 3 + 1) + 4 * (1 << 12) // 16
-
-
-class _FakeBuf:
-    def __init__(self, words):
-        self.words, self.data, self.freed = words, None, False
-
-    def copy_from(self, a):
-        assert a.size == self.words
-        self.data = a.copy()
-        return self
-
-    def free(self):
-        self.freed = True
-
-
-class _FakeUploader:
-    def __init__(self, fail_at=None):
-        self.allocs, self.syncs, self.fail_at = 0, 0, fail_at
-
-    def alloc_elem(self, words):
-        self.allocs += 1
-        return _FakeBuf(words)
-
-    def sync(self):
-        self.syncs += 1
-        if self.fail_at is not None and self.syncs == self.fail_at:
-            raise RuntimeError("upload failed")
-
-    def close(self):
-        pass
-
-
-class _CheckingHal(_FakeHal):
-    """proves from staged buffers: they must hold exactly the segment's host arrays"""
-
-    def prove_segment(self, seg, device_inputs=None):
-        groups, check = device_inputs
-        for g in range(3):
-            assert np.array_equal(groups[g].data.reshape(seg.groups[g].shape), seg.groups[g])
-        assert np.array_equal(check.data.reshape(seg.check.shape), seg.check)
-        import time
-        time.sleep(self.delay)
-        return np.array([int(seg.globals_[0])], dtype=np.uint32)
-
-
-def test_pipeline_stages_host_segments_ahead():
-    segs = [synthetic_segment(4, (2, 2, 3), seed=50 + i) for i in range(9)]
-    segs += [synthetic_segment(5, (2, 2, 3), seed=70)]  # a different shape forces one slot to be re-allocated
-    pipe = _fake_pipeline([_CheckingHal(0.002), _CheckingHal(0.0)])
-    pipe.upload_ahead, pipe._uploader = 2, _FakeUploader()
-    seals = pipe.prove(segs)
-    assert [int(s[0]) for s in seals] == [int(s.globals_[0]) for s in segs]
-    assert len(pipe._ring) == 4                      # upload_ahead + inflight slots: the stager runs ahead
-    assert pipe._uploader.syncs == len(segs)
-    assert pipe._uploader.allocs <= 4 * (len(pipe._ring) + 1)
-    # a second session reuses the ring
-    before = pipe._uploader.allocs
-    pipe.prove(segs[:4])
-    assert pipe._uploader.allocs - before <= 4       # only the slot that held the odd shape
-    pipe.close()
-    assert pipe._ring == []
-
-
-def test_pipeline_upload_error_surfaces():
-    segs = [synthetic_segment(4, (2, 2, 3), seed=90 + i) for i in range(6)]
-    pipe = _fake_pipeline([_CheckingHal(), _CheckingHal()])
-    pipe.upload_ahead, pipe._uploader = 1, _FakeUploader(fail_at=3)
-    with pytest.raises(RuntimeError, match="upload failed"):
-        pipe.prove(segs)
 
 
 def test_journal_word_serde_roundtrip():
