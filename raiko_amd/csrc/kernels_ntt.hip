@@ -3,7 +3,10 @@
 // Each pass: one workgroup per 2^g x T tile, tile staged in LDS (<= 64 KiB so two
 // workgroups share a CU's 160 KiB), coalesced tile rows of T consecutive elements.
 #include "internal.hpp"
-#include "ntt_r16.hpp"
+#include "ntt_fused.hpp"
+
+#include <mutex>
+#include <tuple>
 
 namespace {
 
@@ -56,46 +59,66 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel_u(ntt::PassArgs a, ntt::
     }
 }
 
-// register-blocked passes on full 2^14 tiles (ntt_r16.hpp)
-template <bool FWD, int NST>
-__device__ __forceinline__ void r16_round(uint32_t* v, const ntt::Tables& tb, unsigned ls, unsigned rlow) {
-    if (FWD) r16::round_dit<NST>(v, tb.small[0], ls, rlow);
-    else r16::round_dif<NST>(v, tb.small[1], ls, rlow);
-}
+// shape-specialised two-pass kernels for 2^18 .. 2^22 points (ntt_fused.hpp).
 // 8 waves per SIMD (<= 64 VGPRs): two 1024-lane workgroups per CU, so one group's barriers and LDS
 // round trips are covered by the other's arithmetic
-template <bool FWD, bool CONTIG>
-__global__ __launch_bounds__(1024, 8) void ntt_r16_kernel(r16::Args a, ntt::Tables tb, r16::Sched sc) {
-    __shared__ uint32_t lds[r16::LDS_WORDS];
+template <bool EXPAND>
+__global__ __launch_bounds__(1024, 8) void nf_fwd_contig_kernel(nf::Args a, ntt::Tables tb) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[nf::LDS_WORDS];
     const unsigned tid = threadIdx.x;
-    const r16::Tile t = r16::tile_of(a, blockIdx.x);
-    if (CONTIG) {
-        if (FWD) r16::load_fwd_contig(a, t, lds, tid);
-        else r16::load_rev_contig(a, tb, t, lds, tid);
+    const nf::CTile t = nf::ctile_of(a, blockIdx.x, EXPAND ? 2 : 0);
+    if (EXPAND) {
+        nf::fwd_contig_a(a, tb, t, lds, tid);
     } else {
-        r16::load_plain(a, t, lds, tid);
+        nf::fwd_contig0_a(a, tb, t, lds, tid);
+        __syncthreads();
+        nf::fwd_contig0_b(tb, lds, tid);
     }
     __syncthreads();
-    for (unsigned rd = 0; rd < sc.n; rd++) {
-        const unsigned ls = sc.ls[rd];
-        const r16::RoundIdx x = r16::round_idx(tid, a.g, ls);
-        uint32_t v[16];
-        r16::round_read(v, lds, x);
-        switch (sc.nst[rd]) {
-            case 4: r16_round<FWD, 4>(v, tb, ls, x.rlow); break;
-            case 3: r16_round<FWD, 3>(v, tb, ls, x.rlow); break;
-            case 2: r16_round<FWD, 2>(v, tb, ls, x.rlow); break;
-            default: r16_round<FWD, 1>(v, tb, ls, x.rlow); break;
+    nf::fwd_contig_b(tb, lds, tid);
+    __syncthreads();
+    nf::fwd_contig_c(a, tb, t, lds, tid);
+}
+__global__ __launch_bounds__(1024, 8) void nf_inv_contig_kernel(nf::Args a, ntt::Tables tb) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[nf::LDS_WORDS];
+    const unsigned tid = threadIdx.x;
+    const nf::CTile t = nf::ctile_of(a, blockIdx.x, 0);
+    nf::inv_contig_a(a, tb, t, lds, tid);
+    __syncthreads();
+    nf::inv_contig_mid<6>(tb, lds, tid);
+    __syncthreads();
+    nf::inv_contig_mid<2>(tb, lds, tid);
+    __syncthreads();
+    nf::inv_contig_d(tb, lds, tid);
+    __syncthreads();
+    nf::inv_contig_e(a, t, lds, tid);
+}
+template <bool FWD, int G>
+__global__ __launch_bounds__(1024, 8) void nf_strided_kernel(nf::Args a, ntt::Tables tb) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[G > 4 ? nf::LDS_WORDS : 4];
+    const unsigned tid = threadIdx.x;
+    const nf::STile<G> t = nf::stile_of<G>(a, blockIdx.x);
+    if (FWD) {
+        if (G > 4) {
+            nf::fwd_strided_a<G>(a, tb, t, lds, tid);
+            __syncthreads();
         }
-        r16::round_write(v, lds, x);
-        __syncthreads();
-    }
-    if (CONTIG) {
-        if (FWD) r16::store_fwd_contig(a, tb, t, lds, tid);
-        else r16::store_rev_contig(a, tb, t, lds, tid);
+        nf::fwd_strided_b<G>(a, tb, t, lds, tid);
     } else {
-        r16::store_plain<FWD>(a, t, lds, tid);
+        nf::inv_strided_a<G>(a, tb, t, lds, tid);
+        if (G > 4) {
+            __syncthreads();
+            nf::inv_strided_b<G>(a, tb, t, lds, tid);
+        }
     }
+}
+__global__ void nf_fs_table_kernel(uint32_t* out, size_t n, unsigned k, int dir, ntt::Tables tb) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = nf::fs_entry(tb, k, dir, idx);
+}
+__global__ void nf_zk_table_kernel(uint32_t* out, size_t n, unsigned k, uint32_t scale, ntt::Tables tb) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = nf::zk_entry(tb, k, scale, idx);
 }
 
 __global__ void zk_shift_kernel(uint32_t* io, size_t total, size_t size, unsigned bits, ntt::Tables tb) {
@@ -144,15 +167,79 @@ int launch_pass(rk_ctx* ctx, const ntt::PassArgs& a, size_t count) {
     return rk::post_launch(ctx, FWD ? "ntt_pass_kernel<fwd>" : "ntt_pass_kernel<rev>");
 }
 
-template <bool FWD, bool CONTIG>
-int launch_r16(rk_ctx* ctx, const r16::Args& a, size_t count) {
-    size_t blocks = count * (a.n >> r16::TILE_LOG);
+// per-size tables of the fused kernels, shared by every context of a device for the life of the
+// process (immutable once built): kind 0 / 1 = four-step twiddles forward / inverse, 2 = zk * 1/n
+std::mutex g_nf_mu;
+std::map<std::tuple<int, int, unsigned>, uint32_t*> g_nf_tables;
+int nf_table(rk_ctx* ctx, int kind, unsigned k, const uint32_t** out) {
+    std::lock_guard<std::mutex> l(g_nf_mu);
+    auto key = std::make_tuple(ctx->device, kind, k);
+    auto it = g_nf_tables.find(key);
+    if (it != g_nf_tables.end()) {
+        *out = it->second;
+        return RK_OK;
+    }
+    const size_t n = (size_t)1 << k;
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->last_error = "hipMalloc (NTT table)";
+        return RK_ERR_NOMEM;
+    }
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (kind == 2) {
+        uint32_t scale = bb::inv(bb::encode((uint32_t)n));
+        hipLaunchKernelGGL(nf_zk_table_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, n, k, scale, ctx->tb);
+    } else {
+        hipLaunchKernelGGL(nf_fs_table_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, n, k, kind, ctx->tb);
+    }
+    int st = rk::post_launch(ctx, "nf_table_kernel");
+    // other contexts (other streams) read the table as soon as this returns
+    if (st == RK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ctx->last_error = "NTT table build";
+        st = RK_ERR_HIP;
+    }
+    if (st != RK_OK) {
+        (void)hipFree(d);
+        return st;
+    }
+    g_nf_tables[key] = d;
+    *out = d;
+    return RK_OK;
+}
+
+template <bool FWD>
+int launch_nf_strided(rk_ctx* ctx, const nf::Args& a) {
+    size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
     if (blocks == 0 || blocks > 0x7fffffffu) return RK_ERR_INVALID;
-    r16::Sched sc = FWD ? r16::sched_dit(a.g, a.expand_bits) : r16::sched_dif(a.g);
-    rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)count * 4 * (a.n_src + a.n));
-    hipLaunchKernelGGL((ntt_r16_kernel<FWD, CONTIG>), dim3((unsigned)blocks), dim3(r16::NTHR), 0, ctx->stream, a, ctx->tb,
-                       sc);
-    return rk::post_launch(ctx, "ntt_r16_kernel");
+    rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)a.count * 8 * a.n);
+    dim3 grid((unsigned)blocks), blk(nf::NTHR);
+    switch (a.k - nf::TILE_LOG) {
+        case 4: hipLaunchKernelGGL((nf_strided_kernel<FWD, 4>), grid, blk, 0, ctx->stream, a, ctx->tb); break;
+        case 5: hipLaunchKernelGGL((nf_strided_kernel<FWD, 5>), grid, blk, 0, ctx->stream, a, ctx->tb); break;
+        case 6: hipLaunchKernelGGL((nf_strided_kernel<FWD, 6>), grid, blk, 0, ctx->stream, a, ctx->tb); break;
+        case 7: hipLaunchKernelGGL((nf_strided_kernel<FWD, 7>), grid, blk, 0, ctx->stream, a, ctx->tb); break;
+        case 8: hipLaunchKernelGGL((nf_strided_kernel<FWD, 8>), grid, blk, 0, ctx->stream, a, ctx->tb); break;
+        default: return RK_ERR_INVALID;
+    }
+    return rk::post_launch(ctx, "nf_strided_kernel");
+}
+int launch_nf_fwd_contig(rk_ctx* ctx, const nf::Args& a, unsigned expand_bits) {
+    size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
+    if (blocks == 0 || blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)a.count * 4 * (a.n_src + a.n));
+    if (expand_bits)
+        hipLaunchKernelGGL(nf_fwd_contig_kernel<true>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
+    else
+        hipLaunchKernelGGL(nf_fwd_contig_kernel<false>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
+    return rk::post_launch(ctx, "nf_fwd_contig_kernel");
+}
+int launch_nf_inv_contig(rk_ctx* ctx, const nf::Args& a) {
+    size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
+    if (blocks == 0 || blocks > 0x7fffffffu) return RK_ERR_INVALID;
+    rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)a.count * 8 * a.n);
+    hipLaunchKernelGGL(nf_inv_contig_kernel, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
+    return rk::post_launch(ctx, "nf_inv_contig_kernel");
 }
 inline bool aligned16(const void* p, const void* q) { return ((((uintptr_t)p) | ((uintptr_t)q)) & 15) == 0; }
 
@@ -168,19 +255,20 @@ int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fus
         // size-1 transform: identity (1/1 scale, 3^0 shift)
         return RK_OK;
     }
-    if (r16::usable(k, 0, aligned16(d_io, d_io))) {
-        r16::Args a{};
+    if (nf::usable(k, 0, aligned16(d_io, d_io)) && count <= 0xffffffffu) {
+        // strided pass (top k - 14 stages), then 2^14-point sub-transforms with the four-step twiddle on
+        // the way in and 1/n (and the zk shift) on the way out
+        nf::Args a{};
         a.dst = d_io;
         a.src = d_io;
         a.n = a.n_src = size;
         a.k = k;
-        a.g = k - r16::TILE_LOG;
-        RK_TRY((launch_r16<false, false>(ctx, a, count)));
-        a.g_outer = a.g;
-        a.g = r16::TILE_LOG;
+        a.count = (unsigned)count;
+        RK_TRY(launch_nf_strided<false>(ctx, a));
+        RK_TRY(nf_table(ctx, 1, k, &a.fs));
+        if (fuse_zk_shift) RK_TRY(nf_table(ctx, 2, k, &a.zk));
         a.scale = scale;
-        a.zk = fuse_zk_shift ? 1 : 0;
-        return launch_r16<false, true>(ctx, a, count);
+        return launch_nf_inv_contig(ctx, a);
     }
     ntt::Plan plan = ntt::make_plan(k);
     for (unsigned p = 0; p < plan.npass; p++) {
@@ -212,23 +300,21 @@ int ntt_forward(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_si
             RK_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
         return RK_OK;
     }
-    if (r16::usable(k, expand_bits, aligned16(d_out, d_in))) {
-        r16::Args a{};
+    if (nf::usable(k, expand_bits, aligned16(d_out, d_in)) && count <= 0xffffffffu) {
+        // 2^14-point sub-transforms (expanding 4x on the fly) with the four-step twiddle on the way
+        // out, then the strided pass over the result
+        nf::Args a{};
         a.dst = d_out;
         a.src = d_in;
         a.n = size;
         a.n_src = in_size;
         a.k = k;
-        a.g = r16::TILE_LOG;
-        a.g_outer = k - r16::TILE_LOG;
-        a.expand_bits = expand_bits;
-        RK_TRY((launch_r16<true, true>(ctx, a, count)));
+        a.count = (unsigned)count;
+        RK_TRY(nf_table(ctx, 0, k, &a.fs));
+        RK_TRY(launch_nf_fwd_contig(ctx, a, expand_bits));
         a.src = d_out;
         a.n_src = size;
-        a.g = k - r16::TILE_LOG;
-        a.g_outer = 0;
-        a.expand_bits = 0;
-        return launch_r16<true, false>(ctx, a, count);
+        return launch_nf_strided<true>(ctx, a);
     }
     if (expand_bits == 0 && d_out != d_in) {
         RK_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, count * size * sizeof(uint32_t), hipMemcpyDeviceToDevice,

@@ -8,7 +8,7 @@
 
 #include "bb.hpp"
 #include "ntt_core.hpp"
-#include "ntt_r16.hpp"
+#include "ntt_fused.hpp"
 #include "poseidon2_core.hpp"
 #include "poseidon2_consts.inc"
 
@@ -77,47 +77,71 @@ void run_pass(const ntt::PassArgs& a, size_t count, unsigned nthr) {
         }
     }
 }
-// mirrors ntt_r16_kernel / launch_r16 of kernels_ntt.hip
-template <bool FWD, bool CONTIG>
-void run_r16(const r16::Args& a, size_t count) {
-    size_t blocks = count * (a.n >> r16::TILE_LOG);
-    r16::Sched sc = FWD ? r16::sched_dit(a.g, a.expand_bits) : r16::sched_dif(a.g);
-    std::vector<uint32_t> lds(r16::LDS_WORDS);
+// mirrors the nf_* kernels of kernels_ntt.hip (ntt_fused.hpp): phases in program order, every lane
+// of a phase before the next phase (= the barriers of the GPU kernels)
+std::vector<uint32_t> nf_table(int kind, unsigned k) {
+    size_t n = (size_t)1 << k;
+    std::vector<uint32_t> t(n);
+    uint32_t scale = bb::inv(bb::encode((uint32_t)n));
+    for (size_t i = 0; i < n; i++) t[i] = kind == 2 ? nf::zk_entry(g_tb, k, scale, i) : nf::fs_entry(g_tb, k, kind, i);
+    return t;
+}
+template <class F>
+void all_lanes(F&& f) {
+    for (unsigned tid = 0; tid < nf::NTHR; tid++) f(tid);
+}
+template <bool FWD, int G>
+void run_nf_strided_g(const nf::Args& a) {
+    size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
+    std::vector<uint32_t> lds(nf::LDS_WORDS);
     for (size_t blk = 0; blk < blocks; blk++) {
-        r16::Tile t = r16::tile_of(a, blk);
-        for (unsigned tid = 0; tid < r16::NTHR; tid++) {
-            if (CONTIG) {
-                if (FWD) r16::load_fwd_contig(a, t, lds.data(), tid);
-                else r16::load_rev_contig(a, g_tb, t, lds.data(), tid);
-            } else {
-                r16::load_plain(a, t, lds.data(), tid);
-            }
+        nf::STile<G> t = nf::stile_of<G>(a, blk);
+        if (FWD) {
+            if (G > 4) all_lanes([&](unsigned tid) { nf::fwd_strided_a<G>(a, g_tb, t, lds.data(), tid); });
+            // in-place pass: every lane's loads of a phase come before any lane's stores on the GPU only
+            // because tiles are disjoint and phase b's loads (G == 4) read what nobody else writes
+            all_lanes([&](unsigned tid) { nf::fwd_strided_b<G>(a, g_tb, t, lds.data(), tid); });
+        } else {
+            all_lanes([&](unsigned tid) { nf::inv_strided_a<G>(a, g_tb, t, lds.data(), tid); });
+            if (G > 4) all_lanes([&](unsigned tid) { nf::inv_strided_b<G>(a, g_tb, t, lds.data(), tid); });
         }
-        for (unsigned rd = 0; rd < sc.n; rd++) {
-            unsigned ls = sc.ls[rd];
-            // all lanes read, then all lanes write: a round is in place per lane, so lane order is free
-            for (unsigned tid = 0; tid < r16::NTHR; tid++) {
-                r16::RoundIdx x = r16::round_idx(tid, a.g, ls);
-                uint32_t v[16];
-                r16::round_read(v, lds.data(), x);
-                const uint32_t* tw = g_tb.small[FWD ? 0 : 1];
-                switch (sc.nst[rd]) {
-                    case 4: FWD ? r16::round_dit<4>(v, tw, ls, x.rlow) : r16::round_dif<4>(v, tw, ls, x.rlow); break;
-                    case 3: FWD ? r16::round_dit<3>(v, tw, ls, x.rlow) : r16::round_dif<3>(v, tw, ls, x.rlow); break;
-                    case 2: FWD ? r16::round_dit<2>(v, tw, ls, x.rlow) : r16::round_dif<2>(v, tw, ls, x.rlow); break;
-                    default: FWD ? r16::round_dit<1>(v, tw, ls, x.rlow) : r16::round_dif<1>(v, tw, ls, x.rlow); break;
-                }
-                r16::round_write(v, lds.data(), x);
-            }
+    }
+}
+template <bool FWD>
+void run_nf_strided(const nf::Args& a) {
+    switch (a.k - nf::TILE_LOG) {
+        case 4: run_nf_strided_g<FWD, 4>(a); break;
+        case 5: run_nf_strided_g<FWD, 5>(a); break;
+        case 6: run_nf_strided_g<FWD, 6>(a); break;
+        case 7: run_nf_strided_g<FWD, 7>(a); break;
+        default: run_nf_strided_g<FWD, 8>(a); break;
+    }
+}
+void run_nf_fwd_contig(const nf::Args& a, unsigned expand_bits) {
+    size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
+    std::vector<uint32_t> lds(nf::LDS_WORDS);
+    for (size_t blk = 0; blk < blocks; blk++) {
+        nf::CTile t = nf::ctile_of(a, blk, expand_bits);
+        if (expand_bits) {
+            all_lanes([&](unsigned tid) { nf::fwd_contig_a(a, g_tb, t, lds.data(), tid); });
+        } else {
+            all_lanes([&](unsigned tid) { nf::fwd_contig0_a(a, g_tb, t, lds.data(), tid); });
+            all_lanes([&](unsigned tid) { nf::fwd_contig0_b(g_tb, lds.data(), tid); });
         }
-        for (unsigned tid = 0; tid < r16::NTHR; tid++) {
-            if (CONTIG) {
-                if (FWD) r16::store_fwd_contig(a, g_tb, t, lds.data(), tid);
-                else r16::store_rev_contig(a, g_tb, t, lds.data(), tid);
-            } else {
-                r16::store_plain<FWD>(a, t, lds.data(), tid);
-            }
-        }
+        all_lanes([&](unsigned tid) { nf::fwd_contig_b(g_tb, lds.data(), tid); });
+        all_lanes([&](unsigned tid) { nf::fwd_contig_c(a, g_tb, t, lds.data(), tid); });
+    }
+}
+void run_nf_inv_contig(const nf::Args& a) {
+    size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
+    std::vector<uint32_t> lds(nf::LDS_WORDS);
+    for (size_t blk = 0; blk < blocks; blk++) {
+        nf::CTile t = nf::ctile_of(a, blk, 0);
+        all_lanes([&](unsigned tid) { nf::inv_contig_a(a, g_tb, t, lds.data(), tid); });
+        all_lanes([&](unsigned tid) { nf::inv_contig_mid<6>(g_tb, lds.data(), tid); });
+        all_lanes([&](unsigned tid) { nf::inv_contig_mid<2>(g_tb, lds.data(), tid); });
+        all_lanes([&](unsigned tid) { nf::inv_contig_d(g_tb, lds.data(), tid); });
+        all_lanes([&](unsigned tid) { nf::inv_contig_e(a, t, lds.data(), tid); });
     }
 }
 inline bool aligned16(const void* p, const void* q) { return ((((uintptr_t)p) | ((uintptr_t)q)) & 15) == 0; }
@@ -136,12 +160,15 @@ int emul_ntt_reverse(uint32_t* io, size_t size, size_t count, int fuse_zk, unsig
     unsigned k = log2u(size);
     if (k == 0) return 0;
     uint32_t scale = bb::inv(bb::encode((uint32_t)size));
-    if (max_tile_log == ntt::MAX_TILE_LOG && r16::usable(k, 0, aligned16(io, io))) {
-        r16::Args a{};
-        a.dst = io; a.src = io; a.n = a.n_src = size; a.k = k; a.g = k - r16::TILE_LOG;
-        run_r16<false, false>(a, count);
-        a.g_outer = a.g; a.g = r16::TILE_LOG; a.scale = scale; a.zk = fuse_zk ? 1 : 0;
-        run_r16<false, true>(a, count);
+    if (max_tile_log == ntt::MAX_TILE_LOG && nf::usable(k, 0, aligned16(io, io))) {
+        nf::Args a{};
+        a.dst = io; a.src = io; a.n = a.n_src = size; a.k = k; a.count = (unsigned)count;
+        run_nf_strided<false>(a);
+        std::vector<uint32_t> fs = nf_table(1, k), zk;
+        a.fs = fs.data();
+        if (fuse_zk) { zk = nf_table(2, k); a.zk = zk.data(); }
+        a.scale = scale;
+        run_nf_inv_contig(a);
         return 102;
     }
     ntt::Plan plan = ntt::make_plan(k, max_tile_log);
@@ -163,13 +190,14 @@ int emul_ntt_forward(uint32_t* out, const uint32_t* in, size_t in_size, size_t c
     size_t size = in_size << expand_bits;
     unsigned k = log2u(size);
     if (k == 0) { std::memcpy(out, in, count * 4); return 0; }
-    if (max_tile_log == ntt::MAX_TILE_LOG && r16::usable(k, expand_bits, aligned16(out, in))) {
-        r16::Args a{};
-        a.dst = out; a.src = in; a.n = size; a.n_src = in_size; a.k = k; a.g = r16::TILE_LOG;
-        a.g_outer = k - r16::TILE_LOG; a.expand_bits = expand_bits;
-        run_r16<true, true>(a, count);
-        a.src = out; a.n_src = size; a.g = k - r16::TILE_LOG; a.g_outer = 0; a.expand_bits = 0;
-        run_r16<true, false>(a, count);
+    if (max_tile_log == ntt::MAX_TILE_LOG && nf::usable(k, expand_bits, aligned16(out, in))) {
+        nf::Args a{};
+        a.dst = out; a.src = in; a.n = size; a.n_src = in_size; a.k = k; a.count = (unsigned)count;
+        std::vector<uint32_t> fs = nf_table(0, k);
+        a.fs = fs.data();
+        run_nf_fwd_contig(a, expand_bits);
+        a.src = out; a.n_src = size;
+        run_nf_strided<true>(a);
         return 102;
     }
     if (expand_bits == 0 && out != in) { std::memcpy(out, in, count * size * 4); in = out; }

@@ -28,7 +28,7 @@ def build_oracle(force=False):
 def build_emul(force=False):
     csrc = os.path.join(ROOT, "raiko_amd", "csrc")
     srcs = [os.path.join(EMUL_DIR, "emul.cpp")] + [os.path.join(csrc, f) for f in
-                                                   ("bb.hpp", "ntt_core.hpp", "poseidon2_core.hpp", "poseidon2_consts.inc")]
+                                                   ("bb.hpp", "ntt_core.hpp", "ntt_fused.hpp", "poseidon2_core.hpp", "poseidon2_consts.inc")]
     if not force and os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs):
         return EMUL_SO
     os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)

@@ -39,17 +39,18 @@ def test_ntt_passes_match_oracle(orc, emu, k, max_tile_log, nthr):
     assert np.array_equal(back, x)
 
 
-@pytest.mark.parametrize("k", [18, 19, 21])
-def test_register_blocked_passes_match_oracle(orc, emu, k):
-    """ntt_r16.hpp (the path taken for 2^18..2^22 points): strided radix-16 rounds + contiguous
-    pass carrying the four-step twiddle, fused 1/n and zk shift, 4x expanding forward pass"""
+@pytest.mark.parametrize("k,cnt", [(18, 3), (19, 2), (20, 1), (21, 1), (22, 1)])
+def test_register_blocked_passes_match_oracle(orc, emu, k, cnt):
+    """ntt_fused.hpp (the path taken for 2^18..2^22 points; k - 14 = 4..8 strided stages): rounds of
+    four stages on 16 registers, first / last round of a pass straight from / to global memory,
+    table-driven four-step twiddle, 1/n and zk shift, 4x expanding forward pass"""
     rng = np.random.default_rng(4000 + k)
-    n, cnt = 1 << k, 1
+    n = 1 << k
     x = o.rand_elems(rng, (cnt, n))
     want = x.copy()
     orc.or_batch_interpolate_ntt(want.ctypes.data, n, cnt)
     got = x.copy()
-    assert emu.emul_ntt_reverse(got.ctypes.data, n, cnt, 0, 14, 64) == 102  # 102 = r16 path taken
+    assert emu.emul_ntt_reverse(got.ctypes.data, n, cnt, 0, 14, 64) == 102  # 102 = fused path taken
     assert np.array_equal(got, want)
     want_zk = want.copy()
     orc.or_zk_shift(want_zk.ctypes.data, n, cnt)
@@ -59,7 +60,7 @@ def test_register_blocked_passes_match_oracle(orc, emu, k):
     back = want.copy()
     assert emu.emul_ntt_forward(back.ctypes.data, back.ctypes.data, n, cnt, 0, 14, 64) == 102
     assert np.array_equal(back, x)
-    if k <= 19:
+    if k <= 20:
         want_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
         orc.or_batch_expand_into_evaluate_ntt(want_e.ctypes.data, want_zk.ctypes.data, n, cnt, 2)
         got_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
