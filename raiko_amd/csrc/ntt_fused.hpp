@@ -61,7 +61,8 @@ RK_HD void stage_tw(uint32_t* w, const uint32_t* tw, unsigned rlow) {
 // Values stay "lazy" in [0, 2p) between stages, between rounds (LDS) and until the store:
 //   t = y * w via an unsigned REDC (any u32 y, result < 2p), t and x brought to [0, p) with one
 //   conditional subtraction each, then x + t and x - t + p need no reduction (both < 2p < 2^32).
-template <int LS, int NST>
+// CANON_IN: the 16 inputs are canonical (fresh from global memory): the first stage skips its ucanon of x
+template <int LS, int NST, bool CANON_IN = false>
 RK_HD void dit(uint32_t* v, const uint32_t* tw, unsigned rlow) {
     static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
@@ -70,8 +71,12 @@ RK_HD void dit(uint32_t* v, const uint32_t* tw, unsigned rlow) {
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             if (m & (1 << b)) continue;
-            uint32_t x = bb::ucanon(v[m]);
-            uint32_t t = bb::ucanon(bb::uredc64((uint64_t)v[m | (1 << b)] * w[m & ((1 << b) - 1)]));
+            uint32_t x = (CANON_IN && b == 0) ? v[m] : bb::ucanon(v[m]);
+            uint32_t t;
+            if (LS == 0 && (m & ((1 << b) - 1)) == 0)  // position 0 of its half: the twiddle is w^0 = 1
+                t = (CANON_IN && b == 0) ? v[m | (1 << b)] : bb::ucanon(v[m | (1 << b)]);
+            else
+                t = bb::ucanon(bb::uredc64((uint64_t)v[m | (1 << b)] * w[m & ((1 << b) - 1)]));
             v[m] = x + t;
             v[m | (1 << b)] = x - t + bb::P;
         }
@@ -90,7 +95,10 @@ RK_HD void dif(uint32_t* v, const uint32_t* tw, unsigned rlow) {
             if (m & (1 << b)) continue;
             uint32_t x = v[m], y = v[m | (1 << b)];
             v[m] = bb::add(x, y);
-            v[m | (1 << b)] = bb::canon(bb::smul((int32_t)(x - y), (int32_t)w[m & ((1 << b) - 1)]));
+            if (LS == 0 && (m & ((1 << b) - 1)) == 0)  // w^-0 = 1
+                v[m | (1 << b)] = bb::sub(x, y);
+            else
+                v[m | (1 << b)] = bb::canon(bb::smul((int32_t)(x - y), (int32_t)w[m & ((1 << b) - 1)]));
         }
     });
 }
@@ -163,7 +171,7 @@ RK_HD void fwd_contig_a(const Args& a, const ntt::Tables& tb, const CTile& t, ui
         V4 u = s[q];
         v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
     }
-    dit<2, 4>(v, tb.small[0], tid & 3);
+    dit<2, 4, true>(v, tb.small[0], tid & 3);
     lds_write<2>(v, lds, tid);
 }
 RK_HD void fwd_contig_b(const ntt::Tables& tb, uint32_t* lds, unsigned tid) {
@@ -194,7 +202,7 @@ RK_HD void fwd_contig0_a(const Args& a, const ntt::Tables& tb, const CTile& t, u
         V4 u = s[q];
         v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
     }
-    dit<0, 2>(v, tb.small[0], 0);
+    dit<0, 2, true>(v, tb.small[0], 0);
     V4* p = reinterpret_cast<V4*>(lds + phys(16 * tid));
 #pragma unroll
     for (int q = 0; q < 4; q++) p[q] = V4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -270,7 +278,7 @@ RK_HD void fwd_strided_a(const Args& a, const ntt::Tables& tb, const STile<G>& t
     const uint32_t* s = a.src + t.base + (size_t)(16 * r) * t.S + lo;
 #pragma unroll
     for (int m = 0; m < 16; m++) v[m] = s[(size_t)m * t.S];
-    dit<0, G - 4>(v, tb.small[0], 0);
+    dit<0, G - 4, true>(v, tb.small[0], 0);
     lds_write<LOGT>(v, lds, tid);  // e = (16 r + m) << logT | lo = round_e0<LOGT>(tid) | m << logT
 }
 template <int G>
@@ -285,7 +293,7 @@ RK_HD void fwd_strided_b(const Args& a, const ntt::Tables& tb, const STile<G>& t
 #pragma unroll
         for (int m = 0; m < 16; m++) v[m] = s[(size_t)m * t.S];
     }
-    dit<G - 4, 4>(v, tb.small[0], r);
+    dit<G - 4, 4, G == 4>(v, tb.small[0], r);
     uint32_t* d = a.dst + t.base + (size_t)r * t.S + lo;
 #pragma unroll
     for (int m = 0; m < 16; m++) d[((size_t)m << (G - 4)) * t.S] = bb::ucanon(v[m]);
