@@ -3,12 +3,14 @@
  *
  *   gcc -O2 -I include examples/session_demo.c -o session_demo -L raiko_amd -lraiko_hip \
  *       -Wl,-rpath,$PWD/raiko_amd
- *   ./session_demo [segments] [po2]
+ *   ./session_demo [segments] [po2] [gpu,gpu,...]
  *
  * Builds `segments` synthetic segments (xorshift-filled traces, the tap set of
  * raiko_amd/segment.py:synthetic_tapset for 4/4/12 columns), proves them with rk_prove_session
- * (three in flight, uploads staged ahead, every seal verified inside the call), then checks
- * that a tampered seal is rejected by rk_verify_segment.  Exit code 0 on success. */
+ * (three in flight per GPU, uploads staged ahead, every seal verified inside the call; with a GPU
+ * list all of them take segments from one work queue -- no collective, the seals land in this
+ * process's buffers), then checks that a tampered seal is rejected by rk_verify_segment.
+ * Exit code 0 on success. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -74,11 +76,23 @@ int main(int argc, char** argv) {
         seals[s] = malloc(caps[s] * 4);
     }
 
-    rk_session_opts opts = {0, 3, 2, 1};
+    int devices[64], n_devices = 0;
+    if (argc > 3) {
+        for (char* tok = strtok(argv[3], ","); tok && n_devices < 64; tok = strtok(NULL, ",")) devices[n_devices++] = atoi(tok);
+    }
+    rk_session_opts opts;
+    memset(&opts, 0, sizeof opts);
+    opts.device = 0;
+    opts.inflight = 3;
+    opts.upload_ahead = 2;
+    opts.verify = 1;
+    opts.devices = n_devices ? devices : NULL;
+    opts.n_devices = n_devices;
     size_t failed = 0;
     int st = rk_prove_session(&opts, segs, n_seg, seals, caps, words, &failed);
     if (st != RK_OK) {
-        fprintf(stderr, "rk_prove_session: %s (%s), segment %zu\n", rk_strerror(st), rk_session_last_error(0), failed);
+        fprintf(stderr, "rk_prove_session: %s (%s), segment %zu\n", rk_strerror(st),
+                rk_session_last_error(n_devices ? devices[0] : 0), failed);
         return 1;
     }
     for (size_t s = 0; s < n_seg; s++) {

@@ -22,16 +22,17 @@ Differences from the reference driver, on purpose:
   * the receipt cache lives in a per-process directory instead of the shared, wiped
     `/tmp/risc0-cache` (bonsai.rs:261-265 is a latent race under `concurrency_limit` = 16).
 """
-import hashlib
-import json
 import os
 import struct
 import tempfile
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import receipt as receipt_mod
+from . import risc0_serde as rs
+from .receipt import Receipt, SegmentReceipt
 from .segment import Segment
 
 RISC0_PROVER_CODE = 3  # provers/risc0/driver/src/lib.rs:53; `hip` answers to proof_type "risc0"
@@ -104,21 +105,20 @@ class Risc0Param:
 def encode_journal_b256(h: bytes) -> bytes:
     """The journal the guest commits (`env::commit(&hash)`, provers/risc0/guest/src/main.rs:28) as the
     reference decodes it (`receipt.journal.decode::<B256>()`, bonsai.rs:157): risc0's word serde writes
-    a `[u8; 32]` as 32 little-endian u32 words, one byte each (recalled from risc0-zkvm 1.0.1, whose
-    source is not in the reference tree) -- 128 bytes."""
+    a `[u8; 32]` as 32 little-endian u32 words, one byte each (raiko_amd/risc0_serde.py) -- 128 bytes."""
     if len(h) != 32:
         raise ValueError("B256 is 32 bytes")
-    return b"".join(struct.pack("<I", b) for b in h)
+    return rs.words_to_bytes(rs.to_vec(rs.B256, h))
 
 
 def decode_journal_b256(journal: bytes) -> Optional[bytes]:
     """inverse of encode_journal_b256; None if the bytes are not a word-serialised B256"""
     if len(journal) != 128:
         return None
-    words = struct.unpack("<32I", journal)
-    if any(w > 0xFF for w in words):
+    try:
+        return bytes(rs.from_slice(rs.B256, struct.unpack("<32I", journal)))
+    except ValueError:
         return None
-    return bytes(words)
 
 
 @dataclass
@@ -132,36 +132,6 @@ class Session:
     @property
     def total_cycles(self) -> int:
         return sum(s.cycles for s in self.segments)
-
-
-@dataclass
-class Receipt:
-    """Composite receipt: one seal per segment + the journal (risc0 `ReceiptKind::Composite`)."""
-
-    seals: List[np.ndarray]
-    journal: bytes
-    po2: List[int] = field(default_factory=list)
-
-    MAGIC = b"RKHIPZKP1"
-
-    def to_bytes(self) -> bytes:
-        hdr = json.dumps({"journal": self.journal.hex(), "po2": self.po2, "words": [int(s.size) for s in self.seals]}).encode()
-        body = b"".join(np.ascontiguousarray(s, dtype="<u4").tobytes() for s in self.seals)
-        return self.MAGIC + struct.pack("<I", len(hdr)) + hdr + body
-
-    @staticmethod
-    def from_bytes(b: bytes) -> "Receipt":
-        if not b.startswith(Receipt.MAGIC):
-            raise FileIo("not a raiko-hip receipt")
-        o = len(Receipt.MAGIC)
-        (n,) = struct.unpack_from("<I", b, o)
-        hdr = json.loads(b[o + 4:o + 4 + n])
-        o += 4 + n
-        seals = []
-        for w in hdr["words"]:
-            seals.append(np.frombuffer(b, dtype="<u4", count=w, offset=o).copy())
-            o += 4 * w
-        return Receipt(seals=seals, journal=bytes.fromhex(hdr["journal"]), po2=hdr["po2"])
 
 
 _CACHE_DIR = None
@@ -181,54 +151,87 @@ def zkp_cache_path(label: str) -> str:
     return os.path.join(_cache_dir(), label + ".zkp")
 
 
-def save_receipt(label: str, receipt: Receipt) -> None:
+def save_receipt(label: str, receipt_data: Tuple[str, Receipt]) -> None:
+    """bonsai.rs:294-302: bincode of `(uuid, receipt)` (raiko_amd/receipt.py)"""
     try:
         with open(zkp_cache_path(label), "wb") as f:
-            f.write(receipt.to_bytes())
+            f.write(receipt_mod.serialize(receipt_data[0], receipt_data[1]))
     except OSError as e:
         raise FileIo(str(e))
 
 
-def load_receipt(label: str) -> Optional[Receipt]:
+def load_receipt(label: str) -> Optional[Tuple[str, Receipt]]:
+    """bonsai.rs:274-292: None when there is no such file; a file that does not parse is a FileIo error"""
     try:
         with open(zkp_cache_path(label), "rb") as f:
-            return Receipt.from_bytes(f.read())
+            raw = f.read()
     except OSError:
         return None
+    try:
+        return receipt_mod.deserialize(raw)
+    except ValueError as e:
+        raise FileIo("cached receipt %s: %s" % (label, e))
 
 
-def prove_locally(segment_limit_po2: int, session: Session, device: int = 0, inflight: int = 3) -> Receipt:
+def _rank_and_gpu(device: Optional[int]):
+    """(rank, world, gpu, collective device): with torch.distributed initialised and no explicit
+    `hip.device`, rank r proves on GPU LOCAL_RANK (or r) modulo the GPUs of the node, and the seal
+    gather uses device tensors when the backend is RCCL ("nccl")."""
+    rank, world, coll = 0, 1, None
+    try:
+        import torch
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            rank, world = tdist.get_rank(), tdist.get_world_size()
+            if device is None:
+                device = local_gpu_for_rank(int(os.environ.get("LOCAL_RANK", rank)))
+            if tdist.get_backend() == "nccl":
+                coll = torch.device("cuda", device)
+    except ImportError:
+        pass
+    return rank, world, 0 if device is None else device, coll
+
+
+def local_gpu_for_rank(local_rank: int) -> int:
+    import ctypes as C
+    from . import _lib
+    n = C.c_int(0)
+    _lib.load().rk_device_count(C.byref(n))
+    return local_rank % n.value if n.value > 0 else 0
+
+
+def prove_locally(segment_limit_po2: int, session: Session, device: Optional[int] = None, inflight: int = 3,
+                  devices: Optional[Sequence[int]] = None) -> Receipt:
     """bonsai.rs:230-272 from the point the executor has produced the session: prove every
-    segment (this rank's shard when torch.distributed is initialised), `inflight` at a time on
-    the GPU (rk_prove_session), and assemble the receipt."""
+    segment (this rank's shard when torch.distributed is initialised), `inflight` at a time per
+    GPU, and assemble the receipt.  `devices`: several GPUs driven from this one process
+    (rk_prove_session's work queue) instead of one rank per GPU."""
     from . import dist as rdist
     for s in session.segments:
         if s.po2 > segment_limit_po2:
             raise GuestError("segment of 2^%d cycles exceeds segment_limit_po2 = %d" % (s.po2, segment_limit_po2))
-    rank, world = 0, 1
-    try:
-        import torch.distributed as tdist
-        if tdist.is_available() and tdist.is_initialized():
-            rank, world = tdist.get_rank(), tdist.get_world_size()
-    except ImportError:
-        pass
+    rank, world, gpu, coll_device = _rank_and_gpu(device)
     mine = rdist.shard_indices(len(session.segments), rank, world)
     # rk_prove_session (raiko_amd/csrc/session.hip): `inflight` proofs in flight, uploads staged ahead
     # on their own stream, and -- the `receipt.verify()` of the reference's tests (lib.rs:136) -- every
     # seal verified on a host thread while the GPU goes on.  The library serialises sessions per device and
     # keeps its contexts for the life of the process.
     from . import _lib
-    from .hal import prove_session
+    from . import hal
     try:
-        local = prove_session([session.segments[i] for i in mine], device=device, inflight=inflight)
+        local = hal.prove_session([session.segments[i] for i in mine], device=gpu, inflight=inflight, devices=devices)
     except _lib.RkError as e:  # surface as GuestError like `From<String>` (prover.rs:19-23)
         if e.status == _lib.RK_ERR_VERIFY:
             raise GuestError("segment %d: seal failed verification" % mine[e.segment])
         raise GuestError(str(e))
-    seals = rdist.gather_seals(local, len(session.segments)) if world > 1 else local
+    seals = rdist.gather_seals(local, len(session.segments), device=coll_device) if world > 1 else local
     if seals is None:  # non-root rank of a sharded proof
         seals = []
-    return Receipt(seals=list(seals), journal=session.journal, po2=[s.po2 for s in session.segments])
+    n = len(seals)
+    segs = [SegmentReceipt(seal=np.asarray(s, dtype=np.uint32), index=i, po2=session.segments[i].po2,
+                           exit_code=("Halted", 0) if i + 1 == n else ("SystemSplit", None))
+            for i, s in enumerate(seals)]
+    return Receipt(segments=segs, journal=session.journal)
 
 
 class HipProver:
@@ -249,19 +252,26 @@ class HipProver:
         if not isinstance(session, Session):
             raise GuestError("input carries no executed session (the RV32IM executor is outside this backend)")
         expected = bytes(output.hash)
-        label = session.image_id.hex() + "-" + hashlib.sha3_256(expected).hexdigest()
-        receipt = load_receipt(label)
-        if receipt is None:
+        if len(expected) != 32:
+            raise Param("output.hash must be a B256")
+        # bonsai.rs:100-108: hex(image id) - hex(keccak(bytes of to_vec(expected_output)))
+        label = receipt_mod.receipt_label(session.image_id, expected)
+        cached = load_receipt(label)
+        if cached is not None:
+            receipt = cached[1]
+        else:
             hip = config.get("hip", {}) if isinstance(config.get("hip", {}), dict) else {}
             try:
-                device, inflight = int(hip.get("device", 0)), int(hip.get("inflight", 3))
+                device = int(hip["device"]) if "device" in hip else None
+                inflight = int(hip.get("inflight", 3))
+                devices = [int(d) for d in hip["devices"]] if "devices" in hip else None
             except (TypeError, ValueError):
-                raise Param("`hip.device` / `hip.inflight` must be integers")
+                raise Param("`hip.device` / `hip.inflight` / `hip.devices` must be integers")
             if inflight < 1 or inflight > 16:
                 raise Param("`hip.inflight` must be in 1..16")
-            receipt = prove_locally(param.execution_po2, session, device=device, inflight=inflight)
+            receipt = prove_locally(param.execution_po2, session, device=device, inflight=inflight, devices=devices)
             if receipt.seals:
-                save_receipt(label, receipt)
+                save_receipt(label, ("", receipt))  # local proofs carry an empty uuid (bonsai.rs:139)
         # bonsai.rs:157-162: the journal is decoded and compared with the expected output; a mismatch
         # is logged, not fatal.  (A session whose journal is not word-serialised is compared raw.)
         decoded = decode_journal_b256(receipt.journal)

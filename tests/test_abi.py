@@ -54,6 +54,17 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert lib.rk_strerror(-7) == b"a produced seal failed verification"
     opts = _lib.RkSessionOpts(device=0, inflight=0, upload_ahead=0, verify=1)
     assert lib.rk_prove_session(C.byref(opts), None, 0, None, None, None, None) == -1  # inflight out of range
+    # device-list argument checks happen before any GPU is touched
+    two = (C.c_int * 2)(0, 0)
+    opts = _lib.RkSessionOpts(device=0, inflight=1, upload_ahead=0, verify=0, devices=two, n_devices=2)
+    assert lib.rk_prove_session(C.byref(opts), None, 0, None, None, None, None) == -1  # duplicate GPU
+    opts = _lib.RkSessionOpts(device=0, inflight=1, upload_ahead=0, verify=0, devices=None, n_devices=2)
+    assert lib.rk_prove_session(C.byref(opts), None, 0, None, None, None, None) == -1  # count without a list
+    opts = _lib.RkSessionOpts(device=0, inflight=1, upload_ahead=0, verify=0, devices=two, n_devices=65)
+    assert lib.rk_prove_session(C.byref(opts), None, 0, None, None, None, None) == -1
+    with pytest.raises(_lib.RkError) as ei:
+        prove_session(segs, inflight=2, devices=[0, 1])
+    assert ei.value.status == -4
     assert lib.rk_session_release() == 0
 
 
@@ -98,3 +109,6 @@ def test_plain_c_caller_proves_a_session(tmp_path):
     r = subprocess.run([exe, "5", "12"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "5 segments of 2^12 cycles proven and verified" in r.stdout
+    # the same through the device-list form of rk_session_opts (a one-entry list on this box)
+    r = subprocess.run([exe, "4", "10", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "4 segments of 2^10 cycles proven and verified" in r.stdout, (r.stdout, r.stderr)

@@ -56,3 +56,58 @@ def test_gather_gloo_world2(n_segments):
     for p in procs:
         p.join(timeout=60)
     assert res == ["ok", "ok"]
+
+
+def _prover_worker(rank, world, port, n_segments, q):
+    """HipProver.run itself on two ranks: shard by rank, rank -> GPU mapping, seal gather, receipt on rank 0.
+    No GPU here: hal.prove_session is replaced by a stand-in that records its arguments."""
+    import types
+    import torch.distributed as dist
+    from raiko_amd import hal, prover as pv
+    from raiko_amd.segment import synthetic_segment
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        segs = [synthetic_segment(4, (2, 2, 3), seed=100 + i, n_globals=2) for i in range(n_segments)]
+        seen = {}
+
+        def fake_prove_session(segments, device=0, inflight=3, devices=None, **kw):
+            seen["device"], seen["n"] = device, len(segments)
+            return [np.full(10 + int(s.globals_[0] % 7), int(s.globals_[0]), dtype=np.uint32) for s in segments]
+
+        hal.prove_session = fake_prove_session
+        pv.local_gpu_for_rank = lambda local_rank: local_rank % 8       # an 8-GPU node
+        journal = pv.encode_journal_b256(bytes([5]) * 32)
+        sess = pv.Session(segments=segs, journal=journal, image_id=bytes([1]) * 32)
+        inp = types.SimpleNamespace(session=sess, chain_spec=types.SimpleNamespace(chain_id=167009))
+        out = types.SimpleNamespace(hash=bytes([5]) * 32)
+        cfg = {"proof_type": "risc0", "risc0": {"bonsai": False, "snark": False, "profile": False, "execution_po2": 18}}
+        proof = pv.HipProver.run(inp, out, cfg)
+        ok = proof.proof == journal.hex() and seen["device"] == rank and seen["n"] == len(shard_indices(n_segments, rank, world))
+        if rank == 0:
+            from raiko_amd import receipt as rc
+            _, cached = pv.load_receipt(rc.receipt_label(sess.image_id, out.hash))
+            ok = ok and len(cached.seals) == n_segments and all(
+                int(cached.seals[i][0]) == int(segs[i].globals_[0]) for i in range(n_segments))
+            ok = ok and cached.segments[-1].exit_code == ("Halted", 0)
+        q.put("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prover_run_sharded_over_gloo_world2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prover_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert res == ["ok", "ok"]

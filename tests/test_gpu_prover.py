@@ -162,6 +162,38 @@ def test_native_session_prover(hal):
         assert np.array_equal(a, b)
 
 
+def test_session_device_list_and_custom_poseidon2(hal):
+    """rk_session_opts.devices: the multi-GPU work queue with a one-entry list (all a one-GPU box has);
+    mixed host- and device-resident segments; an unknown or duplicate GPU is refused.  And a session
+    whose contexts prove under caller-supplied Poseidon2 constants verifies only with those constants."""
+    from raiko_amd._lib import RkError
+    from raiko_amd.hal import prove_session, verify_segment
+    segs = [synthetic_segment(9 + (i % 2), (4, 4, 8), seed=900 + i) for i in range(6)]
+    want = [hal.prove_segment(s) for s in segs]
+    dev = [None] * 6
+    for i in (1, 4):
+        dev[i] = ([hal.copy_from_elem(g) for g in segs[i].groups], hal.copy_from_elem(segs[i].check))
+    got = prove_session(segs, inflight=3, upload_ahead=1, devices=[0], device_inputs=dev)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    for bad in ([0, 0], [7]):
+        with pytest.raises(RkError) as ei:
+            prove_session(segs[:2], inflight=1, devices=bad)
+        assert ei.value.status == -1
+    # caller-supplied Poseidon2 instance: proved on a context of its own, checked by rk_verify_segment_ex
+    from raiko_amd.hal import HipHal
+    rng = np.random.default_rng(77)
+    consts = (o.rand_elems(rng, (192,)), o.rand_elems(rng, (21,)), o.rand_elems(rng, (24,)))
+    h2 = HipHal(0)
+    h2.set_poseidon2_params(*consts)
+    seal = h2.prove_segment(segs[0])
+    h2.close()
+    assert not np.array_equal(seal, want[0])
+    assert verify_segment(segs[0], seal) != 0                      # the default instance does not match
+    assert verify_segment(segs[0], seal, poseidon2=consts) == 0
+    assert verify_segment(segs[0], want[0], poseidon2=consts) != 0
+
+
 def test_native_session_reports_the_failing_segment(hal):
     from raiko_amd._lib import RkError
     from raiko_amd.hal import prove_session
