@@ -1,0 +1,178 @@
+//! `extern "C"` declarations of libraiko_hip.so -- the mechanical translation of
+//! `include/raiko_hip.h` (the C header is the source of truth; `tools/check_ffi.py` regenerates
+//! this body with `--emit` and the CPU test suite fails when the two drift apart).
+//!
+//! Reference interfaces these entry points stand behind: `trait Prover` (lib/src/prover.rs:52-62),
+//! `prove_locally` -> `session.prove()` (provers/risc0/driver/src/bonsai.rs:230-272) and, one level
+//! down, `risc0_zkp::hal::{Hal, CircuitHal}` of risc0-zkp 1.0.1 (Cargo.lock:7243).
+#![allow(non_camel_case_types)]
+#![allow(clippy::missing_safety_doc)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub type rk_status = c_int;
+pub const RK_OK: rk_status = 0;
+pub const RK_ERR_INVALID: rk_status = -1;
+pub const RK_ERR_HIP: rk_status = -2;
+pub const RK_ERR_NOMEM: rk_status = -3;
+pub const RK_ERR_NODEVICE: rk_status = -4;
+pub const RK_ERR_CAPACITY: rk_status = -5;
+pub const RK_ERR_INTERNAL: rk_status = -6;
+pub const RK_ERR_VERIFY: rk_status = -7;
+pub const RK_ERR_CALLBACK: rk_status = -8;
+
+pub type rk_kclass = c_int;
+pub const RK_KCLASS_HASH_ROWS: rk_kclass = 0;
+pub const RK_KCLASS_HASH_FOLD: rk_kclass = 1;
+pub const RK_KCLASS_NTT_PASS: rk_kclass = 2;
+pub const RK_KCLASS_BIT_REVERSE: rk_kclass = 3;
+pub const RK_KCLASS_POLY: rk_kclass = 4;
+pub const RK_KCLASS_COUNT: rk_kclass = 5;
+
+#[repr(C)]
+pub struct rk_ctx {
+    _private: [u8; 0],
+}
+
+pub type rk_poly_ext_fn = unsafe extern "C" fn(user: *mut c_void, pub_: *const rk_segment, poly_mix: *const u32, eval_u_ext: *const u32, n_taps: usize, mix: *const u32, n_mix: u32, out_ext: *mut u32) -> c_int;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_taps {
+    pub group_size: [u32; 3],
+    pub n_regs: u32,
+    pub reg_group: *const u32,
+    pub reg_offset: *const u32,
+    pub reg_combo: *const u32,
+    pub n_combos: u32,
+    pub combo_off: *const u32,
+    pub combo_backs: *const u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_circuit_view {
+    pub ctx: *mut rk_ctx,
+    pub stream: *mut c_void,
+    pub po2: u32,
+    pub group_size: [u32; 3],
+    pub d_trace: [*const u32; 3],
+    pub d_lde: [*const u32; 3],
+    pub globals: *const u32,
+    pub n_globals: u32,
+    pub mix: *const u32,
+    pub n_mix: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_circuit_hooks {
+    pub user: *mut c_void,
+    pub accumulate: Option<unsafe extern "C" fn(user: *mut c_void, view: *const rk_circuit_view, d_accum: *mut u32) -> c_int>,
+    pub eval_check: Option<unsafe extern "C" fn(user: *mut c_void, view: *const rk_circuit_view, poly_mix: *const u32, d_check: *mut u32) -> c_int>,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_segment {
+    pub po2: u32,
+    pub on_device: u32,
+    pub taps: rk_taps,
+    pub group: [*const u32; 3],
+    pub check: *const u32,
+    pub globals: *const u32,
+    pub n_globals: u32,
+    pub n_accum_mix: u32,
+    pub proof_system_info: [u8; 16],
+    pub circuit_info: [u8; 16],
+    pub hooks: *const rk_circuit_hooks,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_verify_opts {
+    pub p2_rc_ext: *const u32,
+    pub p2_rc_int: *const u32,
+    pub p2_diag: *const u32,
+    pub poly_ext: Option<rk_poly_ext_fn>,
+    pub user: *mut c_void,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_session_opts {
+    pub device: c_int,
+    pub inflight: c_int,
+    pub upload_ahead: c_int,
+    pub verify: c_int,
+    pub devices: *const c_int,
+    pub n_devices: c_int,
+    pub verify_opts: *const rk_verify_opts,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_timing {
+    pub ntt: f32,
+    pub hash: f32,
+    pub deep: f32,
+    pub fri: f32,
+    pub query: f32,
+    pub total: f32,
+    pub circuit: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_kernel_stat {
+    pub launches: u64,
+    pub ms: f64,
+    pub bytes: f64,
+}
+
+#[link(name = "raiko_hip")]
+extern "C" {
+    pub fn rk_abi_version() -> c_int;
+    pub fn rk_strerror(status: c_int) -> *const c_char;
+    pub fn rk_last_error(ctx: *mut rk_ctx) -> *const c_char;
+    pub fn rk_device_count(count: *mut c_int) -> c_int;
+    pub fn rk_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut rk_ctx) -> c_int;
+    pub fn rk_ctx_destroy(ctx: *mut rk_ctx) -> c_int;
+    pub fn rk_sync(ctx: *mut rk_ctx) -> c_int;
+    pub fn rk_alloc(ctx: *mut rk_ctx, bytes: usize, d_ptr: *mut *mut c_void) -> c_int;
+    pub fn rk_free(ctx: *mut rk_ctx, d_ptr: *mut c_void) -> c_int;
+    pub fn rk_h2d(ctx: *mut rk_ctx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
+    pub fn rk_d2h(ctx: *mut rk_ctx, h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn rk_set_poseidon2_params(ctx: *mut rk_ctx, rc_ext: *const u32, rc_int: *const u32, diag: *const u32) -> c_int;
+    pub fn rk_batch_interpolate_ntt(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize) -> c_int;
+    pub fn rk_batch_evaluate_ntt(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize, expand_bits: u32) -> c_int;
+    pub fn rk_zk_shift(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize) -> c_int;
+    pub fn rk_batch_expand_into_evaluate_ntt(ctx: *mut rk_ctx, d_out: *mut u32, d_in: *const u32, in_size: usize, count: usize, expand_bits: u32) -> c_int;
+    pub fn rk_batch_bit_reverse(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize) -> c_int;
+    pub fn rk_hash_rows(ctx: *mut rk_ctx, d_out_digests: *mut u32, d_matrix: *const u32, rows: usize, cols: usize) -> c_int;
+    pub fn rk_hash_fold(ctx: *mut rk_ctx, d_nodes: *mut u32, input_size: usize, output_size: usize) -> c_int;
+    pub fn rk_batch_evaluate_any(ctx: *mut rk_ctx, d_coeffs: *const u32, poly_count: usize, size: usize, h_which: *const u32, h_xs: *const u32, eval_count: usize, h_out: *mut u32) -> c_int;
+    pub fn rk_mix_poly_coeffs(ctx: *mut rk_ctx, d_out_ext: *mut u32, mix_start: *const u32, mix: *const u32, d_in: *const u32, h_combos: *const u32, input_size: usize, count: usize) -> c_int;
+    pub fn rk_eltwise_add_elem(ctx: *mut rk_ctx, d_out: *mut u32, d_a: *const u32, d_b: *const u32, n: usize) -> c_int;
+    pub fn rk_eltwise_sum_extelem(ctx: *mut rk_ctx, d_out: *mut u32, d_in_ext: *const u32, count: usize, to_add: usize) -> c_int;
+    pub fn rk_eltwise_copy_elem(ctx: *mut rk_ctx, d_out: *mut u32, d_in: *const u32, n: usize) -> c_int;
+    pub fn rk_eltwise_zeroize_elem(ctx: *mut rk_ctx, d_io: *mut u32, n: usize) -> c_int;
+    pub fn rk_fri_fold(ctx: *mut rk_ctx, d_out: *mut u32, d_in: *const u32, out_count: usize, mix: *const u32) -> c_int;
+    pub fn rk_gather_sample(ctx: *mut rk_ctx, d_dst: *mut u32, d_src: *const u32, idx: usize, size: usize, stride: usize) -> c_int;
+    pub fn rk_prefix_products(ctx: *mut rk_ctx, d_io_ext: *mut u32, count: usize) -> c_int;
+    pub fn rk_scatter(ctx: *mut rk_ctx, d_into: *mut u32, into_words: usize, h_index: *const u32, n_cycles: usize, h_offsets: *const u32, h_values: *const u32) -> c_int;
+    pub fn rk_merkle_build(ctx: *mut rk_ctx, d_nodes: *mut u32, d_matrix: *const u32, rows: usize, cols: usize) -> c_int;
+    pub fn rk_poly_divide(ctx: *mut rk_ctx, d_polys_ext: *mut u32, count: usize, z: *const u32, h_rem: *mut u32) -> c_int;
+    pub fn rk_prove_segment(ctx: *mut rk_ctx, seg: *const rk_segment, h_seal: *mut u32, seal_capacity_words: usize, seal_words: *mut usize) -> c_int;
+    pub fn rk_verify_segment(pub_: *const rk_segment, seal: *const u32, seal_words: usize) -> c_int;
+    pub fn rk_verify_segment_ex(pub_: *const rk_segment, opts: *const rk_verify_opts, seal: *const u32, seal_words: usize) -> c_int;
+    pub fn rk_seal_bound_words(seg: *const rk_segment) -> usize;
+    pub fn rk_prove_session(opts: *const rk_session_opts, segs: *const rk_segment, n: usize, h_seals: *const *mut u32, seal_capacity_words: *const usize, seal_words: *mut usize, failed_index: *mut usize) -> c_int;
+    pub fn rk_session_last_error(device: c_int) -> *const c_char;
+    pub fn rk_session_release() -> c_int;
+    pub fn rk_last_timing(ctx: *mut rk_ctx, out: *mut rk_timing) -> c_int;
+    pub fn rk_set_kernel_timing(ctx: *mut rk_ctx, enabled: c_int) -> c_int;
+    pub fn rk_kernel_stats(ctx: *mut rk_ctx, kclass: c_int, out: *mut rk_kernel_stat) -> c_int;
+    pub fn rk_kernel_class_name(kclass: c_int) -> *const c_char;
+    pub fn rk_session_set_kernel_timing(device: c_int, enabled: c_int) -> c_int;
+    pub fn rk_session_kernel_stats(device: c_int, kclass: c_int, out: *mut rk_kernel_stat) -> c_int;
+}
