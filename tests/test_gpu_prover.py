@@ -104,9 +104,11 @@ def test_hip_prover_run_end_to_end(hal):
     proof = pv.HipProver.run(inp, out, cfg)
     assert proof.to_json() == {"proof": journal.hex(), "quote": None, "kzg_proof": None}
     assert pv.HipProver.last_journal_matches is True
-    import hashlib
-    rec = pv.load_receipt(sess.image_id.hex() + "-" + hashlib.sha3_256(block_hash).hexdigest())
-    assert rec is not None and len(rec.seals) == 5
+    # the cache file: bincode (uuid, Receipt) under the label of bonsai.rs:100-108
+    from raiko_amd import receipt as rc
+    uuid, rec = pv.load_receipt(rc.receipt_label(sess.image_id, block_hash))
+    assert uuid == "" and len(rec.seals) == 5 and rec.journal == journal
+    assert [sr.index for sr in rec.segments] == [0, 1, 2, 3, 4] and rec.segments[-1].exit_code == ("Halted", 0)
     for s, seal in zip(segs, rec.seals):
         assert np.array_equal(seal, o.oracle_prove(s))
 
