@@ -60,6 +60,41 @@ int rk_d2h(rk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
  * 21 internal round constants, 24 internal-diagonal entries.  Defaults are compiled in. */
 int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t* rc_int, const uint32_t* diag);
 
+/* ---- the parameter blob: everything instance-specific about the proof system in one place ----
+ * (the same kernels serve risc0's parameter set and SP1 / Plonky3's;
+ * presets carry the RECALLED values of both, any field can be overridden.)  Field elements in the
+ * blob are CANONICAL integers except the Poseidon2 tables, which are Montgomery residues like
+ * every buffer of the ABI.  rk_set_params validates (ext_w a non-residue, root of exact order
+ * 2^27, shapes in range), rebuilds the context's twiddle / shift tables and replaces its
+ * Poseidon2 instance; RK_ERR_INVALID leaves the context unchanged. */
+typedef enum { RK_PRESET_RISC0 = 0, RK_PRESET_SP1 = 1 } rk_preset;
+typedef struct {
+    uint32_t struct_size;        /* = sizeof(rk_params): guards against a caller built for another layout */
+    /* field */
+    uint32_t ext_w;              /* extension Fp[x]/(x^4 - ext_w): p - 11 (risc0: x^4 + 11), 11 (Plonky3: x^4 - 11) */
+    uint32_t root_2_27;          /* generator of the 2^27 subgroup: 137 (risc0), 0x1a427a41 (Plonky3) */
+    uint32_t coset_shift;        /* shift of the zk / LDE coset: 3 (risc0), 31 (Plonky3) */
+    /* Poseidon2 */
+    uint32_t p2_width;           /* 24 (rate 16, R_P 21) or 16 (rate 8, R_P 13); R_F = 8, x^7, digest = 8 cells */
+    uint32_t p2_m4;              /* 4x4 block of the external layer: 0 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
+                                  * (Poseidon2 paper, risc0), 1 = circ(2,3,1,1) (Plonky3 MDSMat4) */
+    uint32_t p2_pad_free;        /* sponge: 0 = zero-pad the last partial block (risc0), 1 = padding-free overwrite
+                                  * (Plonky3 PaddingFreeSponge: cells beyond the input keep their values) */
+    const uint32_t* p2_rc_ext;   /* 8 * p2_width external round constants; NULL = derived defaults */
+    const uint32_t* p2_rc_int;   /* 21 or 13 internal round constants; NULL = derived defaults */
+    const uint32_t* p2_diag;     /* p2_width internal-diagonal entries (matrix 1 1^T + diag); NULL = defaults */
+    /* protocol */
+    uint32_t queries;            /* 50 (risc0), 100 (SP1 core) */
+    uint32_t blowup_log2;        /* 2 (risc0), 1 (SP1 core): rk_prove_segment accepts 2; the operators take
+                                  * expand_bits / sizes as arguments and serve both */
+    uint32_t fri_fold_log2;      /* 4 (risc0), 1 (Plonky3): rk_fri_fold folds by 2^fri_fold_log2 (1..4);
+                                  * rk_prove_segment accepts 4 */
+    uint32_t fri_min_degree;     /* 256 (risc0) */
+} rk_params;
+int rk_params_preset(rk_params* out, int preset);
+int rk_set_params(rk_ctx* ctx, const rk_params* params);
+int rk_get_params(rk_ctx* ctx, rk_params* out);    /* pointers in *out refer to the context's own copies */
+
 /* ---- Hal trait operators (risc0-zkp 1.0.1 hal/mod.rs `trait Hal`) ---- */
 /* Hal::batch_interpolate_ntt: `count` columns of `size` natural-order evaluations ->
  * bit-reversed coefficients, in place. */
@@ -90,7 +125,8 @@ int rk_eltwise_add_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const
 int rk_eltwise_sum_extelem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in_ext, size_t count, size_t to_add);
 int rk_eltwise_copy_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n);
 int rk_eltwise_zeroize_elem(rk_ctx* ctx, uint32_t* d_io, size_t n);
-/* Hal::fri_fold: arity-16 fold of 4 coefficient planes (bit-reversed order in and out). */
+/* Hal::fri_fold: fold of 4 coefficient planes by 2^fri_fold_log2 of the context's parameters
+ * (16 by default; bit-reversed order in and out). */
 int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const uint32_t mix[4]);
 /* Hal::gather_sample: dst[g] = src[g*stride + idx], g < size. */
 int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
@@ -201,10 +237,15 @@ typedef struct {
     const uint32_t* p2_diag;       /* 24 */
     rk_poly_ext_fn poly_ext;
     void* user;
+    const rk_params* params;       /* optional: the parameter blob the seal was produced under (field, Poseidon2
+                                    * instance incl. width 16, queries); overrides the three p2_* pointers */
 } rk_verify_opts;
 int rk_verify_segment_ex(const rk_segment* pub, const rk_verify_opts* opts, const uint32_t* seal, size_t seal_words);
-/* Upper bound on the seal size for a given shape. */
+/* Upper bound on the seal size for a given shape (0 for a shape rk_prove_segment rejects), for up to
+ * RK_MAX_QUERIES queries' worth of openings when called without parameters. */
 size_t rk_seal_bound_words(const rk_segment* seg);
+size_t rk_seal_bound_words_for(const rk_segment* seg, uint32_t queries);
+#define RK_MAX_QUERIES 256
 
 /* ---- whole-session prover: what replaces `session.prove()` (provers/risc0/driver/src/bonsai.rs:271,
  * which proves the segments one after the other) ----

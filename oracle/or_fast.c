@@ -8,8 +8,8 @@
  * entry points of or_ops.c here; results are bit-identical to the plain restatement
  * (tests/test_oracle_fast.py), which stays the reference the GPU is compared with. */
 #include "oracle.h"
-#include "poseidon2_consts.inc"
 #include <immintrin.h>
+#define FAST_CELLS 24 /* the AVX2 permutation serves the width-24 instances only (or_ops.c dispatches) */
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -55,7 +55,7 @@ static inline v8 v_sbox7(v8 x) {
 static void v_m_ext(v8* c) {
     v8 sums[4];
     for (int j = 0; j < 4; j++) sums[j] = _mm256_setzero_si256();
-    for (int i = 0; i < OR_CELLS; i += 4) {
+    for (int i = 0; i < FAST_CELLS; i += 4) {
         v8 a = c[i], b = c[i + 1], d = c[i + 2], e = c[i + 3];
         v8 t0 = v_add(a, b), t1 = v_add(d, e);
         v8 t2 = v_add(v_add(b, b), t1), t3 = v_add(v_add(e, e), t0);
@@ -65,38 +65,38 @@ static void v_m_ext(v8* c) {
         c[i] = t6; c[i + 1] = t5; c[i + 2] = t7; c[i + 3] = t4;
         for (int j = 0; j < 4; j++) sums[j] = v_add(sums[j], c[i + j]);
     }
-    for (int i = 0; i < OR_CELLS; i++) c[i] = v_add(c[i], sums[i & 3]);
+    for (int i = 0; i < FAST_CELLS; i++) c[i] = v_add(c[i], sums[i & 3]);
 }
 static void v_poseidon2(v8* c) {
     int r = 0;
     v_m_ext(c);
     for (int k = 0; k < 4; k++, r++) {
-        for (int i = 0; i < OR_CELLS; i++) c[i] = v_sbox7(v_add(c[i], v_set1(P2_RC_EXT_MONT[r * OR_CELLS + i])));
+        for (int i = 0; i < FAST_CELLS; i++) c[i] = v_sbox7(v_add(c[i], v_set1(g_or.p2_rc_ext[r * FAST_CELLS + i])));
         v_m_ext(c);
     }
     for (int k = 0; k < 21; k++) {
-        c[0] = v_sbox7(v_add(c[0], v_set1(P2_RC_INT_MONT[k])));
+        c[0] = v_sbox7(v_add(c[0], v_set1(g_or.p2_rc_int[k])));
         v8 sum = c[0];
-        for (int i = 1; i < OR_CELLS; i++) sum = v_add(sum, c[i]);
-        for (int i = 0; i < OR_CELLS; i++) c[i] = v_add(sum, v_mul(c[i], v_set1(P2_INT_DIAG_MONT[i])));
+        for (int i = 1; i < FAST_CELLS; i++) sum = v_add(sum, c[i]);
+        for (int i = 0; i < FAST_CELLS; i++) c[i] = v_add(sum, v_mul(c[i], v_set1(g_or.p2_diag[i])));
     }
     for (int k = 0; k < 4; k++, r++) {
-        for (int i = 0; i < OR_CELLS; i++) c[i] = v_sbox7(v_add(c[i], v_set1(P2_RC_EXT_MONT[r * OR_CELLS + i])));
+        for (int i = 0; i < FAST_CELLS; i++) c[i] = v_sbox7(v_add(c[i], v_set1(g_or.p2_rc_ext[r * FAST_CELLS + i])));
         v_m_ext(c);
     }
 }
 
 /* sponge over 8 consecutive rows of a column-major matrix: lane = row */
 static void hash_rows8(uint32_t* out, const fp* matrix, size_t rows, size_t cols, size_t r0) {
-    v8 st[OR_CELLS];
-    for (int i = 0; i < OR_CELLS; i++) st[i] = _mm256_setzero_si256();
+    v8 st[FAST_CELLS];
+    for (int i = 0; i < FAST_CELLS; i++) st[i] = _mm256_setzero_si256();
     size_t unmixed = 0;
     for (size_t c = 0; c < cols; c++) {
         st[unmixed++] = v_load(matrix + c * rows + r0);
-        if (unmixed == OR_CELLS_RATE) { v_poseidon2(st); unmixed = 0; }
+        if (unmixed == 16) { v_poseidon2(st); unmixed = 0; }
     }
     if (unmixed != 0 || cols == 0) {
-        for (size_t i = unmixed; i < OR_CELLS_RATE; i++) st[i] = _mm256_setzero_si256();
+        for (size_t i = unmixed; i < 16; i++) st[i] = _mm256_setzero_si256();
         v_poseidon2(st);
     }
     uint32_t tmp[OR_CELLS_OUT][8];
@@ -118,9 +118,9 @@ void or_fast_hash_fold(uint32_t* nodes, size_t output_size) {
     for (size_t b = 0; b < blocks; b++) {
         size_t idx = output_size + b * 8;
         const int* base = (const int*)(nodes + 2 * idx * OR_DIGEST_WORDS);
-        v8 st[OR_CELLS];
+        v8 st[FAST_CELLS];
         for (int w = 0; w < 16; w++) st[w] = _mm256_i32gather_epi32(base + w, lane_off, 4);
-        for (int w = 16; w < OR_CELLS; w++) st[w] = _mm256_setzero_si256();
+        for (int w = 16; w < FAST_CELLS; w++) st[w] = _mm256_setzero_si256();
         v_poseidon2(st);
         uint32_t tmp[OR_CELLS_OUT][8];
         for (int w = 0; w < OR_CELLS_OUT; w++) v_store(tmp[w], st[w]);
@@ -140,6 +140,7 @@ void or_fast_hash_fold(uint32_t* nodes, size_t output_size) {
 static fp* g_tw_fwd = NULL;
 static fp* g_tw_rev = NULL;
 static unsigned g_tw_log = 0;
+void or_fast_reset_tables(void) { g_tw_log = 0; } /* after or_set_params: the old tables are abandoned */
 static void tw_init(unsigned k) {
     if (k <= g_tw_log) return;
 #pragma omp critical(or_fast_tw)
@@ -244,7 +245,7 @@ void or_fast_zk_shift(fp* io, size_t size, size_t count) {
     unsigned bits = lg(size);
     fp* f = (fp*)malloc(size * sizeof(fp));
     fp pw[32];
-    pw[0] = fp_from_u32(3);
+    pw[0] = fp_from_u32(g_or.coset_shift);
     for (int j = 1; j < 32; j++) pw[j] = fp_mul(pw[j - 1], pw[j - 1]);
     /* f[pos] for pos = b_{bits-1}..b_0 has exponent rev(pos): bit j of pos contributes 3^(2^(bits-1-j)) */
     f[0] = fp_from_u32(1);

@@ -8,7 +8,7 @@
  *   - BabyBear, p = 15*2^27+1, Montgomery form R = 2^32 (risc0-core
  *     field/baby_bear.rs), call sites in the reference:
  *     provers/risc0/driver/src/bonsai.rs:246-271.
- *   - quartic extension Fp[x]/(x^4+11).
+ *   - quartic extension Fp[x]/(x^4 - W), W = -11 (x^4+11) by default.
  * It is pinned by exact big-integer arithmetic in tests/test_oracle_field.py.
  */
 #ifndef OR_FIELD_H
@@ -21,6 +21,8 @@
 #define OR_R2 1172168163u     /* 2^64 mod p */
 #define OR_INVALID 0xffffffffu
 #define OR_BETA 11u
+/* Montgomery form of W in Fp[x]/(x^4 - W): p - 11 unless or_set_params says otherwise (or_params.c) */
+extern uint32_t g_or_wm;
 
 typedef uint32_t fp; /* Montgomery residue, canonical range [0,p) */
 typedef struct { fp c[4]; } fp4;
@@ -54,7 +56,7 @@ static inline fp4 fp4_scale(fp4 a, fp s) { fp4 r; for (int i = 0; i < 4; i++) r.
 static inline int fp4_eq(fp4 a, fp4 b) { return a.c[0]==b.c[0] && a.c[1]==b.c[1] && a.c[2]==b.c[2] && a.c[3]==b.c[3]; }
 /* schoolbook product reduced by x^4 = -11 */
 static inline fp4 fp4_mul(fp4 a, fp4 b) {
-    fp nbeta = fp_from_u32(OR_P - OR_BETA);
+    fp nbeta = g_or_wm;
     fp4 r;
     r.c[0] = fp_add(fp_mul(a.c[0], b.c[0]),
                     fp_mul(nbeta, fp_add(fp_add(fp_mul(a.c[1], b.c[3]), fp_mul(a.c[2], b.c[2])), fp_mul(a.c[3], b.c[1]))));

@@ -3,7 +3,6 @@
  * and hal/cpu.rs (the Hal trait) -- the operators behind `session.prove()`
  * at /root/reference provers/risc0/driver/src/bonsai.rs:271. */
 #include "oracle.h"
-#include "poseidon2_consts.inc"
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -25,12 +24,13 @@ void or_fast_mix_poly_coeffs(fp4* out, const uint32_t* mix_start, const uint32_t
 /* ------------------------------------------------------------------ roots */
 static fp g_rou_fwd[28], g_rou_rev[28];
 static int g_rou_ready = 0;
+void or_ops_reset_roots(void) { g_rou_ready = 0; }
 static void rou_init(void) {
     if (g_rou_ready) return;
 #pragma omp critical(or_rou)
     {
         if (!g_rou_ready) {
-            g_rou_fwd[27] = fp_from_u32(137); /* generator of the 2^27 subgroup */
+            g_rou_fwd[27] = fp_from_u32(g_or.root_2_27); /* generator of the 2^27 subgroup (137 for risc0) */
             for (int k = 26; k >= 0; k--) g_rou_fwd[k] = fp_mul(g_rou_fwd[k + 1], g_rou_fwd[k + 1]);
             for (int k = 0; k <= 27; k++) g_rou_rev[k] = fp_inv(g_rou_fwd[k]);
             g_rou_ready = 1;
@@ -131,61 +131,76 @@ static inline fp sbox7(fp x) {
     fp x2 = fp_mul(x, x), x4 = fp_mul(x2, x2), x6 = fp_mul(x4, x2);
     return fp_mul(x6, x);
 }
-/* circ(2*M4, M4, ..., M4), M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] */
+/* external layer circ(2*M4, M4, ..., M4) over width/4 blocks; M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
+ * (Poseidon2 paper, risc0) or circ(2,3,1,1) (Plonky3 MDSMat4) */
 static void m_ext(fp* c) {
+    const int W = (int)g_or.p2_width;
     fp sums[4] = {0, 0, 0, 0};
-    for (int i = 0; i < OR_CELLS; i += 4) {
+    for (int i = 0; i < W; i += 4) {
         fp a = c[i], b = c[i + 1], d = c[i + 2], e = c[i + 3];
-        fp t0 = fp_add(a, b), t1 = fp_add(d, e);
-        fp t2 = fp_add(fp_add(b, b), t1), t3 = fp_add(fp_add(e, e), t0);
-        fp t1_4 = fp_add(fp_add(t1, t1), fp_add(t1, t1));
-        fp t0_4 = fp_add(fp_add(t0, t0), fp_add(t0, t0));
-        fp t4 = fp_add(t1_4, t3), t5 = fp_add(t0_4, t2);
-        fp t6 = fp_add(t3, t5), t7 = fp_add(t2, t4);
-        c[i] = t6; c[i + 1] = t5; c[i + 2] = t7; c[i + 3] = t4;
+        if (g_or.p2_m4 == 0) {
+            fp t0 = fp_add(a, b), t1 = fp_add(d, e);
+            fp t2 = fp_add(fp_add(b, b), t1), t3 = fp_add(fp_add(e, e), t0);
+            fp t1_4 = fp_add(fp_add(t1, t1), fp_add(t1, t1));
+            fp t0_4 = fp_add(fp_add(t0, t0), fp_add(t0, t0));
+            fp t4 = fp_add(t1_4, t3), t5 = fp_add(t0_4, t2);
+            fp t6 = fp_add(t3, t5), t7 = fp_add(t2, t4);
+            c[i] = t6; c[i + 1] = t5; c[i + 2] = t7; c[i + 3] = t4;
+        } else {
+            fp s = fp_add(fp_add(a, b), fp_add(d, e));
+            c[i] = fp_add(fp_add(s, a), fp_add(b, b));      /* 2a + 3b +  c +  d */
+            c[i + 1] = fp_add(fp_add(s, b), fp_add(d, d));  /*  a + 2b + 3c +  d */
+            c[i + 2] = fp_add(fp_add(s, d), fp_add(e, e));  /*  a +  b + 2c + 3d */
+            c[i + 3] = fp_add(fp_add(s, e), fp_add(a, a));  /* 3a +  b +  c + 2d */
+        }
         for (int j = 0; j < 4; j++) sums[j] = fp_add(sums[j], c[i + j]);
     }
-    for (int i = 0; i < OR_CELLS; i++) c[i] = fp_add(c[i], sums[i & 3]);
+    for (int i = 0; i < W; i++) c[i] = fp_add(c[i], sums[i & 3]);
 }
 static void m_int(fp* c) {
+    const int W = (int)g_or.p2_width;
     fp sum = 0;
-    for (int i = 0; i < OR_CELLS; i++) sum = fp_add(sum, c[i]);
-    for (int i = 0; i < OR_CELLS; i++) c[i] = fp_add(sum, fp_mul(c[i], P2_INT_DIAG_MONT[i]));
+    for (int i = 0; i < W; i++) sum = fp_add(sum, c[i]);
+    for (int i = 0; i < W; i++) c[i] = fp_add(sum, fp_mul(c[i], g_or.p2_diag[i]));
 }
 void or_poseidon2_mix(fp* c) {
+    const int W = (int)g_or.p2_width, RP = W == 16 ? 13 : 21;
     int r = 0;
     m_ext(c);
     for (int k = 0; k < 4; k++, r++) {
-        for (int i = 0; i < OR_CELLS; i++) c[i] = sbox7(fp_add(c[i], P2_RC_EXT_MONT[r * OR_CELLS + i]));
+        for (int i = 0; i < W; i++) c[i] = sbox7(fp_add(c[i], g_or.p2_rc_ext[r * W + i]));
         m_ext(c);
     }
-    for (int k = 0; k < 21; k++) {
-        c[0] = sbox7(fp_add(c[0], P2_RC_INT_MONT[k]));
+    for (int k = 0; k < RP; k++) {
+        c[0] = sbox7(fp_add(c[0], g_or.p2_rc_int[k]));
         m_int(c);
     }
     for (int k = 0; k < 4; k++, r++) {
-        for (int i = 0; i < OR_CELLS; i++) c[i] = sbox7(fp_add(c[i], P2_RC_EXT_MONT[r * OR_CELLS + i]));
+        for (int i = 0; i < W; i++) c[i] = sbox7(fp_add(c[i], g_or.p2_rc_ext[r * W + i]));
         m_ext(c);
     }
 }
-/* overwrite-mode sponge, rate 16, zero pad, one permutation for empty input */
+/* overwrite-mode sponge over the configured rate; the last partial block is zero-padded (risc0) or
+ * leaves the remaining rate cells as they are (Plonky3 PaddingFreeSponge); one permutation for an
+ * empty input in the zero-padded mode */
 void or_hash_elem_slice(const fp* in, size_t n, size_t stride, uint32_t* digest) {
-    fp st[OR_CELLS];
+    fp st[OR_MAX_CELLS];
     memset(st, 0, sizeof st);
     size_t unmixed = 0;
     for (size_t i = 0; i < n; i++) {
         st[unmixed++] = in[i * stride];
         if (unmixed == OR_CELLS_RATE) { or_poseidon2_mix(st); unmixed = 0; }
     }
-    if (unmixed != 0 || n == 0) {
-        for (size_t i = unmixed; i < OR_CELLS_RATE; i++) st[i] = 0;
+    if (unmixed != 0 || (n == 0 && !g_or.p2_pad_free)) {
+        if (!g_or.p2_pad_free)
+            for (size_t i = unmixed; i < OR_CELLS_RATE; i++) st[i] = 0;
         or_poseidon2_mix(st);
     }
     memcpy(digest, st, OR_CELLS_OUT * sizeof(fp));
 }
 void or_hash_pair(const uint32_t* a, const uint32_t* b, uint32_t* out) {
-    fp st[OR_CELLS];
-    memcpy(st, a, 32); memcpy(st + 8, b, 32); memset(st + 16, 0, 32);
+    fp st[OR_MAX_CELLS];
+    memcpy(st, a, 32); memcpy(st + 8, b, 32); memset(st + 16, 0, 32); /* width 16: the two digests fill the state */
     or_poseidon2_mix(st);
     memcpy(out, st, 32);
 }
@@ -205,8 +220,8 @@ void or_batch_evaluate_ntt(fp* io, size_t size, size_t count, unsigned expand_bi
 void or_zk_shift(fp* io, size_t size, size_t count) {
     if (g_or_fast) { or_fast_zk_shift(io, size, count); return; }
     unsigned bits = log2_exact(size);
-    fp three = fp_from_u32(3);
-    /* 3^rev(pos): table of 3^(2^j) */
+    fp three = fp_from_u32(g_or.coset_shift);
+    /* shift^rev(pos): table of shift^(2^j) */
     fp pw[32];
     pw[0] = three;
     for (int j = 1; j < 32; j++) pw[j] = fp_mul(pw[j - 1], pw[j - 1]);
@@ -236,13 +251,13 @@ void or_batch_bit_reverse(fp* io, size_t size, size_t count) {
     for (size_t c = 0; c < count; c++) or_bit_reverse(io + c * size, size);
 }
 void or_hash_rows(uint32_t* out, const fp* matrix, size_t rows, size_t cols) {
-    if (g_or_fast) { or_fast_hash_rows(out, matrix, rows, cols); return; }
+    if (g_or_fast && g_or.p2_width == 24 && g_or.p2_m4 == 0 && !g_or.p2_pad_free) { or_fast_hash_rows(out, matrix, rows, cols); return; }
 #pragma omp parallel for schedule(static)
     for (size_t r = 0; r < rows; r++) or_hash_elem_slice(matrix + r, cols, rows, out + r * OR_DIGEST_WORDS);
 }
 void or_hash_fold(uint32_t* nodes, size_t input_size, size_t output_size) {
     (void)input_size; /* == 2*output_size; heap layout: children of i are 2i, 2i+1 */
-    if (g_or_fast) { or_fast_hash_fold(nodes, output_size); return; }
+    if (g_or_fast && g_or.p2_width == 24 && g_or.p2_m4 == 0) { or_fast_hash_fold(nodes, output_size); return; }
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < output_size; i++) {
         size_t idx = output_size + i;
@@ -292,14 +307,15 @@ void or_eltwise_zeroize_elem(fp* io, size_t n) {
 }
 void or_fri_fold(fp* out, const fp* in, size_t count, const uint32_t* mix) {
     fp4 mx; memcpy(&mx, mix, 16);
+    const unsigned fold_po2 = g_or.fri_fold_log2, fold = 1u << fold_po2;
 #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < count; idx++) {
         fp4 tot = fp4_zero(), cur = fp4_one();
-        for (unsigned i = 0; i < OR_FRI_FOLD; i++) {
-            size_t rev_i = bitrev32(i) >> (32 - OR_FRI_FOLD_PO2);
+        for (unsigned i = 0; i < fold; i++) {
+            size_t rev_i = bitrev32(i) >> (32 - fold_po2);
             size_t rev_idx = rev_i * count + idx;
             fp4 f;
-            for (int k = 0; k < 4; k++) f.c[k] = in[(size_t)k * count * OR_FRI_FOLD + rev_idx];
+            for (int k = 0; k < 4; k++) f.c[k] = in[(size_t)k * count * fold + rev_idx];
             tot = fp4_add(tot, fp4_mul(cur, f));
             cur = fp4_mul(cur, mx);
         }

@@ -167,7 +167,7 @@ static void fri_prove(or_iop* iop, const fp* coeffs_in, size_t coeffs_size, inne
     free(final_coeffs);
     double t1 = now_s();
     g_timing.fri += t1 - t0;
-    for (int q = 0; q < OR_QUERIES; q++) {
+    for (uint32_t q = 0; q < OR_QUERIES; q++) {
         uint32_t rng = or_iop_random_bits(iop, ilog2(orig_domain));
         size_t pos = rng % orig_domain;
         inner(ctx, iop, pos);
@@ -203,6 +203,8 @@ int or_prove_segment(const or_segment* seg, uint32_t** seal, size_t* seal_words,
     (void)threads;
 #endif
     memset(&g_timing, 0, sizeof g_timing);
+    /* the segment flow is risc0's: blow-up 4, fold 16, final degree 256 (field, hash and query count follow g_or) */
+    if (g_or.blowup_log2 != 2 || g_or.fri_fold_log2 != OR_FRI_FOLD_PO2 || g_or.fri_min_degree != OR_FRI_MIN_DEGREE) return -4;
     double t_start = now_s();
     const or_taps* taps = &seg->taps;
     size_t N = (size_t)1 << seg->po2;

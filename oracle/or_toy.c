@@ -88,7 +88,7 @@ static int toy_eval_check(void* user, const or_circuit_view* v, const fp* poly_m
     fp4 pm = ext_of(poly_mix), m = ext_of(v->mix);
     /* x_i^N for x_i = 3*w_D^i takes 4 values: 3^N * w_4^(i mod 4) */
     fp inv_den[4];
-    fp three_n = fp_pow(fp_from_u32(3), N), w4 = or_rou_fwd(2);
+    fp three_n = fp_pow(fp_from_u32(g_or.coset_shift), N), w4 = or_rou_fwd(2);
     for (int r = 0; r < 4; r++) inv_den[r] = fp_inv(fp_sub(fp_mul(three_n, fp_pow(w4, r)), fp_from_u32(1)));
     int bad = 0;
 #pragma omp parallel for schedule(static)

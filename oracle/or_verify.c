@@ -53,6 +53,7 @@ int or_verify_segment(const or_segment* seg, const uint32_t* seal, size_t seal_w
 int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_t seal_words,
                               or_poly_ext_fn poly_ext, void* user) {
     const or_taps* taps = &seg->taps;
+    if (g_or.blowup_log2 != 2 || g_or.fri_fold_log2 != OR_FRI_FOLD_PO2 || g_or.fri_min_degree != OR_FRI_MIN_DEGREE) return -4;
     riop r; memset(&r, 0, sizeof r);
     r.p = seal; r.len = seal_words;
     uint32_t digest[8];
@@ -117,7 +118,7 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
             }
             zi = fp4_mul(zi, z);
         }
-        fp4 vanish = fp4_sub(fp4_pow(fp4_scale(z, fp_from_u32(3)), N), fp4_one());
+        fp4 vanish = fp4_sub(fp4_pow(fp4_scale(z, fp_from_u32(g_or.coset_shift)), N), fp4_one());
         if (!identity_rc && !fp4_eq(fp4_mul(check, vanish), result)) identity_rc = 70;
         free(eval_u);
     }
@@ -166,7 +167,7 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
     fp check_row[OR_CHECK_SIZE];
     fp4* tot = (fp4*)malloc((taps->n_combos + 1) * sizeof(fp4));
 
-    for (int q = 0; q < OR_QUERIES && !rc && !r.err; q++) {
+    for (uint32_t q = 0; q < OR_QUERIES && !rc && !r.err; q++) {
         uint32_t rng = or_iop_random_bits(&r.rng, ilog2(orig_domain));
         size_t pos = rng % orig_domain;
         /* inner: open every group at pos, recompute the DEEP quotient there */

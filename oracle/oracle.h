@@ -23,16 +23,34 @@ extern "C" {
 #endif
 
 #define OR_INV_RATE 4
-#define OR_QUERIES 50
+#define OR_QUERIES (g_or.queries)
+#define OR_MAX_QUERIES 256
 #define OR_FRI_FOLD 16
 #define OR_FRI_FOLD_PO2 4
 #define OR_FRI_MIN_DEGREE 256
 #define OR_DIGEST_WORDS 8
-#define OR_CELLS 24
-#define OR_CELLS_RATE 16
+#define OR_MAX_CELLS 24
+/* sponge width / rate of the configured Poseidon2 instance (24 / 16 by default) */
+#define OR_CELLS (g_or.p2_width)
+#define OR_CELLS_RATE (g_or.p2_width - 8)
 #define OR_CELLS_OUT 8
 #define OR_EXT 4
 #define OR_CHECK_SIZE 16
+
+/* ---- the parameter set (the oracle is configured process-wide, one set at a time) ----
+ * Mirrors rk_params of include/raiko_hip.h: canonical field values, Montgomery Poseidon2 tables.
+ * Presets: 0 = risc0 (x^4+11, 137, shift 3, Poseidon2 t=24 / M4 of the paper / zero-padded sponge,
+ * 50 queries), 1 = SP1 / Plonky3 shape (x^4-11, 0x1a427a41, shift 31, t=16 / circ(2,3,1,1) /
+ * padding-free sponge, 100 queries, fold 2).  RECALLED values, parity unpinned like the rest. */
+typedef struct {
+    uint32_t ext_w, root_2_27, coset_shift;
+    uint32_t p2_width, p2_m4, p2_pad_free;
+    const fp *p2_rc_ext, *p2_rc_int, *p2_diag;   /* NULL = the derived defaults of the width */
+    uint32_t queries, blowup_log2, fri_fold_log2, fri_min_degree;
+} or_params;
+extern or_params g_or;
+void or_params_preset(or_params* out, int preset);
+int or_set_params(const or_params* p);   /* 0, or -1 for an unusable set (left unchanged) */
 
 /* ---- field helpers exported for ctypes tests ---- */
 uint32_t or_fp_mul(uint32_t a, uint32_t b);
@@ -72,7 +90,7 @@ void or_eltwise_add_elem(fp* out, const fp* a, const fp* b, size_t n);
 void or_eltwise_sum_extelem(fp* out, const fp4* in, size_t count, size_t to_add);
 void or_eltwise_copy_elem(fp* out, const fp* in, size_t n);
 void or_eltwise_zeroize_elem(fp* io, size_t n);
-void or_fri_fold(fp* out, const fp* in, size_t out_count, const uint32_t* mix);
+void or_fri_fold(fp* out, const fp* in, size_t out_count, const uint32_t* mix); /* by 2^g_or.fri_fold_log2 */
 void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t stride);
 void or_prefix_products(fp4* io, size_t count);              /* io[i] *= io[i-1], sequential */
 void or_scatter(fp* into, const uint32_t* index, size_t n_cycles, const uint32_t* offsets, const fp* values);
@@ -94,7 +112,7 @@ void or_merkle_free(or_merkle* m);
 /* ---- risc0-zkp prove/write_iop.rs + hash/poseidon2/rng.rs ---- */
 typedef struct {
     uint32_t* proof; size_t len, cap;
-    fp cells[OR_CELLS]; size_t pool_used;
+    fp cells[OR_MAX_CELLS]; size_t pool_used;
 } or_iop;
 void or_iop_init(or_iop* iop);
 void or_iop_free(or_iop* iop);

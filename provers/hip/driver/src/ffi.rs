@@ -20,6 +20,10 @@ pub const RK_ERR_INTERNAL: rk_status = -6;
 pub const RK_ERR_VERIFY: rk_status = -7;
 pub const RK_ERR_CALLBACK: rk_status = -8;
 
+pub type rk_preset = c_int;
+pub const RK_PRESET_RISC0: rk_preset = 0;
+pub const RK_PRESET_SP1: rk_preset = 1;
+
 pub type rk_kclass = c_int;
 pub const RK_KCLASS_HASH_ROWS: rk_kclass = 0;
 pub const RK_KCLASS_HASH_FOLD: rk_kclass = 1;
@@ -28,12 +32,33 @@ pub const RK_KCLASS_BIT_REVERSE: rk_kclass = 3;
 pub const RK_KCLASS_POLY: rk_kclass = 4;
 pub const RK_KCLASS_COUNT: rk_kclass = 5;
 
+pub const RK_MAX_QUERIES: u32 = 256;
+
 #[repr(C)]
 pub struct rk_ctx {
     _private: [u8; 0],
 }
 
 pub type rk_poly_ext_fn = unsafe extern "C" fn(user: *mut c_void, pub_: *const rk_segment, poly_mix: *const u32, eval_u_ext: *const u32, n_taps: usize, mix: *const u32, n_mix: u32, out_ext: *mut u32) -> c_int;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_params {
+    pub struct_size: u32,
+    pub ext_w: u32,
+    pub root_2_27: u32,
+    pub coset_shift: u32,
+    pub p2_width: u32,
+    pub p2_m4: u32,
+    pub p2_pad_free: u32,
+    pub p2_rc_ext: *const u32,
+    pub p2_rc_int: *const u32,
+    pub p2_diag: *const u32,
+    pub queries: u32,
+    pub blowup_log2: u32,
+    pub fri_fold_log2: u32,
+    pub fri_min_degree: u32,
+}
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -95,6 +120,7 @@ pub struct rk_verify_opts {
     pub p2_diag: *const u32,
     pub poly_ext: Option<rk_poly_ext_fn>,
     pub user: *mut c_void,
+    pub params: *const rk_params,
 }
 
 #[repr(C)]
@@ -143,6 +169,9 @@ extern "C" {
     pub fn rk_h2d(ctx: *mut rk_ctx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     pub fn rk_d2h(ctx: *mut rk_ctx, h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn rk_set_poseidon2_params(ctx: *mut rk_ctx, rc_ext: *const u32, rc_int: *const u32, diag: *const u32) -> c_int;
+    pub fn rk_params_preset(out: *mut rk_params, preset: c_int) -> c_int;
+    pub fn rk_set_params(ctx: *mut rk_ctx, params: *const rk_params) -> c_int;
+    pub fn rk_get_params(ctx: *mut rk_ctx, out: *mut rk_params) -> c_int;
     pub fn rk_batch_interpolate_ntt(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize) -> c_int;
     pub fn rk_batch_evaluate_ntt(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize, expand_bits: u32) -> c_int;
     pub fn rk_zk_shift(ctx: *mut rk_ctx, d_io: *mut u32, size: usize, count: usize) -> c_int;
@@ -166,6 +195,7 @@ extern "C" {
     pub fn rk_verify_segment(pub_: *const rk_segment, seal: *const u32, seal_words: usize) -> c_int;
     pub fn rk_verify_segment_ex(pub_: *const rk_segment, opts: *const rk_verify_opts, seal: *const u32, seal_words: usize) -> c_int;
     pub fn rk_seal_bound_words(seg: *const rk_segment) -> usize;
+    pub fn rk_seal_bound_words_for(seg: *const rk_segment, queries: u32) -> usize;
     pub fn rk_prove_session(opts: *const rk_session_opts, segs: *const rk_segment, n: usize, h_seals: *const *mut u32, seal_capacity_words: *const usize, seal_words: *mut usize, failed_index: *mut usize) -> c_int;
     pub fn rk_session_last_error(device: c_int) -> *const c_char;
     pub fn rk_session_release() -> c_int;

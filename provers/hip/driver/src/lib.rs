@@ -190,6 +190,7 @@ fn prove_locally(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Re
         p2_diag: ptr::null(),
         poly_ext: Some(circuit::poly_ext_trampoline),
         user: ptr::null_mut(),
+        params: ptr::null(), // risc0's parameter set is the library default
     };
     let opts = rk_session_opts {
         device: devices.first().copied().unwrap_or(0),

@@ -76,9 +76,20 @@ class RkCircuitHooks(C.Structure):
     _fields_ = [("user", C.c_void_p), ("accumulate", ACCUMULATE_FN), ("eval_check", EVAL_CHECK_FN)]
 
 
+class RkParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("ext_w", C.c_uint32), ("root_2_27", C.c_uint32), ("coset_shift", C.c_uint32),
+                ("p2_width", C.c_uint32), ("p2_m4", C.c_uint32), ("p2_pad_free", C.c_uint32),
+                ("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p),
+                ("queries", C.c_uint32), ("blowup_log2", C.c_uint32), ("fri_fold_log2", C.c_uint32),
+                ("fri_min_degree", C.c_uint32)]
+
+
+RK_PRESET_RISC0, RK_PRESET_SP1 = 0, 1
+
+
 class RkVerifyOpts(C.Structure):
     _fields_ = [("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p), ("poly_ext", POLY_EXT_FN),
-                ("user", C.c_void_p)]
+                ("user", C.c_void_p), ("params", C.POINTER(RkParams))]
 
 
 class RkSessionOpts(C.Structure):
@@ -144,6 +155,10 @@ SYMBOLS = {
     "rk_prefix_products": (C.c_int, [_vp, _vp, _sz]),
     "rk_scatter": (C.c_int, [_vp, _vp, _sz, u32p, _sz, u32p, u32p]),
     "rk_seal_bound_words": (_sz, [C.POINTER(RkSegment)]),
+    "rk_seal_bound_words_for": (_sz, [C.POINTER(RkSegment), _u32]),
+    "rk_params_preset": (C.c_int, [C.POINTER(RkParams), C.c_int]),
+    "rk_set_params": (C.c_int, [_vp, C.POINTER(RkParams)]),
+    "rk_get_params": (C.c_int, [_vp, C.POINTER(RkParams)]),
     "rk_last_timing": (C.c_int, [_vp, C.POINTER(RkTiming)]),
     "rk_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "rk_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(RkKernelStat)]),

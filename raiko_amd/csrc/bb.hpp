@@ -166,9 +166,12 @@ RK_HD Ext scale(const Ext& a, uint32_t s) {
 RK_HD bool eq(const Ext& a, const Ext& b) {
     return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
 }
-// schoolbook product folded through x^4 = -11
-RK_HD Ext mul(const Ext& a, const Ext& b) {
-    constexpr uint32_t NBETA = 1073741848u;  // Montgomery form of p - 11
+// The extension is Fp[x]/(x^4 - W).  W travels as its Montgomery form `wm`: risc0's field has
+// W = -11 (the default), Plonky3 / SP1's BabyBear quartic has W = +11 (rk_params.ext_w).
+constexpr uint32_t WM_RISC0 = 1073741848u;  // Montgomery form of p - 11
+// schoolbook product folded through x^4 = W
+RK_HD Ext mul(const Ext& a, const Ext& b, uint32_t wm = WM_RISC0) {
+    const uint32_t NBETA = wm;
     uint32_t h0 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
     uint32_t h1 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
     uint32_t h2 = mul(a.c[3], b.c[3]);
@@ -179,37 +182,31 @@ RK_HD Ext mul(const Ext& a, const Ext& b) {
     r.c[3] = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
     return r;
 }
-RK_HD Ext pow(Ext a, uint64_t e) {
+RK_HD Ext pow(Ext a, uint64_t e, uint32_t wm = WM_RISC0) {
     Ext r = ext_one();
     while (e) {
-        if (e & 1) r = mul(r, a);
-        a = mul(a, a);
+        if (e & 1) r = mul(r, a, wm);
+        a = mul(a, a, wm);
         e >>= 1;
     }
     return r;
 }
-// a^-1 via the norm to the quadratic subfield Fp[x^2]: for a = a0 + a1 x with
-// a0 = (c0 + c2 y), a1 = (c1 + c3 y), y = x^2, y^2 = -11:
-//   a * (a0 - a1 x) = a0^2 - a1^2 y =: n = n0 + n1 y in Fp[y]
-//   n * (n0 - n1 y) = n0^2 + 11 n1^2 in Fp
-RK_HD Ext inv(const Ext& a) {
-    const uint32_t B11 = encode(11);
-    // a0^2 = (c0^2 - 11 c2^2) + 2 c0 c2 y ; a1^2 y = (c1 + c3 y)^2 y = (c1^2 - 11 c3^2) y + 2 c1 c3 y^2
-    uint32_t a0sq0 = sub(mul(a.c[0], a.c[0]), mul(B11, mul(a.c[2], a.c[2])));
-    uint32_t a0sq1 = dbl(mul(a.c[0], a.c[2]));
-    uint32_t a1sq0 = sub(mul(a.c[1], a.c[1]), mul(B11, mul(a.c[3], a.c[3])));
-    uint32_t a1sq1 = dbl(mul(a.c[1], a.c[3]));
-    // n = a0^2 - y*a1^2 = (a0sq0 + 11*a1sq1) + (a0sq1 - a1sq0) y
-    uint32_t n0 = add(a0sq0, mul(B11, a1sq1));
-    uint32_t n1 = sub(a0sq1, a1sq0);
-    uint32_t d = add(mul(n0, n0), mul(B11, mul(n1, n1)));
+// a^-1 via the norm to the quadratic subfield Fp[y], y = x^2, y^2 = W: for a = a0 + a1 x with
+// a0 = c0 + c2 y, a1 = c1 + c3 y:
+//   a * (a0 - a1 x) = a0^2 - a1^2 y =: n = n0 + n1 y,
+//       n0 = c0^2 + W c2^2 - 2 W c1 c3,   n1 = 2 c0 c2 - c1^2 - W c3^2
+//   n * (n0 - n1 y) = n0^2 - W n1^2 in Fp
+RK_HD Ext inv(const Ext& a, uint32_t wm = WM_RISC0) {
+    uint32_t n0 = sub(add(mul(a.c[0], a.c[0]), mul(wm, mul(a.c[2], a.c[2]))), mul(wm, dbl(mul(a.c[1], a.c[3]))));
+    uint32_t n1 = sub(sub(dbl(mul(a.c[0], a.c[2])), mul(a.c[1], a.c[1])), mul(wm, mul(a.c[3], a.c[3])));
+    uint32_t d = sub(mul(n0, n0), mul(wm, mul(n1, n1)));
     uint32_t di = inv(d);
     // n^-1 = (n0 - n1 y) / d ; a^-1 = (a0 - a1 x) * n^-1
     uint32_t m0 = mul(n0, di), m1 = neg(mul(n1, di));
     // (a0 - a1 x) as Ext: (c0, -c1, c2, -c3); times (m0 + m1 y) = (m0, 0, m1, 0)
     Ext conj{{a.c[0], neg(a.c[1]), a.c[2], neg(a.c[3])}};
     Ext m{{m0, 0, m1, 0}};
-    return mul(conj, m);
+    return mul(conj, m, wm);
 }
 
 RK_HD uint32_t bitrev(uint32_t x, unsigned bits) {

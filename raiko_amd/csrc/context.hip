@@ -1,8 +1,8 @@
 // Context, device memory and table management + the plain C entry points for them.
 #include "internal.hpp"
-#include "poseidon2_consts.inc"
 
 #include <cstring>
+#include <memory>
 
 namespace rk {
 
@@ -109,13 +109,19 @@ static void ktime_collect(rk_ctx* ctx) {
     ctx->krec_used = 0;
 }
 
+// twiddle / shift tables of the context's field parameters (allocated once, refilled by rk_set_params)
 static int build_tables(rk_ctx* ctx) {
     const ntt::TableLayout l = ntt::table_layout();
     std::vector<uint32_t> h(l.total);
-    ntt::fill_tables(h.data());
-    RK_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tables, l.total * sizeof(uint32_t)));
+    ntt::fill_tables(h.data(), ctx->sys.root27m, ctx->sys.shiftm);
+    if (!ctx->d_tables) RK_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tables, l.total * sizeof(uint32_t)));
     RK_HIP_TRY(ctx, hipMemcpy(ctx->d_tables, h.data(), l.total * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->tb = ntt::tables_at(ctx->d_tables);
+    return RK_OK;
+}
+static int upload_p2(rk_ctx* ctx) {
+    if (!ctx->d_p2) RK_HIP_TRY(ctx, hipMalloc(&ctx->d_p2, p2::Any::max_raw_size()));
+    RK_HIP_TRY(ctx, hipMemcpy(ctx->d_p2, ctx->h_p2.raw(), ctx->h_p2.raw_size(), hipMemcpyHostToDevice));
     return RK_OK;
 }
 
@@ -170,17 +176,13 @@ int rk_ctx_create(int device, void* stream, rk_ctx** out) {
             if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = RK_ERR_HIP; break; }
             ctx->own_stream = true;
         }
+        rk_params def;
+        rk::params_preset(&def, RK_PRESET_RISC0);
+        st = rk::resolve_params(&def, &ctx->sys, &ctx->h_p2);
+        if (st != RK_OK) break;
         st = rk::build_tables(ctx);
         if (st != RK_OK) break;
-        std::memcpy(ctx->h_p2.rc_ext, P2_RC_EXT_MONT, sizeof ctx->h_p2.rc_ext);
-        std::memcpy(ctx->h_p2.rc_int, P2_RC_INT_MONT, sizeof ctx->h_p2.rc_int);
-        std::memcpy(ctx->h_p2.diag, P2_INT_DIAG_MONT, sizeof ctx->h_p2.diag);
-        p2::derive(ctx->h_p2);
-        if (hipMalloc((void**)&ctx->d_p2, sizeof(p2::Consts)) != hipSuccess) { st = RK_ERR_NOMEM; break; }
-        if (hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice) != hipSuccess) {
-            st = RK_ERR_HIP;
-            break;
-        }
+        st = rk::upload_p2(ctx);
     } while (0);
     if (st != RK_OK) {
         rk_ctx_destroy(ctx);
@@ -244,21 +246,57 @@ int rk_d2h(rk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     return RK_OK;
 }
 
+// width-24 tables of the paper's instance (the ABI-1 entry point): the rest of the parameter set stays
 int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t* rc_int, const uint32_t* diag) {
+    RK_GUARD_BEGIN
     if (!ctx || !rc_ext || !rc_int || !diag) return RK_ERR_INVALID;
-    for (size_t i = 0; i < sizeof ctx->h_p2.rc_ext / 4; i++)
-        if (rc_ext[i] >= bb::P) return RK_ERR_INVALID;
-    for (int i = 0; i < p2::ROUNDS_PARTIAL; i++)
-        if (rc_int[i] >= bb::P) return RK_ERR_INVALID;
-    for (int i = 0; i < p2::CELLS; i++)
-        if (diag[i] >= bb::P) return RK_ERR_INVALID;
-    std::memcpy(ctx->h_p2.rc_ext, rc_ext, sizeof ctx->h_p2.rc_ext);
-    std::memcpy(ctx->h_p2.rc_int, rc_int, sizeof ctx->h_p2.rc_int);
-    std::memcpy(ctx->h_p2.diag, diag, sizeof ctx->h_p2.diag);
-    p2::derive(ctx->h_p2);
+    rk_params p;
+    RK_TRY(rk_get_params(ctx, &p));
+    if (p.p2_width != 24) return RK_ERR_INVALID;
+    p.p2_rc_ext = rc_ext;
+    p.p2_rc_int = rc_int;
+    p.p2_diag = diag;
+    return rk_set_params(ctx, &p);
+    RK_GUARD_END
+}
+
+int rk_params_preset(rk_params* out, int preset) {
+    if (!out || (preset != RK_PRESET_RISC0 && preset != RK_PRESET_SP1)) return RK_ERR_INVALID;
+    rk::params_preset(out, preset);
+    return RK_OK;
+}
+int rk_set_params(rk_ctx* ctx, const rk_params* params) {
+    RK_GUARD_BEGIN
+    if (!ctx || !params) return RK_ERR_INVALID;
+    rk::Sys sys;
+    auto p2any = std::make_unique<p2::Any>();  // ~50 KiB: not on the stack
+    RK_TRY(rk::resolve_params(params, &sys, p2any.get()));
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    RK_HIP_TRY(ctx, hipMemcpy(ctx->d_p2, &ctx->h_p2, sizeof(p2::Consts), hipMemcpyHostToDevice));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // kernels in flight read the old tables
+    const bool field_changed = sys.root27m != ctx->sys.root27m || sys.shiftm != ctx->sys.shiftm;
+    ctx->sys = sys;
+    ctx->h_p2 = *p2any;
+    if (field_changed) RK_TRY(rk::build_tables(ctx));
+    return rk::upload_p2(ctx);
+    RK_GUARD_END
+}
+int rk_get_params(rk_ctx* ctx, rk_params* out) {
+    if (!ctx || !out) return RK_ERR_INVALID;
+    *out = rk_params{};
+    out->struct_size = (uint32_t)sizeof(rk_params);
+    out->ext_w = ctx->sys.ext_w;
+    out->root_2_27 = ctx->sys.root_2_27;
+    out->coset_shift = ctx->sys.coset_shift;
+    out->p2_width = (uint32_t)ctx->h_p2.cells();
+    out->p2_m4 = (uint32_t)ctx->h_p2.m4();
+    out->p2_pad_free = ctx->h_p2.pad_free ? 1u : 0u;
+    out->p2_rc_ext = ctx->h_p2.rc_ext();
+    out->p2_rc_int = ctx->h_p2.rc_int();
+    out->p2_diag = ctx->h_p2.diag();
+    out->queries = ctx->sys.queries;
+    out->blowup_log2 = ctx->sys.blowup_log2;
+    out->fri_fold_log2 = ctx->sys.fri_fold_log2;
+    out->fri_min_degree = ctx->sys.fri_min_degree;
     return RK_OK;
 }
 

@@ -13,6 +13,7 @@
 #include "bb.hpp"
 #include "ntt_core.hpp"
 #include "poseidon2_core.hpp"
+#include "params.hpp"
 
 struct rk_ctx {
     int device = 0;
@@ -24,9 +25,11 @@ struct rk_ctx {
     uint32_t* d_tables = nullptr;
     ntt::Tables tb{};
 
-    // Poseidon2 constants: host copy for the transcript, device copy for kernels
-    p2::Consts h_p2{};
-    p2::Consts* d_p2 = nullptr;
+    // the parameter set (rk_set_params): field / protocol values and the Poseidon2 instance -- host copy
+    // for the transcript, device copy (the active Core's Consts) for the kernels
+    rk::Sys sys{};
+    p2::Any h_p2{};
+    void* d_p2 = nullptr;
 
     // caching allocator (exact-size free lists) so steady-state proving never calls hipMalloc
     std::multimap<size_t, void*> free_list;

@@ -8,45 +8,58 @@ namespace {
 
 constexpr int HASH_BLOCK = 256;
 
+// C = the configured p2::Core (width 24 or 16, external 4x4 block): one kernel instance per Core.
+// pad_free: the last partial block leaves the remaining rate cells as they are (Plonky3
+// PaddingFreeSponge) instead of zero-padding them (risc0); an empty row then takes no permutation.
+template <class C>
 __global__ __launch_bounds__(HASH_BLOCK) void hash_rows_kernel(uint32_t* __restrict__ out,
                                                                const uint32_t* __restrict__ matrix, size_t rows,
-                                                               size_t cols, const p2::Consts* __restrict__ kc) {
+                                                               size_t cols, const typename C::Consts* __restrict__ kc,
+                                                               int pad_free) {
     size_t row = (size_t)blockIdx.x * HASH_BLOCK + threadIdx.x;
     if (row >= rows) return;
-    const p2::Consts& k = *kc;
-    uint32_t s[p2::CELLS];
+    const typename C::Consts& k = *kc;
+    uint32_t s[C::CELLS];
 #pragma unroll
-    for (int i = 0; i < p2::CELLS; i++) s[i] = 0;
-    size_t full = cols / p2::RATE;
+    for (int i = 0; i < C::CELLS; i++) s[i] = 0;
+    size_t full = cols / C::RATE;
     const uint32_t* src = matrix + row;
     for (size_t b = 0; b < full; b++) {
 #pragma unroll
-        for (int i = 0; i < p2::RATE; i++) s[i] = src[(b * p2::RATE + i) * rows];
-        p2::permute(s, k);
+        for (int i = 0; i < C::RATE; i++) s[i] = src[(b * C::RATE + i) * rows];
+        C::permute(s, k);
     }
-    size_t rem = cols - full * p2::RATE;
-    if (rem != 0 || cols == 0) {
+    size_t rem = cols - full * C::RATE;
+    if (rem != 0 || (cols == 0 && !pad_free)) {
 #pragma unroll
-        for (int i = 0; i < p2::RATE; i++) s[i] = (size_t)i < rem ? src[(full * p2::RATE + i) * rows] : 0u;
-        p2::permute(s, k);
+        for (int i = 0; i < C::RATE; i++) {
+            if ((size_t)i < rem) s[i] = src[(full * C::RATE + i) * rows];
+            else if (!pad_free) s[i] = 0u;
+        }
+        C::permute(s, k);
     }
     uint4* o = reinterpret_cast<uint4*>(out + row * p2::OUT);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// nodes[out_size + i] = H(nodes[2*(out_size+i)] || nodes[2*(out_size+i)+1])
+// nodes[out_size + i] = H(nodes[2*(out_size+i)] || nodes[2*(out_size+i)+1]): the two digests fill
+// cells 0..15, the rest of a wider state is zero; the parent is the first 8 cells
+template <class C>
 __global__ __launch_bounds__(HASH_BLOCK) void hash_fold_kernel(uint32_t* __restrict__ nodes, size_t out_size,
-                                                               const p2::Consts* __restrict__ kc) {
+                                                               const typename C::Consts* __restrict__ kc) {
     size_t i = (size_t)blockIdx.x * HASH_BLOCK + threadIdx.x;
     if (i >= out_size) return;
-    const p2::Consts& k = *kc;
+    const typename C::Consts& k = *kc;
     size_t idx = out_size + i;
     const uint4* in = reinterpret_cast<const uint4*>(nodes + 2 * idx * p2::OUT);
     uint4 a = in[0], b = in[1], c = in[2], d = in[3];
-    uint32_t s[p2::CELLS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w,
-                             d.x, d.y, d.z, d.w, 0,   0,   0,   0,   0,   0,   0,   0};
-    p2::permute(s, k);
+    uint32_t s[C::CELLS];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = c.w; s[12] = d.x; s[13] = d.y; s[14] = d.z; s[15] = d.w;
+#pragma unroll
+    for (int j = 16; j < C::CELLS; j++) s[j] = 0;
+    C::permute(s, k);
     uint4* o = reinterpret_cast<uint4*>(nodes + idx * p2::OUT);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
@@ -56,22 +69,23 @@ __global__ __launch_bounds__(HASH_BLOCK) void hash_fold_kernel(uint32_t* __restr
 // steps, every parent is also written to its heap slot in HBM.  Replaces ~11 latency-bound
 // launches per tree.
 constexpr int TAIL_MAX = 1024;
+template <class C>
 __global__ __launch_bounds__(TAIL_MAX) void hash_fold_tail_kernel(uint32_t* __restrict__ nodes, unsigned top_out,
-                                                                  const p2::Consts* __restrict__ kc) {
+                                                                  const typename C::Consts* __restrict__ kc) {
     __shared__ uint32_t level[2 * TAIL_MAX * p2::OUT];
     const unsigned tid = threadIdx.x;
-    const p2::Consts& k = *kc;
+    const typename C::Consts& k = *kc;
     for (unsigned i = tid; i < 2 * top_out * p2::OUT; i += blockDim.x) level[i] = nodes[(size_t)2 * top_out * p2::OUT + i];
     __syncthreads();
     for (unsigned out = top_out; out >= 1; out >>= 1) {
-        uint32_t s[p2::CELLS];
+        uint32_t s[C::CELLS];
         const bool active = tid < out;
         if (active) {
 #pragma unroll
             for (int i = 0; i < 2 * p2::OUT; i++) s[i] = level[2 * tid * p2::OUT + i];
 #pragma unroll
-            for (int i = 2 * p2::OUT; i < p2::CELLS; i++) s[i] = 0;
-            p2::permute(s, k);
+            for (int i = 2 * p2::OUT; i < C::CELLS; i++) s[i] = 0;
+            C::permute(s, k);
         }
         __syncthreads();  // every child has been read before the level is overwritten
         if (active) {
@@ -85,6 +99,15 @@ __global__ __launch_bounds__(TAIL_MAX) void hash_fold_tail_kernel(uint32_t* __re
     }
 }
 
+// run F<Core> for the context's Poseidon2 instance
+#define RK_P2_DISPATCH(ctx, CALL)                         \
+    switch ((ctx)->h_p2.kind) {                           \
+        case 0: { using C = p2::K0; CALL; } break;        \
+        case 1: { using C = p2::K1; CALL; } break;        \
+        case 2: { using C = p2::K2; CALL; } break;        \
+        default: { using C = p2::K3; CALL; } break;       \
+    }
+
 }  // namespace
 
 namespace rk {
@@ -94,8 +117,9 @@ int hash_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_matrix, size_t row
     size_t blocks = (rows + HASH_BLOCK - 1) / HASH_BLOCK;
     if (blocks > 0x7fffffffu) return RK_ERR_INVALID;
     KTimer kt(ctx, RK_KCLASS_HASH_ROWS, (double)rows * cols * 4 + (double)rows * 32);
-    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_out, d_matrix, rows,
-                       cols, ctx->d_p2);
+    RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_rows_kernel<C>, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_out,
+                                           d_matrix, rows, cols, (const typename C::Consts*)ctx->d_p2,
+                                           ctx->h_p2.pad_free ? 1 : 0));
     return post_launch(ctx, "hash_rows_kernel");
 }
 
@@ -104,8 +128,8 @@ int hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t output_size) {
     size_t blocks = (output_size + HASH_BLOCK - 1) / HASH_BLOCK;
     if (blocks > 0x7fffffffu) return RK_ERR_INVALID;
     KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)output_size * 96);
-    hipLaunchKernelGGL(hash_fold_kernel, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_nodes, output_size,
-                       ctx->d_p2);
+    RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_fold_kernel<C>, dim3((unsigned)blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_nodes,
+                                           output_size, (const typename C::Consts*)ctx->d_p2));
     return post_launch(ctx, "hash_fold_kernel");
 }
 
@@ -122,8 +146,8 @@ int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
     if (!is_pow2(top_output_size) || top_output_size > TAIL_MAX) return RK_ERR_INVALID;
     unsigned threads = top_output_size < 64 ? 64u : (unsigned)top_output_size;
     KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)(2 * top_output_size - 1) * 96);
-    hipLaunchKernelGGL(hash_fold_tail_kernel, dim3(1), dim3(threads), 0, ctx->stream, d_nodes, (unsigned)top_output_size,
-                       ctx->d_p2);
+    RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_fold_tail_kernel<C>, dim3(1), dim3(threads), 0, ctx->stream, d_nodes,
+                                           (unsigned)top_output_size, (const typename C::Consts*)ctx->d_p2));
     return post_launch(ctx, "hash_fold_tail_kernel");
 }
 

@@ -170,10 +170,11 @@ int launch_pass(rk_ctx* ctx, const ntt::PassArgs& a, size_t count) {
 // per-size tables of the fused kernels, shared by every context of a device for the life of the
 // process (immutable once built): kind 0 / 1 = four-step twiddles forward / inverse, 2 = zk * 1/n
 std::mutex g_nf_mu;
-std::map<std::tuple<int, int, unsigned>, uint32_t*> g_nf_tables;
+// key: device, kind, log2 size, and the field parameters the entries depend on (root generator, coset shift)
+std::map<std::tuple<int, int, unsigned, uint32_t, uint32_t>, uint32_t*> g_nf_tables;
 int nf_table(rk_ctx* ctx, int kind, unsigned k, const uint32_t** out) {
     std::lock_guard<std::mutex> l(g_nf_mu);
-    auto key = std::make_tuple(ctx->device, kind, k);
+    auto key = std::make_tuple(ctx->device, kind, k, ctx->sys.root27m, kind == 2 ? ctx->sys.shiftm : 0u);
     auto it = g_nf_tables.find(key);
     if (it != g_nf_tables.end()) {
         *out = it->second;

@@ -48,16 +48,19 @@ __global__ void sum_ext_kernel(uint32_t* out, const uint32_t* in, size_t count, 
 struct FoldPows {
     Ext p[16];
 };
-__global__ void fri_fold_kernel(uint32_t* out, const uint32_t* in, size_t count, FoldPows pw) {
+// fold by A = 2^LOG_A: out[idx] = sum_{i < A} mix^i * in[bitrev(i) * count + idx] over 4 planes of A * count
+template <int LOG_A>
+__global__ void fri_fold_kernel(uint32_t* out, const uint32_t* in, size_t count, FoldPows pw, uint32_t wm) {
+    constexpr unsigned A = 1u << LOG_A;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     for (; idx < count; idx += st) {
         Ext tot = bb::ext_zero();
 #pragma unroll
-        for (unsigned i = 0; i < 16; i++) {
-            unsigned rev_i = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+        for (unsigned i = 0; i < A; i++) {
+            unsigned rev_i = bb::bitrev(i, LOG_A);
             size_t ri = (size_t)rev_i * count + idx;
-            Ext f{{in[ri], in[count * 16 + ri], in[count * 32 + ri], in[count * 48 + ri]}};
-            tot = bb::add(tot, bb::mul(pw.p[i], f));
+            Ext f{{in[ri], in[count * A + ri], in[count * 2 * A + ri], in[count * 3 * A + ri]}};
+            tot = bb::add(tot, bb::mul(pw.p[i], f, wm));
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) out[(size_t)k * count + idx] = tot.c[k];
@@ -84,16 +87,16 @@ __global__ void gather_digests_kernel(uint32_t* dst, const uint32_t* nodes, cons
 // pw[k] = x^k: each lane seeds x^(lane_start) by square-and-multiply, then walks CH powers
 constexpr int PW_CH = 32;
 // rev_bits != 0: x^k is stored at position bitrev(k), matching bit-reversed coefficient storage
-__global__ void ext_powers_kernel(uint32_t* pw, Ext x, size_t n, unsigned rev_bits) {
+__global__ void ext_powers_kernel(uint32_t* pw, Ext x, size_t n, unsigned rev_bits, uint32_t wm) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t start = t * PW_CH;
     if (start >= n) return;
-    Ext cur = bb::pow(x, (uint64_t)start);
+    Ext cur = bb::pow(x, (uint64_t)start, wm);
     size_t end = start + PW_CH < n ? start + PW_CH : n;
     for (size_t k = start; k < end; k++) {
         size_t pos = rev_bits ? (size_t)bb::bitrev((uint32_t)k, rev_bits) : k;
         store_ext(pw + pos * 4, cur);
-        cur = bb::mul(cur, x);
+        cur = bb::mul(cur, x, wm);
     }
 }
 // in-place bit reversal of `count` polynomials of `size` extension elements (16-byte items)
@@ -200,6 +203,8 @@ constexpr int DIV_GRP = 32;    // segments per leader lane
 struct DivItem {
     Ext z, zL;               // divisor point, z^DIV_CH
     unsigned long long off;  // first ext element of the polynomial
+    uint32_t wm;             // the extension's W (Montgomery form)
+    uint32_t pad_;
 };
 // tops[item][b] = sum_{k in chunk b} c[k] z^(k - start_b)
 __global__ void div_tops_kernel(uint32_t* tops, const uint32_t* base, size_t count, size_t nchunks, const DivItem* items) {
@@ -210,7 +215,7 @@ __global__ void div_tops_kernel(uint32_t* tops, const uint32_t* base, size_t cou
     size_t start = b * DIV_CH;
     size_t end = start + DIV_CH < count ? start + DIV_CH : count;
     Ext s = bb::ext_zero();
-    for (size_t k = end; k-- > start;) s = bb::add(bb::mul(s, it.z), load_ext(poly + k * 4));
+    for (size_t k = end; k-- > start;) s = bb::add(bb::mul(s, it.z, it.wm), load_ext(poly + k * 4));
     store_ext(tops + ((size_t)blockIdx.y * nchunks + b) * 4, s);
 }
 // carry[b] = T[b+1] with T[b] = tops[b] + zL * T[b+1], T[nchunks] = 0; rem = T[0] = f(z)
@@ -227,18 +232,18 @@ __global__ __launch_bounds__(DIV_NT) void div_carry_kernel(uint32_t* carry, cons
     // A: value at the segment's first chunk with zero carry-in (missing chunks count as zero)
     Ext acc = bb::ext_zero();
     if (s0 < nchunks)
-        for (size_t b = s1; b-- > s0;) acc = bb::add(bb::mul(acc, it.zL), load_ext(tops + b * 4));
+        for (size_t b = s1; b-- > s0;) acc = bb::add(bb::mul(acc, it.zL, it.wm), load_ext(tops + b * 4));
 #pragma unroll
     for (int j = 0; j < 4; j++) seg[t * 4 + j] = acc.c[j];
     __syncthreads();
-    const Ext zseg = bb::pow(it.zL, (uint64_t)per);
+    const Ext zseg = bb::pow(it.zL, (uint64_t)per, it.wm);
     // B: leaders fold their DIV_GRP segments
     if (t < DIV_GRP) {
         Ext g = bb::ext_zero();
         for (int i = DIV_GRP - 1; i >= 0; i--) {
             unsigned sidx = t * DIV_GRP + i;
             Ext top{{seg[sidx * 4], seg[sidx * 4 + 1], seg[sidx * 4 + 2], seg[sidx * 4 + 3]}};
-            g = bb::add(top, bb::mul(zseg, g));
+            g = bb::add(top, bb::mul(zseg, g, it.wm));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) sup[t * 4 + j] = g.c[j];
@@ -246,13 +251,13 @@ __global__ __launch_bounds__(DIV_NT) void div_carry_kernel(uint32_t* carry, cons
     __syncthreads();
     // C: one lane walks the groups from the top; sup[] becomes the carry entering each group
     if (t == 0) {
-        const Ext zsup = bb::pow(zseg, (uint64_t)DIV_GRP);
+        const Ext zsup = bb::pow(zseg, (uint64_t)DIV_GRP, it.wm);
         Ext run = bb::ext_zero();
         for (int u = DIV_GRP - 1; u >= 0; u--) {
             Ext top{{sup[u * 4], sup[u * 4 + 1], sup[u * 4 + 2], sup[u * 4 + 3]}};
 #pragma unroll
             for (int j = 0; j < 4; j++) sup[u * 4 + j] = run.c[j];
-            run = bb::add(top, bb::mul(zsup, run));
+            run = bb::add(top, bb::mul(zsup, run, it.wm));
         }
         store_ext(rem_out + (size_t)blockIdx.y * 4, run);
     }
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(DIV_NT) void div_carry_kernel(uint32_t* carry, cons
             Ext top{{seg[sidx * 4], seg[sidx * 4 + 1], seg[sidx * 4 + 2], seg[sidx * 4 + 3]}};
 #pragma unroll
             for (int j = 0; j < 4; j++) seg[sidx * 4 + j] = run.c[j];
-            run = bb::add(top, bb::mul(zseg, run));
+            run = bb::add(top, bb::mul(zseg, run, it.wm));
         }
     }
     __syncthreads();
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(DIV_NT) void div_carry_kernel(uint32_t* carry, cons
         Ext run{{seg[t * 4], seg[t * 4 + 1], seg[t * 4 + 2], seg[t * 4 + 3]}};
         for (size_t b = s1; b-- > s0;) {
             store_ext(carry + b * 4, run);
-            run = bb::add(load_ext(tops + b * 4), bb::mul(it.zL, run));
+            run = bb::add(load_ext(tops + b * 4), bb::mul(it.zL, run, it.wm));
         }
     }
 }
@@ -288,7 +293,7 @@ __global__ void div_apply_kernel(uint32_t* base, const uint32_t* carry, size_t c
     size_t end = start + DIV_CH < count ? start + DIV_CH : count;
     Ext cur = load_ext(carry + ((size_t)blockIdx.y * nchunks + b) * 4);
     for (size_t k = end; k-- > start;) {
-        Ext next = bb::add(bb::mul(it.z, cur), load_ext(poly + k * 4));
+        Ext next = bb::add(bb::mul(it.z, cur, it.wm), load_ext(poly + k * 4));
         store_ext(poly + k * 4, cur);
         cur = next;
     }
@@ -323,11 +328,19 @@ int eltwise_sum_ext(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t c
 }
 int fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const bb::Ext& mix) {
     if (out_count == 0) return RK_ERR_INVALID;
+    const uint32_t wm = ctx->sys.wm;
+    const unsigned log_a = ctx->sys.fri_fold_log2, a = 1u << log_a;
     FoldPows pw;
     pw.p[0] = bb::ext_one();
-    for (int i = 1; i < 16; i++) pw.p[i] = bb::mul(pw.p[i - 1], mix);
-    KTimer kt(ctx, RK_KCLASS_POLY, (double)out_count * 17 * 16);
-    hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(out_count)), dim3(TPB), 0, ctx->stream, d_out, d_in, out_count, pw);
+    for (unsigned i = 1; i < 16; i++) pw.p[i] = i < a ? bb::mul(pw.p[i - 1], mix, wm) : bb::ext_zero();
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)out_count * (a + 1) * 16);
+    const dim3 grid(grid_for(out_count)), blk(TPB);
+    switch (log_a) {
+        case 1: hipLaunchKernelGGL(fri_fold_kernel<1>, grid, blk, 0, ctx->stream, d_out, d_in, out_count, pw, wm); break;
+        case 2: hipLaunchKernelGGL(fri_fold_kernel<2>, grid, blk, 0, ctx->stream, d_out, d_in, out_count, pw, wm); break;
+        case 3: hipLaunchKernelGGL(fri_fold_kernel<3>, grid, blk, 0, ctx->stream, d_out, d_in, out_count, pw, wm); break;
+        default: hipLaunchKernelGGL(fri_fold_kernel<4>, grid, blk, 0, ctx->stream, d_out, d_in, out_count, pw, wm); break;
+    }
     return post_launch(ctx, "fri_fold_kernel");
 }
 int gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {
@@ -357,7 +370,7 @@ int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool
     size_t lanes = (n + PW_CH - 1) / PW_CH;
     KTimer kt(ctx, RK_KCLASS_POLY, (double)n * 16);
     hipLaunchKernelGGL(ext_powers_kernel, dim3((unsigned)((lanes + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_pw_ext,
-                       x, n, bit_reversed ? log2u(n) : 0u);
+                       x, n, bit_reversed ? log2u(n) : 0u, ctx->sys.wm);
     return post_launch(ctx, "ext_powers_kernel");
 }
 int bit_reverse_ext(rk_ctx* ctx, uint32_t* d_io_ext, size_t size, size_t count) {
@@ -400,7 +413,7 @@ int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, 
     bb::Ext cur = mix_start;
     for (size_t i = 0; i < input_size; i++) {
         pw[i] = cur;
-        cur = bb::mul(cur, mix);
+        cur = bb::mul(cur, mix, ctx->sys.wm);
     }
     std::vector<uint32_t> slot_combo, slot_off, cols(input_size), pows(input_size * 4);
     for (size_t t = 0; t < input_size; t++) {
@@ -443,8 +456,10 @@ int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size
     std::vector<DivItem> items(n_items);
     for (size_t i = 0; i < n_items; i++) {
         items[i].z = h_z[i];
-        items[i].zL = bb::pow(h_z[i], (uint64_t)DIV_CH);
+        items[i].zL = bb::pow(h_z[i], (uint64_t)DIV_CH, ctx->sys.wm);
         items[i].off = h_offsets[i];
+        items[i].wm = ctx->sys.wm;
+        items[i].pad_ = 0;
     }
     void* buf = nullptr;
     size_t items_bytes = (n_items * sizeof(DivItem) + 15) & ~(size_t)15;

@@ -21,7 +21,7 @@ __device__ __forceinline__ void store_ext(uint32_t* p, const Ext& e) {
 }
 
 // inclusive scan of one value per lane across the workgroup (Hillis-Steele through LDS)
-__device__ Ext block_scan(Ext v, Ext* sh) {
+__device__ Ext block_scan(Ext v, Ext* sh, uint32_t wm) {
     const int t = threadIdx.x;
     sh[t] = v;
     __syncthreads();
@@ -29,7 +29,7 @@ __device__ Ext block_scan(Ext v, Ext* sh) {
         Ext o = t >= d ? sh[t - d] : bb::ext_one();
         __syncthreads();
         if (t >= d) {
-            v = bb::mul(o, v);
+            v = bb::mul(o, v, wm);
             sh[t] = v;
         }
         __syncthreads();
@@ -38,35 +38,35 @@ __device__ Ext block_scan(Ext v, Ext* sh) {
 }
 
 // product of each workgroup's SCAN_BLOCK elements
-__global__ void scan_totals_kernel(uint32_t* totals, const uint32_t* io, size_t count) {
+__global__ void scan_totals_kernel(uint32_t* totals, const uint32_t* io, size_t count, uint32_t wm) {
     __shared__ Ext sh[SCAN_TPB];
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_CH;
     Ext acc = bb::ext_one();
 #pragma unroll
     for (int j = 0; j < SCAN_CH; j++)
-        if (base + j < count) acc = bb::mul(acc, load_ext(io + (base + j) * 4));
-    acc = block_scan(acc, sh);
+        if (base + j < count) acc = bb::mul(acc, load_ext(io + (base + j) * 4), wm);
+    acc = block_scan(acc, sh, wm);
     if (threadIdx.x == SCAN_TPB - 1) store_ext(totals + (size_t)blockIdx.x * 4, acc);
 }
 // in-place inclusive scan of n totals by ONE workgroup: lanes take contiguous runs
-__global__ void scan_carry_kernel(uint32_t* totals, size_t n) {
+__global__ void scan_carry_kernel(uint32_t* totals, size_t n, uint32_t wm) {
     __shared__ Ext sh[SCAN_TPB];
     size_t per = (n + SCAN_TPB - 1) / SCAN_TPB;
     size_t lo = (size_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     Ext acc = bb::ext_one();
-    for (size_t i = lo; i < hi; i++) acc = bb::mul(acc, load_ext(totals + i * 4));
-    Ext incl = block_scan(acc, sh);
+    for (size_t i = lo; i < hi; i++) acc = bb::mul(acc, load_ext(totals + i * 4), wm);
+    Ext incl = block_scan(acc, sh, wm);
     __syncthreads();
     sh[threadIdx.x] = incl;
     __syncthreads();
     Ext run = threadIdx.x ? sh[threadIdx.x - 1] : bb::ext_one();
     for (size_t i = lo; i < hi; i++) {
-        run = bb::mul(run, load_ext(totals + i * 4));
+        run = bb::mul(run, load_ext(totals + i * 4), wm);
         store_ext(totals + i * 4, run);
     }
 }
 // final pass: carry-in of the workgroup (scanned totals of the groups before it) times the local scan
-__global__ void scan_apply_kernel(uint32_t* io, const uint32_t* totals, size_t count) {
+__global__ void scan_apply_kernel(uint32_t* io, const uint32_t* totals, size_t count, uint32_t wm) {
     __shared__ Ext sh[SCAN_TPB];
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_CH;
     Ext v[SCAN_CH];
@@ -74,18 +74,18 @@ __global__ void scan_apply_kernel(uint32_t* io, const uint32_t* totals, size_t c
 #pragma unroll
     for (int j = 0; j < SCAN_CH; j++) {
         v[j] = base + j < count ? load_ext(io + (base + j) * 4) : bb::ext_one();
-        acc = bb::mul(acc, v[j]);
+        acc = bb::mul(acc, v[j], wm);
         v[j] = acc;
     }
-    Ext incl = block_scan(acc, sh);
+    Ext incl = block_scan(acc, sh, wm);
     __syncthreads();
     sh[threadIdx.x] = incl;
     __syncthreads();
     Ext carry = blockIdx.x ? load_ext(totals + ((size_t)blockIdx.x - 1) * 4) : bb::ext_one();
-    if (threadIdx.x) carry = bb::mul(carry, sh[threadIdx.x - 1]);
+    if (threadIdx.x) carry = bb::mul(carry, sh[threadIdx.x - 1], wm);
 #pragma unroll
     for (int j = 0; j < SCAN_CH; j++)
-        if (base + j < count) store_ext(io + (base + j) * 4, bb::mul(carry, v[j]));
+        if (base + j < count) store_ext(io + (base + j) * 4, bb::mul(carry, v[j], wm));
 }
 
 // scatter with "last write wins": stamp = 1 + the largest entry index targeting each word
@@ -116,15 +116,15 @@ int prefix_products(rk_ctx* ctx, uint32_t* d_io_ext, size_t count) {
         KTimer kt(ctx, RK_KCLASS_POLY, (double)count * 48);
         if (blocks > 1) {
             hipLaunchKernelGGL(scan_totals_kernel, dim3((unsigned)blocks), dim3(SCAN_TPB), 0, ctx->stream,
-                               (uint32_t*)totals, d_io_ext, count);
+                               (uint32_t*)totals, d_io_ext, count, ctx->sys.wm);
             st = post_launch(ctx, "scan_totals_kernel");
             if (st != RK_OK) break;
-            hipLaunchKernelGGL(scan_carry_kernel, dim3(1), dim3(SCAN_TPB), 0, ctx->stream, (uint32_t*)totals, blocks);
+            hipLaunchKernelGGL(scan_carry_kernel, dim3(1), dim3(SCAN_TPB), 0, ctx->stream, (uint32_t*)totals, blocks, ctx->sys.wm);
             st = post_launch(ctx, "scan_carry_kernel");
             if (st != RK_OK) break;
         }
         hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)blocks), dim3(SCAN_TPB), 0, ctx->stream, d_io_ext,
-                           (const uint32_t*)totals, count);
+                           (const uint32_t*)totals, count, ctx->sys.wm);
         st = post_launch(ctx, "scan_apply_kernel");
     } while (0);
     dev_free(ctx, totals);  // stream-ordered reuse within this ctx

@@ -31,8 +31,8 @@ struct Tables {
     const uint32_t* small[2];
     const uint32_t* hi[2];     // W^{+-(a << TW_SPLIT)}, W = w_{2^LAMBDA}, a < 2^(LAMBDA-TW_SPLIT)
     const uint32_t* lo[2];     // W^{+-b}, b < 2^TW_SPLIT
-    const uint32_t* pow3_hi;   // 3^(a << TW_SPLIT)
-    const uint32_t* pow3_lo;   // 3^b
+    const uint32_t* pow3_hi;   // shift^(a << TW_SPLIT), shift = the coset shift (3 for risc0)
+    const uint32_t* pow3_lo;   // shift^b
 };
 
 struct PassArgs {
@@ -432,13 +432,15 @@ inline void fill_pow(uint32_t* v, size_t n, uint32_t base) {
         cur = bb::mul(cur, base);
     }
 }
-// h must hold table_layout().total words
-inline void fill_tables(uint32_t* h) {
+// h must hold table_layout().total words.  root27 = a generator of the 2^27 subgroup, shift = the
+// coset shift of the zk / LDE domain, both Montgomery form (risc0: 137 and 3; rk_params)
+inline void fill_tables(uint32_t* h, uint32_t root27 = 0, uint32_t shift = 0) {
+    if (root27 == 0) root27 = bb::encode(137);  // 137 generates the 2^27 subgroup of BabyBear
+    if (shift == 0) shift = bb::encode(3);
     const TableLayout l = table_layout();
     const size_t n_hi = (size_t)1 << (LAMBDA - TW_SPLIT);
     const size_t n_lo = (size_t)1 << TW_SPLIT;
-    // 137 generates the 2^27 subgroup of BabyBear
-    uint32_t W = bb::pow(bb::encode(137), (uint64_t)1 << (27 - LAMBDA));
+    uint32_t W = bb::pow(root27, (uint64_t)1 << (27 - LAMBDA));
     uint32_t Winv = bb::inv(W);
     for (int d = 0; d < 2; d++) {
         h[l.small[d]] = bb::ONE;  // slot 0 unused
@@ -453,9 +455,8 @@ inline void fill_tables(uint32_t* h) {
         fill_pow(h + l.hi[d], n_hi, bb::pow(g, (uint64_t)1 << TW_SPLIT));
         fill_pow(h + l.lo[d], n_lo, g);
     }
-    uint32_t three = bb::encode(3);
-    fill_pow(h + l.pow3_hi, n_hi, bb::pow(three, (uint64_t)1 << TW_SPLIT));
-    fill_pow(h + l.pow3_lo, n_lo, three);
+    fill_pow(h + l.pow3_hi, n_hi, bb::pow(shift, (uint64_t)1 << TW_SPLIT));
+    fill_pow(h + l.pow3_lo, n_lo, shift);
 }
 inline Tables tables_at(const uint32_t* base) {
     const TableLayout l = table_layout();

@@ -27,93 +27,8 @@
 
 namespace p2 {
 
-constexpr int CELLS = 24;
-constexpr int RATE = 16;
-constexpr int OUT = 8;
-constexpr int ROUNDS_HALF_FULL = 4;
-constexpr int ROUNDS_PARTIAL = 21;
-
-// per round r: 23 pairs d_i^r, r pairs c_(r-1-j), then d_0 + 1; at the end 23 x (d_i^21, d_i^(20-j))
-constexpr int PR_STREAM_USED = ROUNDS_PARTIAL * (2 * (CELLS - 1) + 1) + ROUNDS_PARTIAL * (ROUNDS_PARTIAL - 1) +
-                               (CELLS - 1) * 2 * (ROUNDS_PARTIAL + 1);
-constexpr int PR_STREAM_WORDS = (PR_STREAM_USED + 15) / 16 * 16 + 16;
-
-struct Consts {
-    // the instance (Montgomery form), set by the caller
-    uint32_t rc_ext[2 * ROUNDS_HALF_FULL * CELLS];
-    uint32_t rc_int[ROUNDS_PARTIAL];
-    uint32_t diag[CELLS];
-    // derived by derive()
-    uint32_t rc_ext_in[2 * ROUNDS_HALF_FULL * CELLS];  // rc * scale(round) as the S-box input offset: rc - p after an
-                                                       // unsigned state (rounds 0, 4), centred in (-p/2, p/2] otherwise
-    uint32_t rc_int_mp[ROUNDS_PARTIAL];                // rc - p
-    uint32_t fix[2];                                   // block-end rescale constants 2^(32 (2 - e_end)), plain residues
-    uint32_t fix0_nq;                                  // fix[0] * (-p^-1) mod 2^32 (bb::umul_const companion)
-    uint32_t fix1_q;                                   // fix[1] * p^-1 mod 2^32 (bb::smul_const companion)
-    // partial rounds in closed form (see partial_rounds()): the constants in the order the
-    // code consumes them, each as a pair {c, c * 2^16 mod p} for the low / high 16-bit halves
-    // of the variable it multiplies (+ one chunk of padding for the read-ahead)
-    uint32_t pr_stream[PR_STREAM_WORDS];
-};
-
-// exponent e of the scale 2^(32 e) carried by the state at the S-box input of each full round
-// (first block follows the initial external layer + REDC; second block starts from Montgomery form)
-constexpr int SCALE_EXP[2 * ROUNDS_HALF_FULL] = {0, -7, -56, -399, 1, 0, -7, -56};
-
-inline void derive(Consts& k) {
-    const uint32_t Rm = bb::encode(bb::ONE);  // Montgomery form of the field element 2^32
-    const uint32_t Rinv_m = bb::inv(Rm);
-    auto rpow = [&](long e) {  // Montgomery form of 2^(32 e)
-        return e >= 0 ? bb::pow(Rm, (uint64_t)e) : bb::pow(Rinv_m, (uint64_t)(-e));
-    };
-    for (int r = 0; r < 2 * ROUNDS_HALF_FULL; r++) {
-        // stored residue v = rc * 2^32 (Montgomery form).  The S-box input of round r holds the
-        // residue a * 2^(32 e) for the true state a, so the residue to add is rc * 2^(32 e):
-        // bb::mul(v, f) = v * f / 2^32 with the residue f = 2^(32 e) = rpow(e - 1).
-        uint32_t f = rpow((long)SCALE_EXP[r] - 1);
-        const bool after_unsigned = r % ROUNDS_HALF_FULL == 0;  // input in [0, p + 2^22): offset rc - p
-        for (int i = 0; i < CELLS; i++) {
-            uint32_t c = bb::mul(k.rc_ext[r * CELLS + i], f);
-            // otherwise the input is a signed REDC output, |x| <= p/2 + 53: centred offset, |x + rc| < 2^31
-            k.rc_ext_in[r * CELLS + i] = (after_unsigned || c > bb::P / 2) ? c - bb::P : c;
-        }
-    }
-    for (int i = 0; i < ROUNDS_PARTIAL; i++) k.rc_int_mp[i] = k.rc_int[i] - bb::P;
-    // a block ends with the state scaled by 2^(32 e_end), e_end = 7 e - 7 for the last round's e;
-    // x -> x * K / 2^32 with K = 2^(32 (2 - e_end)) (plain residue) gives Montgomery form
-    for (int b = 0; b < 2; b++) {
-        long e = SCALE_EXP[b * ROUNDS_HALF_FULL + ROUNDS_HALF_FULL - 1];
-        k.fix[b] = bb::decode(rpow(2 - (7 * e - 7)));
-    }
-    k.fix0_nq = k.fix[0] * (0u - bb::MPRIME);
-    k.fix1_q = k.fix[1] * bb::MPRIME;
-    // closed-form partial rounds: powers of the diagonal (Montgomery residues: they multiply a
-    // Montgomery-form variable and the sum goes through one REDC).  The constants that multiply
-    // the ENTRY cells also carry fix[0]: those cells arrive scaled by the first block.
-    const uint32_t two16 = bb::encode(65536u);
-    uint32_t pw[CELLS - 1][ROUNDS_PARTIAL + 1];
-    for (int i = 1; i < CELLS; i++) {
-        pw[i - 1][0] = bb::ONE;
-        for (int m = 1; m <= ROUNDS_PARTIAL; m++) pw[i - 1][m] = bb::mul(pw[i - 1][m - 1], k.diag[i]);
-    }
-    uint32_t csum[ROUNDS_PARTIAL];
-    for (int m = 0; m < ROUNDS_PARTIAL; m++) {
-        csum[m] = 0;
-        for (int i = 0; i < CELLS - 1; i++) csum[m] = bb::add(csum[m], pw[i][m]);
-    }
-    int n = 0;
-    auto put = [&](uint32_t c) { k.pr_stream[n++] = c; k.pr_stream[n++] = bb::mul(c, two16); };
-    for (int r = 0; r < ROUNDS_PARTIAL; r++) {
-        for (int i = 0; i < CELLS - 1; i++) put(bb::mul(pw[i][r], k.fix[0]));
-        for (int j = 0; j < r; j++) put(csum[r - 1 - j]);
-        k.pr_stream[n++] = bb::add(k.diag[0], bb::ONE);
-    }
-    for (int i = 0; i < CELLS - 1; i++) {
-        put(bb::mul(pw[i][ROUNDS_PARTIAL], k.fix[0]));
-        for (int j = 0; j < ROUNDS_PARTIAL; j++) put(pw[i][ROUNDS_PARTIAL - 1 - j]);
-    }
-    while (n < PR_STREAM_WORDS) k.pr_stream[n++] = 0;
-}
+constexpr int OUT = 8;              // digest cells
+constexpr int ROUNDS_HALF_FULL = 4;  // R_F = 8
 
 // acc + x * c for a wave-uniform constant c (scalar register operand): one v_mad_u64_u32.
 // Plain C on purpose: an inline-asm mad makes the hazard recogniser pad every product with
@@ -163,93 +78,6 @@ RK_HD int64_t smulk(int32_t x) {
 #endif
 }
 
-// External layer circ(2*M4, M4, ..., M4), M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]], on
-// canonical cells, exact: w[i] < 112 p < 2^38.  Then s[i] = w[i] * 2^-32 (mod p) in [0, p + 53).
-RK_HD void m_ext_redc(uint32_t* s) {
-    uint64_t w[CELLS];
-#pragma unroll
-    for (int i = 0; i < CELLS; i += 4) {
-        uint32_t a = s[i], b = s[i + 1], c = s[i + 2], d = s[i + 3];
-        uint32_t t0 = a + b, t1 = c + d;                     // < 2p < 2^32
-        uint64_t u1 = madk<1>(t1, madk<6>(b, mulk<4>(a)));  // 4a + 6b +  c +  d
-        uint64_t u0 = madk<2>(d, madk<1>(t0, u1));          // 5a + 7b +  c + 3d
-        uint64_t u3 = madk<1>(t0, madk<6>(d, mulk<4>(c)));  //  a +  b + 4c + 6d
-        uint64_t u2 = madk<2>(b, madk<1>(t1, u3));          //  a + 3b + 5c + 7d
-        w[i] = u0; w[i + 1] = u1; w[i + 2] = u2; w[i + 3] = u3;
-    }
-    uint64_t t[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) t[j] = ((w[j] + w[4 + j]) + (w[8 + j] + w[12 + j])) + (w[16 + j] + w[20 + j]);
-#pragma unroll
-    for (int i = 0; i < CELLS; i++) s[i] = bb::uredc64(w[i] + t[i & 3]);
-}
-
-// The same layer on signed-lazy cells |y| < p (S-box outputs), exact in int64 (|w| < 112 p), then
-// r[i] = w[i] * 2^-32 (mod p) as a signed value, |r| <= p/2 + 53.  M4 follows the Poseidon2 paper's
-// add / double schedule: the first two sums and the two doublings take the 32-bit cells through
-// v_mad_i64_i32 (sums like a + b do not fit 32 bits here), the rest are 64-bit shift-adds
-// (v_lshl_add_u64) -- ten instructions per four cells, against two per CELL for a canonicalisation
-// that would let the unsigned form above be used.
-RK_HD void m_ext_redc_s(const int32_t* y, int32_t* r) {
-    int64_t w[CELLS];
-#pragma unroll
-    for (int i = 0; i < CELLS; i += 4) {
-        int32_t a = y[i], b = y[i + 1], c = y[i + 2], d = y[i + 3];
-        int64_t t0 = smadk<1>(b, smulk<1>(a));  //  a +  b
-        int64_t t1 = smadk<1>(d, smulk<1>(c));  //  c +  d
-        int64_t t2 = smadk<2>(b, t1);           // 2b +  c +  d
-        int64_t t3 = smadk<2>(d, t0);           //  a +  b + 2d
-        int64_t t4 = (t1 << 2) + t3;            //  a +  b + 4c + 6d
-        int64_t t5 = (t0 << 2) + t2;            // 4a + 6b +  c +  d
-        w[i] = t3 + t5;                         // 5a + 7b +  c + 3d
-        w[i + 1] = t5;
-        w[i + 2] = t2 + t4;                     //  a + 3b + 5c + 7d
-        w[i + 3] = t4;
-    }
-    int64_t t[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) t[j] = ((w[j] + w[4 + j]) + (w[8 + j] + w[12 + j])) + (w[16 + j] + w[20 + j]);
-#pragma unroll
-    for (int i = 0; i < CELLS; i++) r[i] = bb::redc64(w[i] + t[i & 3]);
-}
-
-// (x + c)^7 * 2^(-6*32) as a signed-lazy value, |result| < p.  x + c must fit an int32: x unsigned in
-// [0, p + 2^22) with c = rc - p, or x a signed REDC output (|x| <= p/2 + 53) with c centred.
-RK_HD int32_t sbox7_lazy(uint32_t x, uint32_t c_mp) {
-    int32_t s = (int32_t)(x + c_mp);
-    int32_t s2 = bb::smul(s, s);
-    int32_t s3 = bb::smul(s2, s);
-    int32_t s6 = bb::smul(s3, s3);
-    return bb::smul(s6, s);
-}
-// One full round on the 32-bit patterns of the cells (unsigned after the first layer / the partial
-// rounds, signed otherwise: the offset form of the round constants follows, see derive()).
-RK_HD void full_round(uint32_t* s, const Consts& k, int r) {
-    int32_t y[CELLS], o[CELLS];
-#pragma unroll
-    for (int i = 0; i < CELLS; i++) y[i] = sbox7_lazy(s[i], k.rc_ext_in[r * CELLS + i]);
-    m_ext_redc_s(y, o);
-#pragma unroll
-    for (int i = 0; i < CELLS; i++) s[i] = (uint32_t)o[i];
-}
-
-// All 21 partial rounds in closed form.  Entry: any 32-bit representatives of the cells, scaled by
-// the first block of full rounds (see permute()); exit: Montgomery form, cells in [0, p + 2^22).
-// With v = cells 1..23 at entry, y_k the S-box output of
-// round k and S_k = y_k + sum(cells 1..23 before round k):
-//     cells_i before round k   = d_i^k v_i + sum_{j<k} d_i^(k-1-j) S_j
-//     sum of them              = sum_i d_i^k v_i + sum_{j<k} c_(k-1-j) S_j,     c_m = sum_i d_i^m
-//     cell 0 after round k     = (d_0 + 1) y_k + that sum
-//     cells_i after round 20   = d_i^21 v_i + sum_j d_i^(20-j) S_j
-// so no cell is touched between entry and exit: each round is one dot product with constant
-// vectors, and every product is accumulated exactly in 64 bits -- variables are split into
-// 16-bit halves, constants come as {c, c 2^16}, so a term is < 2^47 and one v_mad_u64_u32 --
-// with one REDC per sum.  ~3.0 k instructions instead of ~4.1 k for 21 rounds of
-// multiply / reduce / add on every cell.
-// Reader of Consts::pr_stream.  On the device the constants live in scalar registers: chunks of
-// 16 are fetched with s_load_dwordx16 one chunk ahead of their use (the compiler's own scheduling
-// of ~2400 scalar loads spills SGPRs), and the wait is attached to the chunk's registers so that
-// no use can move above it.  Positions are consumed strictly in order.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef uint32_t sgpr16 __attribute__((ext_vector_type(16)));
 struct KStream {
@@ -292,7 +120,213 @@ RK_HD void pr_fma(KStream& ks, uint64_t& acc, uint32_t x) {
     acc = mad_sc(acc, x, c);
 }
 
-RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
+// One Poseidon2 instance family: width W (rate W - 8), RP partial rounds, 4x4 block M4K of the
+// external layer (0: the Poseidon2 paper's / risc0's, 1: circ(2,3,1,1), Plonky3's MDSMat4).
+// risc0's suite is Core<24, 21, 0>; SP1 / Plonky3's BabyBear permutation is Core<16, 13, 1>.
+template <int W, int RP, int M4K>
+struct Core {
+static constexpr int CELLS = W;
+static constexpr int RATE = W - 8;
+static constexpr int ROUNDS_PARTIAL = RP;
+static constexpr int M4_KIND = M4K;
+
+// per round r: 23 pairs d_i^r, r pairs c_(r-1-j), then d_0 + 1; at the end 23 x (d_i^21, d_i^(20-j))
+static constexpr int PR_STREAM_USED = ROUNDS_PARTIAL * (2 * (CELLS - 1) + 1) + ROUNDS_PARTIAL * (ROUNDS_PARTIAL - 1) +
+                               (CELLS - 1) * 2 * (ROUNDS_PARTIAL + 1);
+static constexpr int PR_STREAM_WORDS = (PR_STREAM_USED + 15) / 16 * 16 + 16;
+
+struct Consts {
+    // the instance (Montgomery form), set by the caller
+    uint32_t rc_ext[2 * ROUNDS_HALF_FULL * CELLS];
+    uint32_t rc_int[ROUNDS_PARTIAL];
+    uint32_t diag[CELLS];
+    // derived by derive()
+    uint32_t rc_ext_in[2 * ROUNDS_HALF_FULL * CELLS];  // rc * scale(round) as the S-box input offset: rc - p after an
+                                                       // unsigned state (rounds 0, 4), centred in (-p/2, p/2] otherwise
+    uint32_t rc_int_mp[ROUNDS_PARTIAL];                // rc - p
+    uint32_t fix[2];                                   // block-end rescale constants 2^(32 (2 - e_end)), plain residues
+    uint32_t fix0_nq;                                  // fix[0] * (-p^-1) mod 2^32 (bb::umul_const companion)
+    uint32_t fix1_q;                                   // fix[1] * p^-1 mod 2^32 (bb::smul_const companion)
+    // partial rounds in closed form (see partial_rounds()): the constants in the order the
+    // code consumes them, each as a pair {c, c * 2^16 mod p} for the low / high 16-bit halves
+    // of the variable it multiplies (+ one chunk of padding for the read-ahead)
+    uint32_t pr_stream[PR_STREAM_WORDS];
+};
+
+// exponent e of the scale 2^(32 e) carried by the state at the S-box input of each full round
+// (first block follows the initial external layer + REDC; second block starts from Montgomery form)
+static constexpr int scale_exp(int r) {
+    constexpr int t[2 * ROUNDS_HALF_FULL] = {0, -7, -56, -399, 1, 0, -7, -56};
+    return t[r];
+}
+
+static inline void derive(Consts& k) {
+    const uint32_t Rm = bb::encode(bb::ONE);  // Montgomery form of the field element 2^32
+    const uint32_t Rinv_m = bb::inv(Rm);
+    auto rpow = [&](long e) {  // Montgomery form of 2^(32 e)
+        return e >= 0 ? bb::pow(Rm, (uint64_t)e) : bb::pow(Rinv_m, (uint64_t)(-e));
+    };
+    for (int r = 0; r < 2 * ROUNDS_HALF_FULL; r++) {
+        // stored residue v = rc * 2^32 (Montgomery form).  The S-box input of round r holds the
+        // residue a * 2^(32 e) for the true state a, so the residue to add is rc * 2^(32 e):
+        // bb::mul(v, f) = v * f / 2^32 with the residue f = 2^(32 e) = rpow(e - 1).
+        uint32_t f = rpow((long)scale_exp(r) - 1);
+        const bool after_unsigned = r % ROUNDS_HALF_FULL == 0;  // input in [0, p + 2^22): offset rc - p
+        for (int i = 0; i < CELLS; i++) {
+            uint32_t c = bb::mul(k.rc_ext[r * CELLS + i], f);
+            // otherwise the input is a signed REDC output, |x| <= p/2 + 53: centred offset, |x + rc| < 2^31
+            k.rc_ext_in[r * CELLS + i] = (after_unsigned || c > bb::P / 2) ? c - bb::P : c;
+        }
+    }
+    for (int i = 0; i < ROUNDS_PARTIAL; i++) k.rc_int_mp[i] = k.rc_int[i] - bb::P;
+    // a block ends with the state scaled by 2^(32 e_end), e_end = 7 e - 7 for the last round's e;
+    // x -> x * K / 2^32 with K = 2^(32 (2 - e_end)) (plain residue) gives Montgomery form
+    for (int b = 0; b < 2; b++) {
+        long e = scale_exp(b * ROUNDS_HALF_FULL + ROUNDS_HALF_FULL - 1);
+        k.fix[b] = bb::decode(rpow(2 - (7 * e - 7)));
+    }
+    k.fix0_nq = k.fix[0] * (0u - bb::MPRIME);
+    k.fix1_q = k.fix[1] * bb::MPRIME;
+    // closed-form partial rounds: powers of the diagonal (Montgomery residues: they multiply a
+    // Montgomery-form variable and the sum goes through one REDC).  The constants that multiply
+    // the ENTRY cells also carry fix[0]: those cells arrive scaled by the first block.
+    const uint32_t two16 = bb::encode(65536u);
+    uint32_t pw[CELLS - 1][ROUNDS_PARTIAL + 1];
+    for (int i = 1; i < CELLS; i++) {
+        pw[i - 1][0] = bb::ONE;
+        for (int m = 1; m <= ROUNDS_PARTIAL; m++) pw[i - 1][m] = bb::mul(pw[i - 1][m - 1], k.diag[i]);
+    }
+    uint32_t csum[ROUNDS_PARTIAL];
+    for (int m = 0; m < ROUNDS_PARTIAL; m++) {
+        csum[m] = 0;
+        for (int i = 0; i < CELLS - 1; i++) csum[m] = bb::add(csum[m], pw[i][m]);
+    }
+    int n = 0;
+    auto put = [&](uint32_t c) { k.pr_stream[n++] = c; k.pr_stream[n++] = bb::mul(c, two16); };
+    for (int r = 0; r < ROUNDS_PARTIAL; r++) {
+        for (int i = 0; i < CELLS - 1; i++) put(bb::mul(pw[i][r], k.fix[0]));
+        for (int j = 0; j < r; j++) put(csum[r - 1 - j]);
+        k.pr_stream[n++] = bb::add(k.diag[0], bb::ONE);
+    }
+    for (int i = 0; i < CELLS - 1; i++) {
+        put(bb::mul(pw[i][ROUNDS_PARTIAL], k.fix[0]));
+        for (int j = 0; j < ROUNDS_PARTIAL; j++) put(pw[i][ROUNDS_PARTIAL - 1 - j]);
+    }
+    while (n < PR_STREAM_WORDS) k.pr_stream[n++] = 0;
+}
+
+// External layer circ(2*M4, M4, ..., M4), M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]], on
+// canonical cells, exact: w[i] < 112 p < 2^38.  Then s[i] = w[i] * 2^-32 (mod p) in [0, p + 53).
+static RK_HD void m_ext_redc(uint32_t* s) {
+    uint64_t w[CELLS];
+#pragma unroll
+    for (int i = 0; i < CELLS; i += 4) {
+        uint32_t a = s[i], b = s[i + 1], c = s[i + 2], d = s[i + 3];
+        uint32_t t0 = a + b, t1 = c + d;                     // < 2p < 2^32
+        if constexpr (M4K == 0) {
+            uint64_t u1 = madk<1>(t1, madk<6>(b, mulk<4>(a)));  // 4a + 6b +  c +  d
+            uint64_t u0 = madk<2>(d, madk<1>(t0, u1));          // 5a + 7b +  c + 3d
+            uint64_t u3 = madk<1>(t0, madk<6>(d, mulk<4>(c)));  //  a +  b + 4c + 6d
+            uint64_t u2 = madk<2>(b, madk<1>(t1, u3));          //  a + 3b + 5c + 7d
+            w[i] = u0; w[i + 1] = u1; w[i + 2] = u2; w[i + 3] = u3;
+        } else {  // circ(2, 3, 1, 1): every output is the block sum plus one cell plus twice the next
+            uint64_t sum = madk<1>(t1, mulk<1>(t0));
+            w[i] = madk<2>(b, madk<1>(a, sum));      // 2a + 3b +  c +  d
+            w[i + 1] = madk<2>(c, madk<1>(b, sum));  //  a + 2b + 3c +  d
+            w[i + 2] = madk<2>(d, madk<1>(c, sum));  //  a +  b + 2c + 3d
+            w[i + 3] = madk<2>(a, madk<1>(d, sum));  // 3a +  b +  c + 2d
+        }
+    }
+    uint64_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        t[j] = w[j];
+#pragma unroll
+        for (int b = 4; b < CELLS; b += 4) t[j] += w[b + j];
+    }
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) s[i] = bb::uredc64(w[i] + t[i & 3]);
+}
+
+// The same layer on signed-lazy cells |y| < p (S-box outputs), exact in int64 (|w| < 112 p), then
+// r[i] = w[i] * 2^-32 (mod p) as a signed value, |r| <= p/2 + 53.  M4 follows the Poseidon2 paper's
+// add / double schedule: the first two sums and the two doublings take the 32-bit cells through
+// v_mad_i64_i32 (sums like a + b do not fit 32 bits here), the rest are 64-bit shift-adds
+// (v_lshl_add_u64) -- ten instructions per four cells, against two per CELL for a canonicalisation
+// that would let the unsigned form above be used.
+static RK_HD void m_ext_redc_s(const int32_t* y, int32_t* r) {
+    int64_t w[CELLS];
+#pragma unroll
+    for (int i = 0; i < CELLS; i += 4) {
+        int32_t a = y[i], b = y[i + 1], c = y[i + 2], d = y[i + 3];
+        int64_t t0 = smadk<1>(b, smulk<1>(a));  //  a +  b
+        int64_t t1 = smadk<1>(d, smulk<1>(c));  //  c +  d
+        if constexpr (M4K == 0) {
+            int64_t t2 = smadk<2>(b, t1);           // 2b +  c +  d
+            int64_t t3 = smadk<2>(d, t0);           //  a +  b + 2d
+            int64_t t4 = (t1 << 2) + t3;            //  a +  b + 4c + 6d
+            int64_t t5 = (t0 << 2) + t2;            // 4a + 6b +  c +  d
+            w[i] = t3 + t5;                         // 5a + 7b +  c + 3d
+            w[i + 1] = t5;
+            w[i + 2] = t2 + t4;                     //  a + 3b + 5c + 7d
+            w[i + 3] = t4;
+        } else {  // circ(2, 3, 1, 1)
+            int64_t sum = t0 + t1;
+            w[i] = smadk<2>(b, smadk<1>(a, sum));
+            w[i + 1] = smadk<2>(c, smadk<1>(b, sum));
+            w[i + 2] = smadk<2>(d, smadk<1>(c, sum));
+            w[i + 3] = smadk<2>(a, smadk<1>(d, sum));
+        }
+    }
+    int64_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        t[j] = w[j];
+#pragma unroll
+        for (int b = 4; b < CELLS; b += 4) t[j] += w[b + j];
+    }
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) r[i] = bb::redc64(w[i] + t[i & 3]);
+}
+
+// (x + c)^7 * 2^(-6*32) as a signed-lazy value, |result| < p.  x + c must fit an int32: x unsigned in
+// [0, p + 2^22) with c = rc - p, or x a signed REDC output (|x| <= p/2 + 53) with c centred.
+static RK_HD int32_t sbox7_lazy(uint32_t x, uint32_t c_mp) {
+    int32_t s = (int32_t)(x + c_mp);
+    int32_t s2 = bb::smul(s, s);
+    int32_t s3 = bb::smul(s2, s);
+    int32_t s6 = bb::smul(s3, s3);
+    return bb::smul(s6, s);
+}
+// One full round on the 32-bit patterns of the cells (unsigned after the first layer / the partial
+// rounds, signed otherwise: the offset form of the round constants follows, see derive()).
+static RK_HD void full_round(uint32_t* s, const Consts& k, int r) {
+    int32_t y[CELLS], o[CELLS];
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) y[i] = sbox7_lazy(s[i], k.rc_ext_in[r * CELLS + i]);
+    m_ext_redc_s(y, o);
+#pragma unroll
+    for (int i = 0; i < CELLS; i++) s[i] = (uint32_t)o[i];
+}
+
+// All 21 partial rounds in closed form.  Entry: any 32-bit representatives of the cells, scaled by
+// the first block of full rounds (see permute()); exit: Montgomery form, cells in [0, p + 2^22).
+// With v = cells 1..23 at entry, y_k the S-box output of
+// round k and S_k = y_k + sum(cells 1..23 before round k):
+//     cells_i before round k   = d_i^k v_i + sum_{j<k} d_i^(k-1-j) S_j
+//     sum of them              = sum_i d_i^k v_i + sum_{j<k} c_(k-1-j) S_j,     c_m = sum_i d_i^m
+//     cell 0 after round k     = (d_0 + 1) y_k + that sum
+//     cells_i after round 20   = d_i^21 v_i + sum_j d_i^(20-j) S_j
+// so no cell is touched between entry and exit: each round is one dot product with constant
+// vectors, and every product is accumulated exactly in 64 bits -- variables are split into
+// 16-bit halves, constants come as {c, c 2^16}, so a term is < 2^47 and one v_mad_u64_u32 --
+// with one REDC per sum.  ~3.0 k instructions instead of ~4.1 k for 21 rounds of
+// multiply / reduce / add on every cell.
+// Reader of Consts::pr_stream.  On the device the constants live in scalar registers: chunks of
+// 16 are fetched with s_load_dwordx16 one chunk ahead of their use (the compiler's own scheduling
+// of ~2400 scalar loads spills SGPRs), and the wait is attached to the chunk's registers so that
+// no use can move above it.  Positions are consumed strictly in order.
+static RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
     constexpr int NV = CELLS - 1;
     uint32_t vlo[NV], vhi[NV], slo[ROUNDS_PARTIAL], shi[ROUNDS_PARTIAL];
 #pragma unroll
@@ -348,7 +382,7 @@ RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
     ks.drain();
 }
 
-RK_HD void permute(uint32_t* s, const Consts& k) {
+static RK_HD void permute(uint32_t* s, const Consts& k) {
     m_ext_redc(s);  // canonical Montgomery input -> plain residues (scale 2^0), cells in [0, p + 53)
 #pragma unroll 1
     for (int r = 0; r < ROUNDS_HALF_FULL; r++) full_round(s, k, r);
@@ -363,5 +397,16 @@ RK_HD void permute(uint32_t* s, const Consts& k) {
 #pragma unroll
     for (int i = 0; i < CELLS; i++) s[i] = bb::canon(bb::smul_const((int32_t)s[i], (int32_t)k.fix[1], k.fix1_q));
 }
+
+};  // struct Core
+
+// risc0's instance under the names the rest of the library grew up with
+using C24 = Core<24, 21, 0>;
+constexpr int CELLS = C24::CELLS;
+constexpr int RATE = C24::RATE;
+constexpr int ROUNDS_PARTIAL = C24::ROUNDS_PARTIAL;
+using Consts = C24::Consts;
+inline void derive(Consts& k) { C24::derive(k); }
+RK_HD void permute(uint32_t* s, const Consts& k) { C24::permute(s, k); }
 
 }  // namespace p2

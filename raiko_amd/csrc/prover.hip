@@ -24,59 +24,18 @@ namespace {
 using bb::Ext;
 
 // ---------------------------------------------------------------- transcript
-// WriteIOP + Poseidon2Rng (risc0-zkp prove/write_iop.rs, core/hash/poseidon2/rng.rs)
+// WriteIOP + Poseidon2Rng (risc0-zkp prove/write_iop.rs, core/hash/poseidon2/rng.rs) over the
+// context's Poseidon2 instance (poseidon2_any.hpp)
 struct Transcript {
-    const p2::Consts* k;
+    p2::Rng rng;
     std::vector<uint32_t> proof;
-    uint32_t cells[p2::CELLS];
-    unsigned pool_used = 0;
-    explicit Transcript(const p2::Consts* kc) : k(kc) { std::memset(cells, 0, sizeof cells); }
+    explicit Transcript(const p2::Any* kc) : rng(kc) {}
     void write(const uint32_t* w, size_t n) { proof.insert(proof.end(), w, w + n); }
-    void commit(const uint32_t* digest) {
-        if (pool_used != 0) {
-            p2::permute(cells, *k);
-            pool_used = 0;
-        }
-        for (int i = 0; i < p2::OUT; i++) cells[i] = bb::add(cells[i], digest[i]);
-        p2::permute(cells, *k);
-    }
-    uint32_t random_elem() {
-        if (pool_used == p2::RATE) {
-            p2::permute(cells, *k);
-            pool_used = 0;
-        }
-        return cells[pool_used++];
-    }
-    Ext random_ext() {
-        Ext r;
-        for (int i = 0; i < 4; i++) r.c[i] = random_elem();
-        return r;
-    }
-    uint32_t random_bits(unsigned bits) {
-        uint32_t v = bb::decode(random_elem());
-        for (int i = 0; i < 3; i++) v ^= bb::decode(random_elem());
-        return v & (uint32_t)(((uint64_t)1 << bits) - 1);
-    }
+    void commit(const uint32_t* digest) { rng.mix(digest); }
+    uint32_t random_elem() { return rng.random_elem(); }
+    Ext random_ext() { return rng.random_ext(); }
+    uint32_t random_bits(unsigned bits) { return rng.random_bits(bits); }
 };
-
-// host sponge over a contiguous element slice (Poseidon2HashFn::hash_elem_slice)
-void hash_elems(const p2::Consts& k, const uint32_t* in, size_t n, uint32_t* digest) {
-    uint32_t s[p2::CELLS];
-    std::memset(s, 0, sizeof s);
-    size_t unmixed = 0;
-    for (size_t i = 0; i < n; i++) {
-        s[unmixed++] = in[i];
-        if (unmixed == p2::RATE) {
-            p2::permute(s, k);
-            unmixed = 0;
-        }
-    }
-    if (unmixed != 0 || n == 0) {
-        for (size_t i = unmixed; i < p2::RATE; i++) s[i] = 0;
-        p2::permute(s, k);
-    }
-    std::memcpy(digest, s, p2::OUT * 4);
-}
 
 // ---------------------------------------------------------------- device helpers
 struct DevBuf {
@@ -240,7 +199,7 @@ struct Stopwatch {
 };
 
 // core/poly.rs poly_interpolate for the handful of taps of one register
-void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n) {
+void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n, uint32_t wm) {
     std::vector<Ext> num(n + 1);
     for (size_t i = 0; i < n; i++) out[i] = bb::ext_zero();
     for (size_t i = 0; i < n; i++) {
@@ -250,13 +209,13 @@ void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n) {
         for (size_t j = 0; j < n; j++) {
             if (j == i) continue;
             num[deg + 1] = num[deg];
-            for (size_t k = deg; k > 0; k--) num[k] = bb::sub(num[k - 1], bb::mul(num[k], x[j]));
-            num[0] = bb::sub(bb::ext_zero(), bb::mul(num[0], x[j]));
+            for (size_t k = deg; k > 0; k--) num[k] = bb::sub(num[k - 1], bb::mul(num[k], x[j], wm));
+            num[0] = bb::sub(bb::ext_zero(), bb::mul(num[0], x[j], wm));
             deg++;
-            denom = bb::mul(denom, bb::sub(x[i], x[j]));
+            denom = bb::mul(denom, bb::sub(x[i], x[j]), wm);
         }
-        Ext sc = bb::mul(fx[i], bb::inv(denom));
-        for (size_t k = 0; k < n; k++) out[k] = bb::add(out[k], bb::mul(num[k], sc));
+        Ext sc = bb::mul(fx[i], bb::inv(denom, wm), wm);
+        for (size_t k = 0; k < n; k++) out[k] = bb::add(out[k], bb::mul(num[k], sc, wm));
     }
 }
 
@@ -273,9 +232,15 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     if ((!seg->check && !hook_check) || (seg->n_globals && !seg->globals)) return RK_ERR_INVALID;
     if (seg->n_accum_mix > (1u << 16)) return RK_ERR_INVALID;
 
+    // the flow is risc0's: blow-up 4, fold 16, final degree 256; field, hash and query count follow rk_params
+    if (!ctx->sys.segment_flow_ok()) {
+        ctx->last_error = "rk_prove_segment needs blowup_log2 = 2, fri_fold_log2 = 4, fri_min_degree = 256";
+        return RK_ERR_INVALID;
+    }
     const size_t N = (size_t)1 << seg->po2, D = N * 4;
-    const size_t QUERIES = 50, FRI_FOLD = 16, FRI_MIN_DEGREE = 256, CHECK_SIZE = 16;
-    const p2::Consts& kc = ctx->h_p2;
+    const size_t QUERIES = ctx->sys.queries, FRI_FOLD = 16, FRI_MIN_DEGREE = 256, CHECK_SIZE = 16;
+    const uint32_t wm = ctx->sys.wm;
+    const p2::Any& kc = ctx->h_p2;
     Transcript iop(&kc);
     uint32_t digest[8];
     ctx->timing = rk_timing{};
@@ -285,14 +250,14 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     {
         uint32_t e[16];
         for (int i = 0; i < 16; i++) e[i] = bb::encode(seg->proof_system_info[i]);
-        hash_elems(kc, e, 16, digest);
+        kc.hash_elems(e, 16, digest);
         iop.commit(digest);
         for (int i = 0; i < 16; i++) e[i] = bb::encode(seg->circuit_info[i]);
-        hash_elems(kc, e, 16, digest);
+        kc.hash_elems(e, 16, digest);
         iop.commit(digest);
         std::vector<uint32_t> vec(seg->globals, seg->globals + seg->n_globals);
         vec.push_back(bb::encode(seg->po2));
-        hash_elems(kc, vec.data(), vec.size(), digest);
+        kc.hash_elems(vec.data(), vec.size(), digest);
         iop.commit(digest);
         iop.write(seg->globals, seg->n_globals);
         iop.write(&seg->po2, 1);
@@ -410,9 +375,9 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
 
     sw.start();
     Ext z = iop.random_ext();
-    uint32_t w27 = bb::encode(137);
+    uint32_t w27 = ctx->sys.root27m;
     uint32_t back_one = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - seg->po2)));
-    Ext z_pow = bb::pow(z, 4);
+    Ext z_pow = bb::pow(z, 4, wm);
 
     // tap openings: every register at z * back_one^back for each of its backs
     size_t tot_taps = 0;
@@ -470,7 +435,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         for (uint32_t r = 0; r < taps.n_regs; r++) {
             uint32_t cb = taps.reg_combo[r];
             size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
-            poly_interpolate(&coeff_u[p], &all_xs[p], &eval_u[p], sz);
+            poly_interpolate(&coeff_u[p], &all_xs[p], &eval_u[p], sz, wm);
             p += sz;
         }
         which.clear();
@@ -483,7 +448,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         for (uint32_t i = 0; i < CHECK_SIZE; i++) coeff_u[tot_taps + i] = eval_u[tot_taps + i];
     }
     iop.write((const uint32_t*)coeff_u.data(), coeff_u.size() * 4);
-    hash_elems(kc, (const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
+    kc.hash_elems((const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
     iop.commit(digest);
 
     // DEEP: mix all columns into one polynomial per combo, remove the openings, divide
@@ -501,7 +466,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
             which.assign(gs, 0);
             for (uint32_t i = 0; i < gs; i++, reg++) which[i] = taps.reg_combo[reg];
             RK_TRY(rk::mix_poly_coeffs(ctx, combos.u32(), cur_mix, mix, groups[gid].coeffs.u32(), which.data(), gs, N));
-            cur_mix = bb::mul(cur_mix, bb::pow(mix, gs));
+            cur_mix = bb::mul(cur_mix, bb::pow(mix, gs, wm), wm);
         }
         which.assign(CHECK_SIZE, (uint32_t)combo_count);
         RK_TRY(rk::mix_poly_coeffs(ctx, combos.u32(), cur_mix, mix, check.coeffs.u32(), which.data(), CHECK_SIZE, N));
@@ -520,13 +485,13 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
             size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
             if (sz > stride || sz > N) return RK_ERR_INVALID;
             for (size_t i = 0; i < sz; i++)
-                delta[cb * stride + i] = bb::add(delta[cb * stride + i], bb::mul(cur, coeff_u[cur_pos + i]));
-            cur = bb::mul(cur, mix);
+                delta[cb * stride + i] = bb::add(delta[cb * stride + i], bb::mul(cur, coeff_u[cur_pos + i], wm));
+            cur = bb::mul(cur, mix, wm);
             cur_pos += sz;
         }
         for (uint32_t i = 0; i < CHECK_SIZE; i++) {
-            delta[combo_count * stride] = bb::add(delta[combo_count * stride], bb::mul(cur, coeff_u[cur_pos++]));
-            cur = bb::mul(cur, mix);
+            delta[combo_count * stride] = bb::add(delta[combo_count * stride], bb::mul(cur, coeff_u[cur_pos++], wm));
+            cur = bb::mul(cur, mix, wm);
         }
         std::vector<Ext> dl;
         for (size_t c = 0; c <= combo_count; c++) {
@@ -604,7 +569,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         std::vector<uint32_t> h(cur_words);
         RK_TRY(d2h_sync(ctx, h.data(), fin.p, cur_words * 4));
         iop.write(h.data(), h.size());
-        hash_elems(kc, h.data(), h.size(), digest);
+        kc.hash_elems(h.data(), h.size(), digest);
         iop.commit(digest);
     }
     sw.stop(&ctx->timing.fri);
@@ -640,6 +605,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
 extern "C" {
 
 size_t rk_seal_bound_words(const rk_segment* seg) { return rk::seal_bound_words(seg); }
+size_t rk_seal_bound_words_for(const rk_segment* seg, uint32_t queries) { return rk::seal_bound_words(seg, queries); }
 
 int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t cap, size_t* seal_words) {
     RK_GUARD_BEGIN

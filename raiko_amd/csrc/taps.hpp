@@ -35,9 +35,9 @@ inline int check_taps(const rk_taps& t) {
 }
 
 
-// upper bound on the seal words of a shape; 0 for a shape rk_prove_segment would reject
-inline size_t seal_bound_words(const rk_segment* seg) {
-    if (!seg || seg->po2 < 1 || seg->po2 + 2 > MAX_PO2_PLUS_2) return 0;
+// upper bound on the seal words of a shape for `queries` query openings; 0 for a shape rk_prove_segment would reject
+inline size_t seal_bound_words(const rk_segment* seg, size_t queries = 50) {
+    if (!seg || seg->po2 < 1 || seg->po2 + 2 > MAX_PO2_PLUS_2 || queries == 0 || queries > RK_MAX_QUERIES) return 0;
     const rk_taps& t = seg->taps;
     if (check_taps(t) != RK_OK) return 0;
     auto lg = [](size_t n) {
@@ -51,13 +51,15 @@ inline size_t seal_bound_words(const rk_segment* seg) {
     size_t tot_taps = 0;
     for (uint32_t r = 0; r < t.n_regs; r++) tot_taps += t.combo_off[t.reg_combo[r] + 1] - t.combo_off[t.reg_combo[r]];
     size_t w_all = (size_t)t.group_size[0] + t.group_size[1] + t.group_size[2] + 16;
-    words += 4 * 32 * 8;                      // top layers of the four trace trees
+    size_t top = 1;                           // Merkle cap: the largest power of two <= queries
+    while (top * 2 <= queries) top *= 2;
+    words += 4 * top * 8;                     // top layers of the four trace trees
     words += (tot_taps + 16) * 4;             // coeff_u
-    words += 50 * (w_all + 4 * layers * 8);   // trace openings
+    words += queries * (w_all + 4 * layers * 8);   // trace openings
     size_t size = N;
     while (size > 256) {
         size_t domain = size * 4;
-        words += 32 * 8 + 50 * (64 + lg(domain / 16) * 8);
+        words += top * 8 + queries * (64 + lg(domain / 16) * 8);
         size /= 16;
     }
     words += size * 4;

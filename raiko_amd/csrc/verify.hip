@@ -8,83 +8,29 @@
 // (rk_verify_opts) -- the constraint identity on the tap openings.  The rv32im constraint system
 // itself (risc0-circuit-rv32im) is not in this repo; examples/toy_circuit shows a complete one.
 #include "internal.hpp"
-#include "poseidon2_consts.inc"
 
 #include <cstring>
+#include <memory>
 
 namespace {
 
 using bb::Ext;
 
-const p2::Consts& default_consts() {
-    static p2::Consts k = [] {
-        p2::Consts c{};
-        std::memcpy(c.rc_ext, P2_RC_EXT_MONT, sizeof c.rc_ext);
-        std::memcpy(c.rc_int, P2_RC_INT_MONT, sizeof c.rc_int);
-        std::memcpy(c.diag, P2_INT_DIAG_MONT, sizeof c.diag);
-        p2::derive(c);
-        return c;
-    }();
-    return k;
-}
-
-struct Sponge {  // Poseidon2Rng
-    const p2::Consts& k;
-    uint32_t cells[p2::CELLS];
-    unsigned used = 0;
-    explicit Sponge(const p2::Consts& kc) : k(kc) { std::memset(cells, 0, sizeof cells); }
-    void mix(const uint32_t* d) {
-        if (used) {
-            p2::permute(cells, k);
-            used = 0;
-        }
-        for (int i = 0; i < p2::OUT; i++) cells[i] = bb::add(cells[i], d[i]);
-        p2::permute(cells, k);
-    }
-    uint32_t elem() {
-        if (used == p2::RATE) {
-            p2::permute(cells, k);
-            used = 0;
-        }
-        return cells[used++];
-    }
-    Ext ext() {
-        Ext r;
-        for (int i = 0; i < 4; i++) r.c[i] = elem();
-        return r;
-    }
-    uint32_t bits(unsigned n) {
-        uint32_t v = bb::decode(elem());
-        for (int i = 0; i < 3; i++) v ^= bb::decode(elem());
-        return v & (uint32_t)(((uint64_t)1 << n) - 1);
+// the compiled-in risc0 parameter set (what rk_verify_segment assumes)
+struct Defaults {
+    rk::Sys sys;
+    p2::Any p2any;
+    Defaults() {
+        rk_params def;
+        rk::params_preset(&def, RK_PRESET_RISC0);
+        (void)rk::resolve_params(&def, &sys, &p2any);
     }
 };
-
-void hash_slice(const p2::Consts& k, const uint32_t* in, size_t n, uint32_t* out) {
-    uint32_t s[p2::CELLS];
-    std::memset(s, 0, sizeof s);
-    size_t fill = 0;
-    for (size_t i = 0; i < n; i++) {
-        s[fill++] = in[i];
-        if (fill == p2::RATE) {
-            p2::permute(s, k);
-            fill = 0;
-        }
-    }
-    if (fill || n == 0) {
-        for (size_t i = fill; i < p2::RATE; i++) s[i] = 0;
-        p2::permute(s, k);
-    }
-    std::memcpy(out, s, 32);
+const Defaults& defaults() {
+    static Defaults d;
+    return d;
 }
-void hash_pair(const p2::Consts& k, const uint32_t* a, const uint32_t* b, uint32_t* out) {
-    uint32_t s[p2::CELLS];
-    std::memcpy(s, a, 32);
-    std::memcpy(s + 8, b, 32);
-    std::memset(s + 16, 0, 32);
-    p2::permute(s, k);
-    std::memcpy(out, s, 32);
-}
+using Sponge = p2::Rng;
 
 struct Reader {
     const uint32_t* p;
@@ -104,7 +50,7 @@ struct Reader {
 struct TreeVerifier {  // MerkleTreeVerifier
     size_t rows = 0, cols = 0, top_size = 1;
     std::vector<uint32_t> top;  // heap, index 1 = root
-    void init(const p2::Consts& k, Reader& r, Sponge& rng, size_t rows_, size_t cols_, size_t queries) {
+    void init(const p2::Any& k, Reader& r, Sponge& rng, size_t rows_, size_t cols_, size_t queries) {
         rows = rows_;
         cols = cols_;
         size_t layers = log2u(rows), top_layer = 0;
@@ -115,30 +61,30 @@ struct TreeVerifier {  // MerkleTreeVerifier
         top_size = (size_t)1 << top_layer;
         top.assign(2 * top_size * 8, 0);
         r.read(top.data() + top_size * 8, top_size * 8);
-        for (size_t i = top_size; i-- > 1;) hash_pair(k, &top[2 * i * 8], &top[(2 * i + 1) * 8], &top[i * 8]);
+        for (size_t i = top_size; i-- > 1;) k.hash_pair(&top[2 * i * 8], &top[(2 * i + 1) * 8], &top[i * 8]);
         rng.mix(&top[8]);
     }
-    bool open(const p2::Consts& k, Reader& r, size_t idx, uint32_t* row) const {
+    bool open(const p2::Any& k, Reader& r, size_t idx, uint32_t* row) const {
         if (idx >= rows) return false;
         r.read(row, cols);
         uint32_t cur[8], other[8], nxt[8];
-        hash_slice(k, row, cols, cur);
+        k.hash_elems(row, cols, cur);
         idx += rows;
         while (idx >= 2 * top_size) {
             bool right = idx & 1;
             r.read(other, 8);
             idx >>= 1;
-            if (right) hash_pair(k, other, cur, nxt);
-            else hash_pair(k, cur, other, nxt);
+            if (right) k.hash_pair(other, cur, nxt);
+            else k.hash_pair(cur, other, nxt);
             std::memcpy(cur, nxt, 32);
         }
         return std::memcmp(cur, &top[idx * 8], 32) == 0;
     }
 };
 
-Ext poly_eval(const Ext* c, size_t n, const Ext& x) {
+Ext poly_eval(const Ext* c, size_t n, const Ext& x, uint32_t wm) {
     Ext acc = bb::ext_zero();
-    for (size_t i = n; i-- > 0;) acc = bb::add(bb::mul(acc, x), c[i]);
+    for (size_t i = n; i-- > 0;) acc = bb::add(bb::mul(acc, x, wm), c[i]);
     return acc;
 }
 
@@ -154,32 +100,35 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     if (pub->po2 < 1 || pub->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
     if (pub->n_globals && !pub->globals) return RK_ERR_INVALID;
     if (pub->n_accum_mix > (1u << 16)) return RK_ERR_INVALID;
-    p2::Consts custom;
-    const p2::Consts* kp = &default_consts();
-    if (opts && (opts->p2_rc_ext || opts->p2_rc_int || opts->p2_diag)) {
+    // parameter set: opts->params (the whole blob), else the three width-24 tables of ABI 1, else the defaults
+    rk::Sys sys = defaults().sys;
+    auto custom = std::make_unique<p2::Any>();
+    const p2::Any* kp = &defaults().p2any;
+    if (opts && opts->params) {
+        if (rk::resolve_params(opts->params, &sys, custom.get()) != RK_OK) return RK_ERR_INVALID;
+        kp = custom.get();
+    } else if (opts && (opts->p2_rc_ext || opts->p2_rc_int || opts->p2_diag)) {
         if (!opts->p2_rc_ext || !opts->p2_rc_int || !opts->p2_diag) return RK_ERR_INVALID;
-        for (size_t i = 0; i < sizeof custom.rc_ext / 4; i++)
-            if (opts->p2_rc_ext[i] >= bb::P) return RK_ERR_INVALID;
-        for (int i = 0; i < p2::ROUNDS_PARTIAL; i++)
-            if (opts->p2_rc_int[i] >= bb::P) return RK_ERR_INVALID;
-        for (int i = 0; i < p2::CELLS; i++)
-            if (opts->p2_diag[i] >= bb::P) return RK_ERR_INVALID;
-        std::memcpy(custom.rc_ext, opts->p2_rc_ext, sizeof custom.rc_ext);
-        std::memcpy(custom.rc_int, opts->p2_rc_int, sizeof custom.rc_int);
-        std::memcpy(custom.diag, opts->p2_diag, sizeof custom.diag);
-        p2::derive(custom);
-        kp = &custom;
+        rk_params pp;
+        rk::params_preset(&pp, RK_PRESET_RISC0);
+        pp.p2_rc_ext = opts->p2_rc_ext;
+        pp.p2_rc_int = opts->p2_rc_int;
+        pp.p2_diag = opts->p2_diag;
+        if (rk::resolve_params(&pp, &sys, custom.get()) != RK_OK) return RK_ERR_INVALID;
+        kp = custom.get();
     }
-    const p2::Consts& k = *kp;
-    const size_t QUERIES = 50, FOLD = 16, MIN_DEGREE = 256, CHECK = 16;
+    if (!sys.segment_flow_ok()) return RK_ERR_INVALID;
+    const p2::Any& k = *kp;
+    const uint32_t wm = sys.wm;
+    const size_t QUERIES = sys.queries, FOLD = 16, MIN_DEGREE = 256, CHECK = 16;
     Reader r{seal, seal_words};
-    Sponge rng(k);
+    Sponge rng(&k);
     uint32_t digest[8], e16[16];
     for (int i = 0; i < 16; i++) e16[i] = bb::encode(pub->proof_system_info[i]);
-    hash_slice(k, e16, 16, digest);
+    k.hash_elems(e16, 16, digest);
     rng.mix(digest);
     for (int i = 0; i < 16; i++) e16[i] = bb::encode(pub->circuit_info[i]);
-    hash_slice(k, e16, 16, digest);
+    k.hash_elems(e16, 16, digest);
     rng.mix(digest);
 
     std::vector<uint32_t> io(pub->n_globals + 1);
@@ -189,7 +138,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     if (r.short_read || po2 != pub->po2) return 10;
     if (pub->n_globals && std::memcmp(io.data(), pub->globals, pub->n_globals * 4) != 0) return 10;
     io[pub->n_globals] = bb::encode(po2);
-    hash_slice(k, io.data(), io.size(), digest);
+    k.hash_elems(io.data(), io.size(), digest);
     rng.mix(digest);
 
     const size_t N = (size_t)1 << po2, D = 4 * N;
@@ -197,12 +146,12 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     tg[1].init(k, r, rng, D, taps.group_size[1], QUERIES);
     tg[2].init(k, r, rng, D, taps.group_size[2], QUERIES);
     std::vector<uint32_t> accum_mix(pub->n_accum_mix);
-    for (uint32_t i = 0; i < pub->n_accum_mix; i++) accum_mix[i] = rng.elem();
+    for (uint32_t i = 0; i < pub->n_accum_mix; i++) accum_mix[i] = rng.random_elem();
     tg[0].init(k, r, rng, D, taps.group_size[0], QUERIES);
-    const Ext poly_mix = rng.ext();
+    const Ext poly_mix = rng.random_ext();
     tcheck.init(k, r, rng, D, CHECK, QUERIES);
-    const Ext z = rng.ext();
-    const uint32_t w27 = bb::encode(137);
+    const Ext z = rng.random_ext();
+    const uint32_t w27 = sys.root27m;
     const uint32_t back_one = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - po2)));
 
     size_t tot_taps = 0;
@@ -211,7 +160,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
         tot_taps += taps.combo_off[taps.reg_combo[i] + 1] - taps.combo_off[taps.reg_combo[i]];
     std::vector<Ext> coeff_u(tot_taps + CHECK);
     r.read((uint32_t*)coeff_u.data(), coeff_u.size() * 4);
-    hash_slice(k, (const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
+    k.hash_elems((const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
     rng.mix(digest);
     if (r.short_read) return 60;
     if (opts && opts->poly_ext) {
@@ -225,7 +174,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
             size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
             for (size_t j = 0; j < sz; j++) {
                 Ext x = bb::scale(z, bb::pow(back_one, taps.combo_backs[taps.combo_off[cb] + j]));
-                eval_u[pos + j] = poly_eval(&coeff_u[pos], sz, x);
+                eval_u[pos + j] = poly_eval(&coeff_u[pos], sz, x, wm);
             }
             pos += sz;
         }
@@ -239,14 +188,14 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
             for (int e = 0; e < 4; e++) {
                 Ext basis = bb::ext_zero();
                 basis.c[e] = bb::ONE;
-                check = bb::add(check, bb::mul(bb::mul(coeff_u[tot_taps + remap[i] + 4 * e], zi), basis));
+                check = bb::add(check, bb::mul(bb::mul(coeff_u[tot_taps + remap[i] + 4 * e], zi, wm), basis, wm));
             }
-            zi = bb::mul(zi, z);
+            zi = bb::mul(zi, z, wm);
         }
-        Ext vanish = bb::sub(bb::pow(bb::scale(z, bb::encode(3)), N), bb::ext_one());
-        if (!bb::eq(bb::mul(check, vanish), result)) return 70;
+        Ext vanish = bb::sub(bb::pow(bb::scale(z, sys.shiftm), N, wm), bb::ext_one());
+        if (!bb::eq(bb::mul(check, vanish, wm), result)) return 70;
     }
-    const Ext mix = rng.ext();
+    const Ext mix = rng.random_ext();
     std::vector<Ext> combo_u(tot_backs + 1, bb::ext_zero());
     {
         Ext cur = bb::ext_one();
@@ -255,16 +204,16 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
             uint32_t cb = taps.reg_combo[i];
             size_t sz = taps.combo_off[cb + 1] - taps.combo_off[cb];
             for (size_t j = 0; j < sz; j++)
-                combo_u[taps.combo_off[cb] + j] = bb::add(combo_u[taps.combo_off[cb] + j], bb::mul(cur, coeff_u[pos + j]));
-            cur = bb::mul(cur, mix);
+                combo_u[taps.combo_off[cb] + j] = bb::add(combo_u[taps.combo_off[cb] + j], bb::mul(cur, coeff_u[pos + j], wm));
+            cur = bb::mul(cur, mix, wm);
             pos += sz;
         }
         for (size_t i = 0; i < CHECK; i++) {
-            combo_u[tot_backs] = bb::add(combo_u[tot_backs], bb::mul(cur, coeff_u[pos++]));
-            cur = bb::mul(cur, mix);
+            combo_u[tot_backs] = bb::add(combo_u[tot_backs], bb::mul(cur, coeff_u[pos++], wm));
+            cur = bb::mul(cur, mix, wm);
         }
     }
-    const Ext z_pow = bb::pow(z, 4);
+    const Ext z_pow = bb::pow(z, 4, wm);
 
     // FRI commitments
     struct Round {
@@ -279,13 +228,13 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
         Round& rd = rounds.back();
         rd.domain = domain;
         rd.tree.init(k, r, rng, domain / FOLD, FOLD * 4, QUERIES);
-        rd.mix = rng.ext();
+        rd.mix = rng.random_ext();
         domain /= FOLD;
         degree /= FOLD;
     }
     std::vector<uint32_t> final_coeffs(4 * degree);
     r.read(final_coeffs.data(), final_coeffs.size());
-    hash_slice(k, final_coeffs.data(), final_coeffs.size(), digest);
+    k.hash_elems(final_coeffs.data(), final_coeffs.size(), digest);
     rng.mix(digest);
     if (r.short_read) return 60;
 
@@ -299,7 +248,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     std::vector<Ext> tot(taps.n_combos + 1);
 
     for (size_t q = 0; q < QUERIES; q++) {
-        size_t pos = rng.bits(log2u(D)) % D;
+        size_t pos = rng.random_bits(log2u(D)) % D;
         const Ext x = bb::ext_from(bb::pow(gen0, pos));
         for (int g = 0; g < 3; g++)
             if (!tg[g].open(k, r, pos, row[g].data())) return r.short_read ? 60 : 20 + g;
@@ -309,22 +258,22 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
         for (uint32_t i = 0; i < taps.n_regs; i++) {
             uint32_t v = row[taps.reg_group[i]][taps.reg_offset[i]];
             tot[taps.reg_combo[i]] = bb::add(tot[taps.reg_combo[i]], bb::scale(cur, v));
-            cur = bb::mul(cur, mix);
+            cur = bb::mul(cur, mix, wm);
         }
         for (size_t i = 0; i < CHECK; i++) {
             tot[taps.n_combos] = bb::add(tot[taps.n_combos], bb::scale(cur, check_row[i]));
-            cur = bb::mul(cur, mix);
+            cur = bb::mul(cur, mix, wm);
         }
         Ext goal = bb::ext_zero();
         for (uint32_t c = 0; c < taps.n_combos; c++) {
             size_t b0 = taps.combo_off[c], b1 = taps.combo_off[c + 1];
-            Ext num = bb::sub(tot[c], poly_eval(&combo_u[b0], b1 - b0, x));
+            Ext num = bb::sub(tot[c], poly_eval(&combo_u[b0], b1 - b0, x, wm));
             Ext den = bb::ext_one();
             for (size_t b = b0; b < b1; b++)
-                den = bb::mul(den, bb::sub(x, bb::scale(z, bb::pow(back_one, taps.combo_backs[b]))));
-            goal = bb::add(goal, bb::mul(num, bb::inv(den)));
+                den = bb::mul(den, bb::sub(x, bb::scale(z, bb::pow(back_one, taps.combo_backs[b]))), wm);
+            goal = bb::add(goal, bb::mul(num, bb::inv(den, wm), wm));
         }
-        goal = bb::add(goal, bb::mul(bb::sub(tot[taps.n_combos], combo_u[tot_backs]), bb::inv(bb::sub(x, z_pow))));
+        goal = bb::add(goal, bb::mul(bb::sub(tot[taps.n_combos], combo_u[tot_backs]), bb::inv(bb::sub(x, z_pow), wm), wm));
 
         for (size_t kr = 0; kr < rounds.size(); kr++) {
             const Round& rd = rounds[kr];
@@ -344,14 +293,14 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
                 co[i] = bb::scale(acc, inv16);
             }
             uint32_t inv_wk = bb::pow(bb::inv(bb::pow(w27, (uint64_t)1 << (27 - log2u(rd.domain)))), group);
-            goal = poly_eval(co, 16, bb::scale(rd.mix, inv_wk));
+            goal = poly_eval(co, 16, bb::scale(rd.mix, inv_wk), wm);
             pos = group;
         }
         const Ext xf = bb::ext_from(bb::pow(gen_final, pos));
         Ext fx = bb::ext_zero();
         for (size_t i = degree; i-- > 0;) {
             Ext c{{final_coeffs[i], final_coeffs[degree + i], final_coeffs[2 * degree + i], final_coeffs[3 * degree + i]}};
-            fx = bb::add(bb::mul(fx, xf), c);
+            fx = bb::add(bb::mul(fx, xf, wm), c);
         }
         if (!bb::eq(fx, goal)) return 50;
     }

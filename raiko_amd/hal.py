@@ -110,6 +110,21 @@ class HipHal:
             raise ValueError("expected 192 + 21 + 24 constants")
         self._ck(self._lib.rk_set_poseidon2_params(self._ctx, _u32p(a[0]), _u32p(a[1]), _u32p(a[2])))
 
+    def set_params(self, preset: int = 0, **over):
+        """rk_set_params: a preset (_lib.RK_PRESET_RISC0 / RK_PRESET_SP1) with overrides -- ext_w,
+        root_2_27, coset_shift (canonical integers), p2_width / p2_m4 / p2_pad_free, p2_rc_ext /
+        p2_rc_int / p2_diag (uint32 arrays, Montgomery form), queries, blowup_log2, fri_fold_log2,
+        fri_min_degree.  Returns the blob applied (keep it for verify_segment(params=...))."""
+        p = make_params(preset, **over)
+        self._ck(self._lib.rk_set_params(self._ctx, C.byref(p)))
+        self._params = p
+        return p
+
+    def get_params(self) -> "_lib.RkParams":
+        p = _lib.RkParams()
+        self._ck(self._lib.rk_get_params(self._ctx, C.byref(p)))
+        return p
+
     # ---- Hal operators ----
     def batch_interpolate_ntt(self, io, count: int, size: Optional[int] = None):
         size = size if size is not None else io.size() // count
@@ -190,7 +205,7 @@ class HipHal:
         c_seg, keep = make_c_segment(seg, device_inputs)
         if consume_inputs and device_inputs is not None:
             c_seg.on_device = 2
-        cap = int(self._lib.rk_seal_bound_words(C.byref(c_seg)))
+        cap = int(self._lib.rk_seal_bound_words_for(C.byref(c_seg), self.get_params().queries))
         if cap == 0:  # malformed shape / tap set: nothing is allocated for it
             raise _lib.RkError(_lib.RK_ERR_INVALID, "invalid argument (segment shape or tap set)")
         seal = np.empty(cap, dtype=np.uint32)
@@ -271,6 +286,26 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
     return [seals[i][: words[i]].copy() for i in range(n)]
 
 
+_params_keep = []
+
+
+def make_params(preset: int = 0, **over) -> "_lib.RkParams":
+    """an rk_params blob: preset + overrides (see HipHal.set_params); arrays are kept alive by the module"""
+    lib = _lib.load()
+    p = _lib.RkParams()
+    _lib.check(None, lib.rk_params_preset(C.byref(p), preset))
+    for k, v in over.items():
+        if k in ("p2_rc_ext", "p2_rc_int", "p2_diag"):
+            a = np.ascontiguousarray(v, dtype=np.uint32).reshape(-1)
+            _params_keep.append(a)
+            setattr(p, k, _u32p(a))
+        else:
+            if not hasattr(p, k):
+                raise ValueError("unknown parameter %r" % k)
+            setattr(p, k, int(v))
+    return p
+
+
 def session_set_kernel_timing(device: int, enabled: bool):
     """hipEvent brackets around every launch class of rk_prove_session's contexts of `device`"""
     lib = _lib.load()
@@ -288,7 +323,7 @@ def session_kernel_stats(device: int) -> dict:
     return out
 
 
-def make_verify_opts(poly_ext=None, poseidon2=None):
+def make_verify_opts(poly_ext=None, poseidon2=None, params=None):
     """rk_verify_opts: `poly_ext` = a _lib.POLY_EXT_FN (the circuit's constraint polynomial: the
     verifier then checks the constraint identity); `poseidon2` = (rc_ext[192], rc_int[21], diag[24])
     the seal was produced under (default: the compiled-in instance).  Returns (opts, keepalive)."""
@@ -303,10 +338,13 @@ def make_verify_opts(poly_ext=None, poseidon2=None):
     if poly_ext is not None:
         o.poly_ext = poly_ext
         keep.append(poly_ext)
+    if params is not None:  # the whole blob the seal was produced under (overrides `poseidon2`)
+        o.params = C.pointer(params)
+        keep.append(params)
     return o, keep
 
 
-def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None) -> int:
+def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None, params=None) -> int:
     """Host-side check of a seal against the public data of `seg` (no GPU needed): 0 = valid,
     positive = reason code of the first failed check (raiko_amd/csrc/verify.hip)."""
     lib = _lib.load()
@@ -322,9 +360,9 @@ def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None
         c.proof_system_info[i] = seg.proof_system_info[i]
         c.circuit_info[i] = seg.circuit_info[i]
     s = np.ascontiguousarray(seal, dtype=np.uint32)
-    if poly_ext is None and poseidon2 is None:
+    if poly_ext is None and poseidon2 is None and params is None:
         return int(lib.rk_verify_segment(C.byref(c), _u32p(s), s.size))
-    opts, k2 = make_verify_opts(poly_ext, poseidon2)
+    opts, k2 = make_verify_opts(poly_ext, poseidon2, params)
     rc = int(lib.rk_verify_segment_ex(C.byref(c), C.byref(opts), _u32p(s), s.size))
     del k2
     return rc

@@ -9,7 +9,7 @@
 #include "bb.hpp"
 #include "ntt_core.hpp"
 #include "ntt_fused.hpp"
-#include "poseidon2_core.hpp"
+#include "poseidon2_any.hpp"
 #include "poseidon2_consts.inc"
 
 namespace {
@@ -212,6 +212,27 @@ int emul_ntt_forward(uint32_t* out, const uint32_t* in, size_t in_size, size_t c
         run_pass<true>(a, count, nthr);
     }
     return (int)plan.npass;
+}
+// any shipped instance: width 24 / 16, external 4x4 block 0 / 1, caller's tables (Montgomery form)
+void emul_poseidon2_permute_cfg(uint32_t* cells, int width, int m4, const uint32_t* rc_ext, const uint32_t* rc_int,
+                                const uint32_t* diag) {
+    static p2::Any k;
+    k.set(width, m4, false, rc_ext, rc_int, diag);
+    k.permute(cells);
+}
+// the extension product / inverse for a caller-chosen W (Montgomery form)
+void emul_ext_mul_w(const uint32_t* a, const uint32_t* b, uint32_t wm, uint32_t* out) {
+    bb::Ext x, y;
+    std::memcpy(x.c, a, 16);
+    std::memcpy(y.c, b, 16);
+    bb::Ext r = bb::mul(x, y, wm);
+    std::memcpy(out, r.c, 16);
+}
+void emul_ext_inv_w(const uint32_t* a, uint32_t wm, uint32_t* out) {
+    bb::Ext x;
+    std::memcpy(x.c, a, 16);
+    bb::Ext r = bb::inv(x, wm);
+    std::memcpy(out, r.c, 16);
 }
 void emul_poseidon2_permute(uint32_t* cells) {
     p2::Consts k = consts();

@@ -28,7 +28,7 @@ def build_oracle(force=False):
 def build_emul(force=False):
     csrc = os.path.join(ROOT, "raiko_amd", "csrc")
     srcs = [os.path.join(EMUL_DIR, "emul.cpp")] + [os.path.join(csrc, f) for f in
-                                                   ("bb.hpp", "ntt_core.hpp", "ntt_fused.hpp", "poseidon2_core.hpp", "poseidon2_consts.inc")]
+                                                   ("bb.hpp", "ntt_core.hpp", "ntt_fused.hpp", "poseidon2_core.hpp", "poseidon2_any.hpp", "poseidon2_consts.inc")]
     if not force and os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs):
         return EMUL_SO
     os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
@@ -46,6 +46,14 @@ class OrSegment(C.Structure):
     _fields_ = [("po2", C.c_uint32), ("taps", OrTaps), ("group", C.c_void_p * 3), ("check", C.c_void_p),
                 ("globals", u32p), ("n_globals", C.c_uint32), ("n_accum_mix", C.c_uint32),
                 ("proof_system_info", C.c_uint8 * 16), ("circuit_info", C.c_uint8 * 16), ("hooks", C.c_void_p)]
+
+
+class OrParams(C.Structure):
+    _fields_ = [("ext_w", C.c_uint32), ("root_2_27", C.c_uint32), ("coset_shift", C.c_uint32),
+                ("p2_width", C.c_uint32), ("p2_m4", C.c_uint32), ("p2_pad_free", C.c_uint32),
+                ("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p),
+                ("queries", C.c_uint32), ("blowup_log2", C.c_uint32), ("fri_fold_log2", C.c_uint32),
+                ("fri_min_degree", C.c_uint32)]
 
 
 class OrTiming(C.Structure):
@@ -87,6 +95,7 @@ def oracle():
             "or_verify_segment_circuit": (C.c_int, [C.POINTER(OrSegment), u32p, sz, vp, vp]),
             "or_toy_hooks": (vp, []),
             "or_set_fast": (None, [C.c_int]), "or_get_fast": (C.c_int, []),
+            "or_params_preset": (None, [C.POINTER(OrParams), C.c_int]), "or_set_params": (C.c_int, [C.POINTER(OrParams)]),
             "or_prefix_products": (None, [vp, sz]),
             "or_scatter": (None, [vp, vp, sz, vp, vp]),
             "or_free": (None, [vp]), "or_max_threads": (C.c_int, []),
@@ -113,6 +122,12 @@ def emul():
         lib.emul_poseidon2_permute.argtypes = [vp]
         lib.emul_poseidon2_permute_with.restype = None
         lib.emul_poseidon2_permute_with.argtypes = [vp, vp, vp, vp]
+        lib.emul_poseidon2_permute_cfg.restype = None
+        lib.emul_poseidon2_permute_cfg.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+        lib.emul_ext_mul_w.restype = None
+        lib.emul_ext_mul_w.argtypes = [vp, vp, u32, vp]
+        lib.emul_ext_inv_w.restype = None
+        lib.emul_ext_inv_w.argtypes = [vp, u32, vp]
         for n in ("emul_mul", "emul_add", "emul_sub"):
             getattr(lib, n).restype = u32
             getattr(lib, n).argtypes = [u32, u32]
@@ -222,3 +237,25 @@ def oracle_timing() -> dict:
     t = OrTiming()
     oracle().or_last_timing(C.byref(t))
     return {n: getattr(t, n) for n, _ in t._fields_}
+
+
+# ---- parameter sets (mirror of rk_params): keep the oracle and the product on the same blob ----
+_param_keep = []
+
+
+def oracle_set_params(preset=0, **over):
+    """or_params_preset + overrides (numpy uint32 arrays for the Poseidon2 tables) + or_set_params.
+    Returns the OrParams applied; oracle_set_params() restores risc0's defaults."""
+    lib = oracle()
+    p = OrParams()
+    lib.or_params_preset(C.byref(p), preset)
+    for k, v in over.items():
+        if k in ("p2_rc_ext", "p2_rc_int", "p2_diag"):
+            a = np.ascontiguousarray(v, dtype=np.uint32)
+            _param_keep.append(a)
+            setattr(p, k, a.ctypes.data_as(u32p))
+        else:
+            setattr(p, k, int(v))
+    if lib.or_set_params(C.byref(p)) != 0:
+        raise ValueError("or_set_params rejected the parameter set")
+    return p

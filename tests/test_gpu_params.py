@@ -1,0 +1,188 @@
+"""GPU parity under other parameter sets (rk_set_params): every operator and the whole segment
+flow against the oracle configured with the same blob -- SP1 / Plonky3's field (x^4 - 11, root
+0x1a427a41, shift 31), Poseidon2 width 16 with circ(2,3,1,1) and the padding-free sponge, fold
+arity 2, 100 queries (BASELINE config 5's parameters on the same kernels; values RECALLED, see
+tests/test_params.py)."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from raiko_amd import _lib
+from raiko_amd.hal import HipHal, verify_segment
+from raiko_amd.segment import synthetic_segment
+
+pytestmark = pytest.mark.gpu
+
+SP1_FIELD = dict(ext_w=11, root_2_27=0x1A427A41, coset_shift=31)
+SP1_HASH = dict(p2_width=16, p2_m4=1, p2_pad_free=1)
+
+
+@pytest.fixture()
+def cfg():
+    """a context of its own and the oracle under one blob; both back to risc0's defaults afterwards"""
+    h = HipHal(0)
+
+    def apply(preset=0, **kw):
+        o.oracle_set_params(preset, **kw)
+        return h.set_params(preset, **kw)
+
+    yield h, apply
+    h.close()
+    o.oracle_set_params()
+
+
+@pytest.mark.parametrize("k", [3, 10, 14, 16, 18, 20])
+def test_ntt_with_other_root_and_shift(cfg, orc, k):
+    h, apply = cfg
+    apply(**SP1_FIELD)
+    rng = np.random.default_rng(k)
+    n, cnt = 1 << k, 3
+    x = o.rand_elems(rng, (cnt, n))
+    want = x.copy()
+    orc.or_batch_interpolate_ntt(o.ptr(want), n, cnt)
+    buf = h.copy_from_elem(x)
+    h.batch_interpolate_ntt(buf, cnt)
+    assert np.array_equal(buf.to_host().reshape(cnt, n), want)
+    orc.or_zk_shift(o.ptr(want), n, cnt)
+    h.zk_shift(buf, cnt)
+    assert np.array_equal(buf.to_host().reshape(cnt, n), want)
+    want_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(o.ptr(want_e), o.ptr(want), n, cnt, 2)
+    out = h.alloc_elem(cnt * 4 * n)
+    h.batch_expand_into_evaluate_ntt(out, buf, cnt, 2)
+    assert np.array_equal(out.to_host().reshape(cnt, 4 * n), want_e)
+    # blow-up 2 (SP1 core's): the operator takes expand_bits as an argument
+    want_2 = np.zeros((cnt, 2 * n), dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(o.ptr(want_2), o.ptr(want), n, cnt, 1)
+    out2 = h.alloc_elem(cnt * 2 * n)
+    h.batch_expand_into_evaluate_ntt(out2, buf, cnt, 1)
+    assert np.array_equal(out2.to_host().reshape(cnt, 2 * n), want_2)
+    # the risc0 tables come back with the risc0 parameters (tables are keyed by the field parameters)
+    apply()
+    back = x.copy()
+    orc.or_batch_interpolate_ntt(o.ptr(back), n, cnt)
+    buf2 = h.copy_from_elem(x)
+    h.batch_interpolate_ntt(buf2, cnt)
+    assert np.array_equal(buf2.to_host().reshape(cnt, n), back)
+
+
+@pytest.mark.parametrize("kw", [SP1_HASH, dict(p2_width=16, p2_m4=0), dict(p2_width=24, p2_m4=1), dict(p2_width=24, p2_pad_free=1)])
+@pytest.mark.parametrize("cols", [0, 1, 7, 8, 9, 16, 17, 40])
+def test_hash_rows_fold_merkle_instances(cfg, orc, kw, cols):
+    h, apply = cfg
+    apply(**kw)
+    rng = np.random.default_rng(cols)
+    rows = 256
+    m = o.rand_elems(rng, (max(cols, 1), rows))
+    want = np.zeros((2 * rows, 8), dtype=np.uint32)
+    orc.or_hash_rows(o.ptr(want[rows:]), o.ptr(m), rows, cols)
+    size = rows
+    while size > 1:
+        orc.or_hash_fold(o.ptr(want), size, size // 2)
+        size //= 2
+    dm = h.copy_from_elem(m)
+    nodes = h.alloc_elem(2 * rows * 8)
+    h.merkle_build(nodes, dm, rows, cols)
+    got = nodes.to_host().reshape(2 * rows, 8)
+    assert np.array_equal(got[1:], want[1:])
+    leaves = h.alloc_elem(rows * 8)
+    h.hash_rows(leaves, dm, rows, cols)
+    assert np.array_equal(leaves.to_host().reshape(rows, 8), want[rows:])
+
+
+def test_custom_width16_tables(cfg, orc):
+    h, apply = cfg
+    rng = np.random.default_rng(16)
+    tabs = dict(p2_rc_ext=o.rand_elems(rng, (128,)), p2_rc_int=o.rand_elems(rng, (13,)), p2_diag=o.rand_elems(rng, (16,)))
+    apply(**SP1_HASH, **tabs)
+    rows, cols = 4096, 21
+    m = o.rand_elems(rng, (cols, rows))
+    want = np.zeros((rows, 8), dtype=np.uint32)
+    orc.or_hash_rows(o.ptr(want), o.ptr(m), rows, cols)
+    out = h.alloc_elem(rows * 8)
+    h.hash_rows(out, h.copy_from_elem(m), rows, cols)
+    assert np.array_equal(out.to_host().reshape(rows, 8), want)
+    got = h.get_params()
+    assert (got.p2_width, got.p2_m4, got.p2_pad_free) == (16, 1, 1) and got.p2_rc_int[12] == int(tabs["p2_rc_int"][12])
+
+
+@pytest.mark.parametrize("log_a", [1, 2, 3, 4])
+def test_fri_fold_arity_and_ext_ops(cfg, orc, log_a):
+    h, apply = cfg
+    apply(fri_fold_log2=log_a, **SP1_FIELD)
+    rng = np.random.default_rng(log_a)
+    a, count = 1 << log_a, 5000
+    planes = o.rand_elems(rng, (4, a * count))
+    mix = o.rand_elems(rng, (4,))
+    want = np.zeros((4, count), dtype=np.uint32)
+    orc.or_fri_fold(o.ptr(want), o.ptr(planes), count, o.ptr(mix))
+    out = h.alloc_elem(4 * count)
+    h.fri_fold(out, h.copy_from_elem(planes), count, mix)
+    assert np.array_equal(out.to_host().reshape(4, count), want)
+    # the other extension-field operators under x^4 - 11
+    size, polys = 1 << 11, 5
+    coeffs = o.rand_elems(rng, (polys, size))
+    which = np.array([0, 4, 2, 2, 1], dtype=np.uint32)
+    xs = o.rand_elems(rng, (which.size, 4))
+    want_e = np.zeros((which.size, 4), dtype=np.uint32)
+    orc.or_batch_evaluate_any(o.ptr(coeffs), size, o.ptr(which), o.ptr(xs), which.size, o.ptr(want_e))
+    assert np.array_equal(h.batch_evaluate_any(h.copy_from_elem(coeffs), polys, size, which, xs), want_e)
+    combos = np.array([0, 1, 1, 0, 2], dtype=np.uint32)
+    ms, mx = o.rand_elems(rng, (4,)), o.rand_elems(rng, (4,))
+    start = o.rand_elems(rng, (3, size, 4))
+    want_m = start.copy()
+    orc.or_mix_poly_coeffs(o.ptr(want_m), o.ptr(ms), o.ptr(mx), o.ptr(coeffs), o.ptr(combos), polys, size)
+    dm = h.copy_from_elem(start)
+    h.mix_poly_coeffs(dm, ms, mx, h.copy_from_elem(coeffs), combos, polys, size)
+    assert np.array_equal(dm.to_host().reshape(3, size, 4), want_m)
+    poly = o.rand_elems(rng, (size, 4))
+    z = o.rand_elems(rng, (4,))
+    want_p, want_rem = poly.copy(), np.zeros(4, dtype=np.uint32)
+    orc.or_poly_divide(o.ptr(want_p), size, o.ptr(z), o.ptr(want_rem))
+    dp = h.copy_from_elem(poly)
+    rem = h.poly_divide(dp, size, z)
+    assert np.array_equal(rem, want_rem) and np.array_equal(dp.to_host().reshape(size, 4), want_p)
+    pp = o.rand_elems(rng, (5000, 4))
+    want_pp = pp.copy()
+    orc.or_prefix_products(o.ptr(want_pp), 5000)
+    dpp = h.copy_from_elem(pp)
+    _lib.check(h._ctx, h._lib.rk_prefix_products(h._ctx, dpp.ptr, 5000))
+    assert np.array_equal(dpp.to_host().reshape(5000, 4), want_pp)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(queries=100),
+    dict(queries=7),
+    SP1_FIELD,
+    SP1_HASH,
+    dict(queries=100, **SP1_FIELD, **SP1_HASH),
+])
+def test_segment_seal_under_other_parameters(cfg, kw):
+    """the whole segment flow (risc0's: blow-up 4, fold 16) with SP1's field, hash and query count:
+    seal word for word the oracle's; both verifiers accept it under the same blob only"""
+    h, apply = cfg
+    blob = apply(**kw)
+    for po2, widths in ((9, (4, 4, 12)), (14, (16, 16, 40))):
+        seg = synthetic_segment(po2, widths, seed=31 + po2)
+        want = o.oracle_prove(seg)
+        got = h.prove_segment(seg)
+        assert got.size == want.size and np.array_equal(got, want)
+        assert o.oracle_verify(seg, got) == 0
+        assert verify_segment(seg, got, params=blob) == 0
+        assert verify_segment(seg, got) != 0           # not a proof under the default parameters
+        bad = got.copy()
+        bad[got.size // 3] ^= 1
+        assert verify_segment(seg, bad, params=blob) != 0
+
+
+def test_protocol_shapes_the_segment_flow_refuses(cfg):
+    h, apply = cfg
+    h.set_params(_lib.RK_PRESET_SP1)                   # blow-up 2, fold 2: served by the operators only
+    with pytest.raises(_lib.RkError) as ei:
+        h.prove_segment(synthetic_segment(6, (2, 2, 3), seed=1))
+    assert ei.value.status == -1
+    for bad in (dict(ext_w=4), dict(root_2_27=3), dict(p2_width=20), dict(queries=0), dict(fri_fold_log2=0)):
+        with pytest.raises(_lib.RkError):
+            h.set_params(0, **bad)
+    # a refused blob leaves the context as it was
+    assert h.get_params().p2_width == 16 and h.get_params().ext_w == 11

@@ -132,6 +132,9 @@ def emit(header_src):
         for vn, v in vals:
             lines.append("pub const %s: %s = %d;" % (vn, name, v))
         lines.append("")
+    for m in re.finditer(r"^#define (RK_[A-Z0-9_]+) (\d+)\s*$", strip_comments(header_src), flags=re.M):
+        lines.append("pub const %s: u32 = %s;" % (m.group(1), m.group(2)))
+    lines.append("")
     lines.append("#[repr(C)]\npub struct rk_ctx {\n    _private: [u8; 0],\n}\n")
     for name, (ret, params) in fn_types.items():
         ps = ", ".join("%s: %s" % p for p in params_to_rust(params, known, fn_types))
