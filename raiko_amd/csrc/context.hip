@@ -148,6 +148,7 @@ const char* rk_strerror(int s) {
 const char* rk_last_error(rk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 int rk_device_count(int* count) {
+    RK_GUARD_BEGIN
     if (!count) return RK_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -156,6 +157,7 @@ int rk_device_count(int* count) {
     }
     *count = n;
     return RK_OK;
+    RK_GUARD_END
 }
 
 int rk_ctx_create(int device, void* stream, rk_ctx** out) {
@@ -194,6 +196,7 @@ int rk_ctx_create(int device, void* stream, rk_ctx** out) {
 }
 
 int rk_ctx_destroy(rk_ctx* ctx) {
+    RK_GUARD_BEGIN
     if (!ctx) return RK_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -209,13 +212,16 @@ int rk_ctx_destroy(rk_ctx* ctx) {
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RK_OK;
+    RK_GUARD_END
 }
 
 int rk_sync(rk_ctx* ctx) {
+    RK_GUARD_BEGIN
     if (!ctx) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RK_OK;
+    RK_GUARD_END
 }
 int rk_alloc(rk_ctx* ctx, size_t bytes, void** d_ptr) {
     RK_GUARD_BEGIN
@@ -225,25 +231,31 @@ int rk_alloc(rk_ctx* ctx, size_t bytes, void** d_ptr) {
     RK_GUARD_END
 }
 int rk_free(rk_ctx* ctx, void* d_ptr) {
+    RK_GUARD_BEGIN
     if (!ctx) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the block may still be in use by queued work on the stream
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return rk::dev_free(ctx, d_ptr);
+    RK_GUARD_END
 }
 int rk_h2d(rk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    RK_GUARD_BEGIN
     if (!ctx || (!d_dst && bytes) || (!h_src && bytes)) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RK_OK;
+    RK_GUARD_END
 }
 int rk_d2h(rk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    RK_GUARD_BEGIN
     if (!ctx || (!h_dst && bytes) || (!d_src && bytes)) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RK_OK;
+    RK_GUARD_END
 }
 
 // width-24 tables of the paper's instance (the ABI-1 entry point): the rest of the parameter set stays
@@ -261,9 +273,11 @@ int rk_set_poseidon2_params(rk_ctx* ctx, const uint32_t* rc_ext, const uint32_t*
 }
 
 int rk_params_preset(rk_params* out, int preset) {
+    RK_GUARD_BEGIN
     if (!out || (preset != RK_PRESET_RISC0 && preset != RK_PRESET_SP1)) return RK_ERR_INVALID;
     rk::params_preset(out, preset);
     return RK_OK;
+    RK_GUARD_END
 }
 int rk_set_params(rk_ctx* ctx, const rk_params* params) {
     RK_GUARD_BEGIN
@@ -281,6 +295,7 @@ int rk_set_params(rk_ctx* ctx, const rk_params* params) {
     RK_GUARD_END
 }
 int rk_get_params(rk_ctx* ctx, rk_params* out) {
+    RK_GUARD_BEGIN
     if (!ctx || !out) return RK_ERR_INVALID;
     *out = rk_params{};
     out->struct_size = (uint32_t)sizeof(rk_params);
@@ -298,9 +313,11 @@ int rk_get_params(rk_ctx* ctx, rk_params* out) {
     out->fri_fold_log2 = ctx->sys.fri_fold_log2;
     out->fri_min_degree = ctx->sys.fri_min_degree;
     return RK_OK;
+    RK_GUARD_END
 }
 
 int rk_set_kernel_timing(rk_ctx* ctx, int enabled) {
+    RK_GUARD_BEGIN
     if (!ctx) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -312,8 +329,10 @@ int rk_set_kernel_timing(rk_ctx* ctx, int enabled) {
     }
     ctx->ktime_on = enabled != 0;
     return RK_OK;
+    RK_GUARD_END
 }
 int rk_kernel_stats(rk_ctx* ctx, int kclass, rk_kernel_stat* out) {
+    RK_GUARD_BEGIN
     if (!ctx || !out || kclass < 0 || kclass >= RK_KCLASS_COUNT) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -322,6 +341,7 @@ int rk_kernel_stats(rk_ctx* ctx, int kclass, rk_kernel_stat* out) {
     out->ms = ctx->k_ms[kclass];
     out->bytes = ctx->k_bytes[kclass];
     return RK_OK;
+    RK_GUARD_END
 }
 const char* rk_kernel_class_name(int kclass) {
     switch (kclass) {
@@ -335,9 +355,11 @@ const char* rk_kernel_class_name(int kclass) {
 }
 
 int rk_last_timing(rk_ctx* ctx, rk_timing* out) {
+    RK_GUARD_BEGIN
     if (!ctx || !out) return RK_ERR_INVALID;
     *out = ctx->timing;
     return RK_OK;
+    RK_GUARD_END
 }
 
 }  // extern "C"

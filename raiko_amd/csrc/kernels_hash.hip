@@ -156,19 +156,25 @@ int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
 extern "C" {
 
 int rk_hash_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_matrix, size_t rows, size_t cols) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_out || (!d_matrix && cols)) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::hash_rows(ctx, d_out, d_matrix, rows, cols);
+    RK_GUARD_END
 }
 int rk_hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t input_size, size_t output_size) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_nodes || input_size != 2 * output_size) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::hash_fold(ctx, d_nodes, output_size);
+    RK_GUARD_END
 }
 int rk_merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_nodes || !d_matrix) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::merkle_build(ctx, d_nodes, d_matrix, rows, cols);
+    RK_GUARD_END
 }
 
 }  // extern "C"

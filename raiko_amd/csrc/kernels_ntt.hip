@@ -366,11 +366,14 @@ int bit_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count) {
 extern "C" {
 
 int rk_batch_interpolate_ntt(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_io) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::ntt_reverse(ctx, d_io, size, count, false);
+    RK_GUARD_END
 }
 int rk_batch_evaluate_ntt(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, uint32_t expand_bits) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_io || !is_pow2(size) || (size >> expand_bits) == 0) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (expand_bits != 0) {
@@ -379,22 +382,29 @@ int rk_batch_evaluate_ntt(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count
         return RK_ERR_INVALID;
     }
     return rk::ntt_forward(ctx, d_io, d_io, size, count, 0);
+    RK_GUARD_END
 }
 int rk_zk_shift(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_io) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::zk_shift(ctx, d_io, size, count);
+    RK_GUARD_END
 }
 int rk_batch_expand_into_evaluate_ntt(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_size,
                                       size_t count, uint32_t expand_bits) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_out || !d_in || d_out == d_in) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::ntt_forward(ctx, d_out, d_in, in_size, count, expand_bits);
+    RK_GUARD_END
 }
 int rk_batch_bit_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_io) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::bit_reverse(ctx, d_io, size, count);
+    RK_GUARD_END
 }
 
 }  // extern "C"

@@ -529,41 +529,54 @@ int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ex
 extern "C" {
 
 int rk_eltwise_add_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n) {
+    RK_GUARD_BEGIN
     if (!ctx || (n && (!d_out || !d_a || !d_b))) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::eltwise_add(ctx, d_out, d_a, d_b, n);
+    RK_GUARD_END
 }
 int rk_eltwise_sum_extelem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in_ext, size_t count, size_t to_add) {
+    RK_GUARD_BEGIN
     if (!ctx || (count && (!d_out || !d_in_ext))) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::eltwise_sum_ext(ctx, d_out, d_in_ext, count, to_add);
+    RK_GUARD_END
 }
 int rk_eltwise_copy_elem(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n) {
+    RK_GUARD_BEGIN
     if (!ctx || (n && (!d_out || !d_in))) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n)
         RK_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     return RK_OK;
+    RK_GUARD_END
 }
 int rk_eltwise_zeroize_elem(rk_ctx* ctx, uint32_t* d_io, size_t n) {
+    RK_GUARD_BEGIN
     if (!ctx || (n && !d_io)) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::eltwise_zeroize(ctx, d_io, n);
+    RK_GUARD_END
 }
 int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const uint32_t mix[4]) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_out || !d_in || !mix) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     bb::Ext m{{mix[0], mix[1], mix[2], mix[3]}};
     return rk::fri_fold(ctx, d_out, d_in, out_count, m);
+    RK_GUARD_END
 }
 int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {
+    RK_GUARD_BEGIN
     if (!ctx || (size && (!d_dst || !d_src))) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::gather_sample(ctx, d_dst, d_src, idx, size, stride);
+    RK_GUARD_END
 }
 
 int rk_batch_evaluate_any(rk_ctx* ctx, const uint32_t* d_coeffs, size_t poly_count, size_t size,
                           const uint32_t* h_which, const uint32_t* h_xs, size_t eval_count, uint32_t* h_out) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_coeffs || !is_pow2(size)) return RK_ERR_INVALID;
     if (eval_count == 0) return RK_OK;
     if (!h_which || !h_xs || !h_out) return RK_ERR_INVALID;
@@ -610,18 +623,22 @@ int rk_batch_evaluate_any(rk_ctx* ctx, const uint32_t* d_coeffs, size_t poly_cou
     rk::dev_free(ctx, d_small);
     rk::dev_free(ctx, d_pw);
     return st;
+    RK_GUARD_END
 }
 
 int rk_mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t mix_start[4], const uint32_t mix[4],
                        const uint32_t* d_in, const uint32_t* h_combos, size_t input_size, size_t count) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_out_ext || !d_in || !h_combos || !mix_start || !mix) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     bb::Ext ms{{mix_start[0], mix_start[1], mix_start[2], mix_start[3]}};
     bb::Ext mx{{mix[0], mix[1], mix[2], mix[3]}};
     return rk::mix_poly_coeffs(ctx, d_out_ext, ms, mx, d_in, h_combos, input_size, count);
+    RK_GUARD_END
 }
 
 int rk_poly_divide(rk_ctx* ctx, uint32_t* d_polys_ext, size_t count, const uint32_t z[4], uint32_t* h_rem) {
+    RK_GUARD_BEGIN
     if (!ctx || !d_polys_ext || !z || count == 0) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     bb::Ext zz{{z[0], z[1], z[2], z[3]}};
@@ -629,6 +646,7 @@ int rk_poly_divide(rk_ctx* ctx, uint32_t* d_polys_ext, size_t count, const uint3
     RK_TRY(rk::poly_divide(ctx, d_polys_ext, count, zz, &rem));
     if (h_rem) std::memcpy(h_rem, rem.c, 16);
     return RK_OK;
+    RK_GUARD_END
 }
 
 }  // extern "C"

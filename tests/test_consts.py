@@ -11,9 +11,11 @@ import gen_poseidon2_consts as gen  # noqa: E402
 P = gen.P
 
 
-def test_grain_stream_matches_published_leading_constants():
-    # leading entries of risc0's published ROUND_CONSTANTS (SURVEY.md App. A recall), reproduced by
-    # the Grain LFSR with (field=1, sbox=0, n=31, t=24, R_F=8, R_P=21)
+def test_grain_stream_matches_recalled_leading_constants():
+    # leading entries of risc0's published ROUND_CONSTANTS as the BUILDER recalls them (own recall:
+    # SURVEY.md App. A states the values are not available in the container), reproduced by the
+    # Grain LFSR with (field=1, sbox=0, n=31, t=24, R_F=8, R_P=21).  A regression pin of the
+    # generator, not evidence of risc0 parity ("Recalled, unverifiable here").
     ext, internal = gen.round_constants()
     assert ext[:8] == [0x0FA20C37, 0x0795BB97, 0x12C60B9C, 0x0EABD88E, 0x096485CA, 0x07093527, 0x1B1D4E50, 0x30A01ACE]
     assert len(ext) == 8 * 24 and len(internal) == 21
