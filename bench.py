@@ -66,19 +66,6 @@ def device_segment(torch, seg_mod, po2, widths, seed, device):
     return seg, groups, check
 
 
-def usable_cores():
-    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
-    n = len(os.sched_getaffinity(0))
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
 def main():
     args = parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
@@ -272,7 +259,7 @@ def main():
             # its optimised operator forms (oracle/or_fast.c), the same seal as the plain restatement
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
-            cores = usable_cores()
+            cores = oracle_lib.usable_cores()
             cpu_po2 = args.cpu_po2 if args.cpu_po2 is not None else args.po2
             cseg = seg_mod.synthetic_segment(cpu_po2, widths, seed=20240807)
             t1 = time.perf_counter()

@@ -53,6 +53,15 @@ void or_fp4_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
 void or_fp4_inv(const uint32_t* a, uint32_t* out) {
     fp4 x; memcpy(&x, a, 16); fp4 r = fp4_inv(x); memcpy(out, &r, 16);
 }
+/* team size of every later parallel region (the default is one thread per hardware thread of the host,
+ * far more than a container's CPU share: oversubscribed teams spin) */
+void or_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int or_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -182,6 +182,7 @@ int or_toy_poly_ext(void* user, const or_segment* pub, const fp* poly_mix, const
                     const fp* mix, uint32_t n_mix, fp* out);
 void or_free(void* p);
 int or_max_threads(void);
+void or_set_threads(int n);
 /* or_fast.c: route the hot operators (NTT, zk_shift, Poseidon2 rows/folds, tap evaluation, DEEP mix)
  * through their AVX2 / table-driven forms -- the timed cpu_baseline; results are bit-identical */
 void or_set_fast(int on);

@@ -64,9 +64,24 @@ _oracle = None
 _emul = None
 
 
+def usable_cores() -> int:
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU
+    box shows 256 hardware threads to a container that owns 16 of them)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def oracle():
     global _oracle
     if _oracle is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         lib = C.CDLL(build_oracle())
         sz, u32, vp = C.c_size_t, C.c_uint32, C.c_void_p
         sig = {
@@ -98,13 +113,14 @@ def oracle():
             "or_params_preset": (None, [C.POINTER(OrParams), C.c_int]), "or_set_params": (C.c_int, [C.POINTER(OrParams)]),
             "or_prefix_products": (None, [vp, sz]),
             "or_scatter": (None, [vp, vp, sz, vp, vp]),
-            "or_free": (None, [vp]), "or_max_threads": (C.c_int, []),
+            "or_free": (None, [vp]), "or_max_threads": (C.c_int, []), "or_set_threads": (None, [C.c_int]),
             "or_last_timing": (None, [C.POINTER(OrTiming)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        lib.or_set_threads(usable_cores())
         _oracle = lib
     return _oracle
 
@@ -209,7 +225,7 @@ def oracle_prove(seg, threads=0, fast=False):
     c, keep = make_or_segment(seg)
     seal = u32p()
     n = C.c_size_t(0)
-    rc = lib.or_prove_segment(C.byref(c), C.byref(seal), C.byref(n), threads)
+    rc = lib.or_prove_segment(C.byref(c), C.byref(seal), C.byref(n), threads if threads > 0 else usable_cores())
     if rc != 0:
         raise RuntimeError(f"or_prove_segment failed: {rc}")
     lib.or_set_fast(0)
