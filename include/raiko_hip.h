@@ -277,6 +277,49 @@ int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t
 const char* rk_session_last_error(int device);
 int rk_session_release(void);
 
+/* ---- RV32IM executor + segmenter: the step before the path ----
+ * `ExecutorImpl::from_elf(env, elf).run()` (provers/risc0/driver/src/bonsai.rs:267-269): interprets a
+ * 32-bit RISC-V ELF (RV32I + M) and cuts the run into segments of at most 2^segment_limit_po2
+ * cycles (bonsai.rs:249), each with the machine-state digests before and after it.  Host code.
+ * NOT risc0's: the cycle model (one cycle per instruction), the ecall table (t0 selects:
+ * RK_ECALL_HALT a0 = exit code; RK_ECALL_READ a0 = word-aligned destination, a1 = capacity in
+ * words -> a0 = words taken from input_words; RK_ECALL_COMMIT a0 = source, a1 = bytes appended to
+ * the journal) and the state digest (Poseidon2 over pc, registers and touched pages).  The
+ * rv32im witness layout is outside this repo: a segment carries bounds and digests, not columns. */
+typedef struct rk_exec rk_exec;
+enum { RK_ECALL_HALT = 0, RK_ECALL_READ = 1, RK_ECALL_COMMIT = 2 };
+enum { RK_EXIT_HALTED = 0, RK_EXIT_SYSTEM_SPLIT = 2 };
+typedef struct {
+    uint32_t struct_size;          /* = sizeof(rk_exec_opts) */
+    uint32_t segment_limit_po2;    /* 13..24 */
+    uint64_t session_limit;        /* total cycles allowed, 0 = no limit (session_limit(None), bonsai.rs:248) */
+    const uint32_t* input_words;   /* env.write_slice(&encoded_input), bonsai.rs:250 */
+    size_t n_input_words;
+} rk_exec_opts;
+typedef struct {
+    uint64_t total_cycles;
+    uint32_t n_segments;
+    uint32_t exit_code;            /* a0 of the halting ecall */
+    size_t journal_bytes;
+    size_t input_words_read;
+    int status;                    /* RK_OK, or why the run stopped (the segments before it stay readable) */
+} rk_exec_summary;
+typedef struct {
+    uint32_t index;
+    uint32_t po2;                  /* smallest power of two >= cycles, at least 13 */
+    uint64_t cycles;
+    uint32_t start_pc, end_pc;
+    uint32_t exit;                 /* RK_EXIT_SYSTEM_SPLIT for every segment but the last */
+    uint32_t pre_state[8], post_state[8];   /* post_state of segment i == pre_state of segment i + 1 */
+} rk_exec_segment;
+/* *out is set also when the run traps (status < 0): read rk_exec_error, then rk_exec_free */
+int rk_exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out);
+int rk_exec_summary_get(const rk_exec* ex, rk_exec_summary* out);
+int rk_exec_segment_get(const rk_exec* ex, uint32_t index, rk_exec_segment* out);
+int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* len);
+const char* rk_exec_error(const rk_exec* ex);
+int rk_exec_free(rk_exec* ex);
+
 /* per-stage device time of the last rk_prove_segment on this ctx, milliseconds (hipEvent) */
 typedef struct { float ntt, hash, deep, fri, query, total, circuit /* time inside rk_circuit_hooks */; } rk_timing;
 int rk_last_timing(rk_ctx* ctx, rk_timing* out);

@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE -- CPU oracle, not product code (see oracle/oracle.h: parity unpinned).
+
+Pure-Python restatement of the executor + segmenter of raiko_amd/csrc/executor.cpp for small
+programs: RV32I + M straight from the RISC-V unprivileged specification (20191213, chapters 2
+and 7), ELF32 PT_LOAD loading, one cycle per instruction, the three stand-in ecalls and the cut
+into segments of at most 2^po2 cycles.  It stands where `ExecutorImpl::from_elf(env, elf).run()`
+(reference provers/risc0/driver/src/bonsai.rs:267-269) stands; risc0's own executor (cycle
+model, ecall table, paging) lives in crates outside the reference tree and is NOT restated.
+State digests are not recomputed here (they need the Poseidon2 oracle): tests compare registers,
+memory, journal, cycle counts and segment bounds, and check the digests' chaining."""
+import struct
+
+M32 = 0xFFFFFFFF
+ECALL_HALT, ECALL_READ, ECALL_COMMIT = 0, 1, 2
+MIN_PO2 = 13
+
+
+class Trap(Exception):
+    pass
+
+
+def sx(v, bits):
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def s32(v):
+    return sx(v, 32)
+
+
+class Machine:
+    def __init__(self):
+        self.pc = 0
+        self.x = [0] * 32
+        self.mem = {}          # byte address -> byte
+        self.journal = bytearray()
+        self.exit_code = 0
+
+    def lb(self, a):
+        return self.mem.get(a & M32, 0)
+
+    def lw(self, a):
+        return sum(self.lb(a + i) << (8 * i) for i in range(4))
+
+    def sb(self, a, v):
+        self.mem[a & M32] = v & 0xFF
+
+    def sw(self, a, v):
+        for i in range(4):
+            self.sb(a + i, v >> (8 * i))
+
+
+def load_elf(m, elf):
+    if elf[:4] != b"\x7fELF" or elf[4] != 1 or elf[5] != 1:
+        raise Trap("not a 32-bit little-endian ELF")
+    if struct.unpack_from("<H", elf, 18)[0] != 243:
+        raise Trap("not RISC-V")
+    m.pc = struct.unpack_from("<I", elf, 24)[0]
+    phoff, = struct.unpack_from("<I", elf, 28)
+    phentsize, phnum = struct.unpack_from("<HH", elf, 42)
+    for i in range(phnum):
+        t, off, vaddr, _pa, filesz, memsz = struct.unpack_from("<IIIIII", elf, phoff + i * phentsize)
+        if t != 1:
+            continue
+        for b in range(filesz):
+            m.sb(vaddr + b, elf[off + b])
+
+
+def step(m, inputs, in_pos):
+    """returns (halted, in_pos)"""
+    pc, ins = m.pc, m.lw(m.pc)
+    opc, rd, f3, rs1, rs2, f7 = ins & 0x7F, (ins >> 7) & 31, (ins >> 12) & 7, (ins >> 15) & 31, (ins >> 20) & 31, ins >> 25
+    a, b = m.x[rs1], m.x[rs2]
+    nxt, res = (pc + 4) & M32, None
+    if opc == 0x37:
+        res = ins & 0xFFFFF000
+    elif opc == 0x17:
+        res = (pc + (ins & 0xFFFFF000)) & M32
+    elif opc == 0x6F:
+        imm = ((ins >> 31) << 20) | (((ins >> 12) & 0xFF) << 12) | (((ins >> 20) & 1) << 11) | (((ins >> 21) & 0x3FF) << 1)
+        res, nxt = (pc + 4) & M32, (pc + sx(imm, 21)) & M32
+    elif opc == 0x67 and f3 == 0:
+        res, nxt = (pc + 4) & M32, (a + sx(ins >> 20, 12)) & M32 & ~1
+    elif opc == 0x63:
+        imm = ((ins >> 31) << 12) | (((ins >> 7) & 1) << 11) | (((ins >> 25) & 0x3F) << 5) | (((ins >> 8) & 0xF) << 1)
+        cond = {0: a == b, 1: a != b, 4: s32(a) < s32(b), 5: s32(a) >= s32(b), 6: a < b, 7: a >= b}.get(f3)
+        if cond is None:
+            raise Trap("illegal")
+        if cond:
+            nxt = (pc + sx(imm, 13)) & M32
+    elif opc == 0x03:
+        addr = (a + sx(ins >> 20, 12)) & M32
+        if f3 == 0:
+            res = sx(m.lb(addr), 8) & M32
+        elif f3 == 4:
+            res = m.lb(addr)
+        elif f3 in (1, 5):
+            if addr & 1:
+                raise Trap("misaligned")
+            h = m.lb(addr) | (m.lb(addr + 1) << 8)
+            res = sx(h, 16) & M32 if f3 == 1 else h
+        elif f3 == 2:
+            if addr & 3:
+                raise Trap("misaligned")
+            res = m.lw(addr)
+        else:
+            raise Trap("illegal")
+    elif opc == 0x23:
+        addr = (a + sx(((ins >> 25) << 5) | ((ins >> 7) & 31), 12)) & M32
+        if f3 == 0:
+            m.sb(addr, b)
+        elif f3 == 1:
+            if addr & 1:
+                raise Trap("misaligned")
+            m.sb(addr, b)
+            m.sb(addr + 1, b >> 8)
+        elif f3 == 2:
+            if addr & 3:
+                raise Trap("misaligned")
+            m.sw(addr, b)
+        else:
+            raise Trap("illegal")
+    elif opc == 0x13:
+        imm, sh = sx(ins >> 20, 12), rs2
+        if f3 == 0:
+            res = (a + imm) & M32
+        elif f3 == 2:
+            res = int(s32(a) < imm)
+        elif f3 == 3:
+            res = int(a < (imm & M32))
+        elif f3 == 4:
+            res = a ^ (imm & M32)
+        elif f3 == 6:
+            res = a | (imm & M32)
+        elif f3 == 7:
+            res = a & (imm & M32)
+        elif f3 == 1 and f7 == 0:
+            res = (a << sh) & M32
+        elif f3 == 5 and f7 == 0:
+            res = a >> sh
+        elif f3 == 5 and f7 == 0x20:
+            res = (s32(a) >> sh) & M32
+        else:
+            raise Trap("illegal")
+    elif opc == 0x33 and f7 == 1:
+        sa, sb_ = s32(a), s32(b)
+        if f3 == 0:
+            res = (a * b) & M32
+        elif f3 == 1:
+            res = ((sa * sb_) >> 32) & M32
+        elif f3 == 2:
+            res = ((sa * b) >> 32) & M32
+        elif f3 == 3:
+            res = ((a * b) >> 32) & M32
+        elif f3 == 4:   # DIV: quotient rounds towards zero; x / 0 = -1; overflow keeps the dividend
+            res = M32 if b == 0 else a if (a == 0x80000000 and b == M32) else int(abs(sa) // abs(sb_) * (1 if (sa < 0) == (sb_ < 0) else -1)) & M32
+        elif f3 == 5:
+            res = M32 if b == 0 else a // b
+        elif f3 == 6:   # REM: sign of the dividend; x % 0 = x; overflow gives 0
+            res = a if b == 0 else 0 if (a == 0x80000000 and b == M32) else int((abs(sa) % abs(sb_)) * (-1 if sa < 0 else 1)) & M32
+        else:
+            res = a if b == 0 else a % b
+    elif opc == 0x33 and f7 in (0, 0x20):
+        alt = f7 == 0x20
+        if f3 == 0:
+            res = (a - b if alt else a + b) & M32
+        elif f3 == 5:
+            res = ((s32(a) >> (b & 31)) & M32) if alt else a >> (b & 31)
+        elif alt:
+            raise Trap("illegal")
+        elif f3 == 1:
+            res = (a << (b & 31)) & M32
+        elif f3 == 2:
+            res = int(s32(a) < s32(b))
+        elif f3 == 3:
+            res = int(a < b)
+        elif f3 == 4:
+            res = a ^ b
+        elif f3 == 6:
+            res = a | b
+        else:
+            res = a & b
+    elif opc == 0x0F:
+        pass
+    elif ins == 0x00000073:
+        call = m.x[5]
+        if call == ECALL_HALT:
+            m.exit_code = m.x[10]
+            m.pc = nxt
+            return True, in_pos
+        if call == ECALL_READ:
+            dst, cap, got = m.x[10], m.x[11], 0
+            if dst & 3:
+                raise Trap("misaligned")
+            while got < cap and in_pos < len(inputs):
+                m.sw(dst + 4 * got, inputs[in_pos])
+                in_pos += 1
+                got += 1
+            m.x[10] = got
+        elif call == ECALL_COMMIT:
+            for i in range(m.x[11]):
+                m.journal.append(m.lb(m.x[10] + i))
+        else:
+            raise Trap("unknown ecall")
+    else:
+        raise Trap("illegal")
+    if res is not None and rd:
+        m.x[rd] = res & M32
+    if nxt & 3:
+        raise Trap("misaligned jump")
+    m.pc = nxt
+    return False, in_pos
+
+
+def run(elf, inputs=(), segment_limit_po2=20, max_cycles=10 ** 7):
+    """-> dict(segments=[(cycles, po2, start_pc, end_pc, exit)], journal, exit_code, total_cycles, machine)"""
+    m = Machine()
+    load_elf(m, elf)
+    limit, total, in_pos, halted, segs = 1 << segment_limit_po2, 0, 0, False, []
+    while not halted:
+        start, cycles = m.pc, 0
+        while cycles < limit and not halted:
+            if total >= max_cycles:
+                raise Trap("cycle budget of the oracle exhausted")
+            halted, in_pos = step(m, inputs, in_pos)
+            cycles += 1
+            total += 1
+        po2 = MIN_PO2
+        while (1 << po2) < cycles:
+            po2 += 1
+        segs.append((cycles, po2, start, m.pc, 0 if halted else 2))
+    return dict(segments=segs, journal=bytes(m.journal), exit_code=m.exit_code, total_cycles=total, machine=m,
+                input_words_read=in_pos)

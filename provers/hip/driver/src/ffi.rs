@@ -9,6 +9,13 @@
 #![allow(clippy::missing_safety_doc)]
 use std::os::raw::{c_char, c_int, c_void};
 
+pub const RK_ECALL_HALT: c_int = 0;
+pub const RK_ECALL_READ: c_int = 1;
+pub const RK_ECALL_COMMIT: c_int = 2;
+
+pub const RK_EXIT_HALTED: c_int = 0;
+pub const RK_EXIT_SYSTEM_SPLIT: c_int = 2;
+
 pub type rk_status = c_int;
 pub const RK_OK: rk_status = 0;
 pub const RK_ERR_INVALID: rk_status = -1;
@@ -36,6 +43,11 @@ pub const RK_MAX_QUERIES: u32 = 256;
 
 #[repr(C)]
 pub struct rk_ctx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct rk_exec {
     _private: [u8; 0],
 }
 
@@ -137,6 +149,40 @@ pub struct rk_session_opts {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct rk_exec_opts {
+    pub struct_size: u32,
+    pub segment_limit_po2: u32,
+    pub session_limit: u64,
+    pub input_words: *const u32,
+    pub n_input_words: usize,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_exec_summary {
+    pub total_cycles: u64,
+    pub n_segments: u32,
+    pub exit_code: u32,
+    pub journal_bytes: usize,
+    pub input_words_read: usize,
+    pub status: c_int,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_exec_segment {
+    pub index: u32,
+    pub po2: u32,
+    pub cycles: u64,
+    pub start_pc: u32,
+    pub end_pc: u32,
+    pub exit: u32,
+    pub pre_state: [u32; 8],
+    pub post_state[8]: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct rk_timing {
     pub ntt: f32,
     pub hash: f32,
@@ -199,6 +245,12 @@ extern "C" {
     pub fn rk_prove_session(opts: *const rk_session_opts, segs: *const rk_segment, n: usize, h_seals: *const *mut u32, seal_capacity_words: *const usize, seal_words: *mut usize, failed_index: *mut usize) -> c_int;
     pub fn rk_session_last_error(device: c_int) -> *const c_char;
     pub fn rk_session_release() -> c_int;
+    pub fn rk_exec_elf(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
+    pub fn rk_exec_summary_get(ex: *const rk_exec, out: *mut rk_exec_summary) -> c_int;
+    pub fn rk_exec_segment_get(ex: *const rk_exec, index: u32, out: *mut rk_exec_segment) -> c_int;
+    pub fn rk_exec_journal(ex: *const rk_exec, out: *mut u8, capacity: usize, len: *mut usize) -> c_int;
+    pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
+    pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
     pub fn rk_last_timing(ctx: *mut rk_ctx, out: *mut rk_timing) -> c_int;
     pub fn rk_set_kernel_timing(ctx: *mut rk_ctx, enabled: c_int) -> c_int;
     pub fn rk_kernel_stats(ctx: *mut rk_ctx, kclass: c_int, out: *mut rk_kernel_stat) -> c_int;

@@ -113,6 +113,21 @@ class RkTiming(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ntt", "hash", "deep", "fri", "query", "total", "circuit")]
 
 
+class RkExecOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("segment_limit_po2", C.c_uint32), ("session_limit", C.c_uint64),
+                ("input_words", u32p), ("n_input_words", C.c_size_t)]
+
+
+class RkExecSummary(C.Structure):
+    _fields_ = [("total_cycles", C.c_uint64), ("n_segments", C.c_uint32), ("exit_code", C.c_uint32),
+                ("journal_bytes", C.c_size_t), ("input_words_read", C.c_size_t), ("status", C.c_int)]
+
+
+class RkExecSegment(C.Structure):
+    _fields_ = [("index", C.c_uint32), ("po2", C.c_uint32), ("cycles", C.c_uint64), ("start_pc", C.c_uint32),
+                ("end_pc", C.c_uint32), ("exit", C.c_uint32), ("pre_state", C.c_uint32 * 8), ("post_state", C.c_uint32 * 8)]
+
+
 # every symbol include/raiko_hip.h declares: name -> (restype, argtypes)
 _vp, _sz, _u32 = C.c_void_p, C.c_size_t, C.c_uint32
 SYMBOLS = {
@@ -163,6 +178,12 @@ SYMBOLS = {
     "rk_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "rk_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(RkKernelStat)]),
     "rk_kernel_class_name": (C.c_char_p, [C.c_int]),
+    "rk_exec_elf": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(RkExecOpts), C.POINTER(C.c_void_p)]),
+    "rk_exec_summary_get": (C.c_int, [C.c_void_p, C.POINTER(RkExecSummary)]),
+    "rk_exec_segment_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RkExecSegment)]),
+    "rk_exec_journal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rk_exec_error": (C.c_char_p, [C.c_void_p]),
+    "rk_exec_free": (C.c_int, [C.c_void_p]),
     "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
     "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),
 }

@@ -1,0 +1,366 @@
+// RV32IM executor + segmenter: the step BEFORE the proving path --
+// `ExecutorImpl::from_elf(env, elf).run()` at reference provers/risc0/driver/src/bonsai.rs:267-269,
+// which interprets the guest and cuts the run into segments of at most 2^segment_limit_po2 cycles
+// (bonsai.rs:249) that `session.prove()` (bonsai.rs:271) then proves one by one.
+//
+// Host code (no GPU work: the reference's executor is CPU code too, single-threaded).  What is
+// restated is the public part: the RV32IM instruction set (RISC-V unprivileged spec 2.2: RV32I +
+// M), a little-endian paged memory, an ELF32 loader, and the cut into power-of-two segments.
+// What is NOT risc0's (its executor lives in risc0-zkvm / risc0-circuit-rv32im 1.0.1, outside the
+// reference tree): the cycle model (one cycle per instruction here; risc0 charges paging and
+// multi-cycle ecalls), the ecall table (a three-call stand-in: halt / read input words / commit to
+// the journal) and the state digest.  The witness layout of the rv32im circuit is not available
+// either, so a segment here carries its bounds and state digests, not trace columns.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/raiko_hip.h"
+#include "internal.hpp"
+
+namespace {
+
+constexpr uint32_t PAGE_WORDS = 1024;  // 4 KiB pages
+constexpr uint32_t MIN_PO2 = 13;       // risc0's MIN_CYCLES_PO2 (RECALLED): the smallest segment it proves
+
+struct Machine {
+    uint32_t pc = 0;
+    uint32_t x[32] = {0};
+    std::map<uint32_t, std::vector<uint32_t>> pages;  // page index -> 1024 words (ordered: digests walk it)
+
+    uint32_t* word_ptr(uint32_t addr) {
+        auto& pg = pages[addr >> 12];
+        if (pg.empty()) pg.assign(PAGE_WORDS, 0);
+        return &pg[(addr >> 2) & (PAGE_WORDS - 1)];
+    }
+    uint32_t load_word(uint32_t addr) {
+        auto it = pages.find(addr >> 12);
+        return it == pages.end() ? 0u : it->second[(addr >> 2) & (PAGE_WORDS - 1)];
+    }
+    uint8_t load_byte(uint32_t addr) { return (uint8_t)(load_word(addr & ~3u) >> (8 * (addr & 3))); }
+    void store_byte(uint32_t addr, uint8_t v) {
+        uint32_t* w = word_ptr(addr & ~3u);
+        unsigned sh = 8 * (addr & 3);
+        *w = (*w & ~(0xffu << sh)) | ((uint32_t)v << sh);
+    }
+};
+
+// digest of the machine state: Poseidon2 sponge (the default instance) over pc, the registers and
+// every touched page (index, then its words), each 32-bit word as two 16-bit field elements so the
+// encoding is injective.  Stands where risc0's SystemState { pc, merkle_root } stands.
+void state_digest(const p2::Any& k, const Machine& m, uint32_t* out8) {
+    std::vector<uint32_t> e;
+    auto put = [&](uint32_t w) {
+        e.push_back(bb::encode(w & 0xffffu));
+        e.push_back(bb::encode(w >> 16));
+    };
+    put(m.pc);
+    for (int i = 0; i < 32; i++) put(m.x[i]);
+    for (const auto& kv : m.pages) {
+        bool any = false;
+        for (uint32_t w : kv.second) any |= w != 0;
+        if (!any) continue;  // an all-zero page is the same as an absent one
+        put(kv.first);
+        for (uint32_t w : kv.second) put(w);
+    }
+    k.hash_elems(e.data(), e.size(), out8);
+}
+
+}  // namespace
+
+struct rk_exec {
+    std::vector<rk_exec_segment> segments;
+    std::vector<uint8_t> journal;
+    rk_exec_summary summary{};
+    std::string error;
+};
+
+namespace {
+
+int load_elf(Machine& m, const uint8_t* elf, size_t n, std::string& err) {
+    auto rd16 = [&](size_t o) { return (uint32_t)elf[o] | (uint32_t)elf[o + 1] << 8; };
+    auto rd32 = [&](size_t o) { return rd16(o) | rd16(o + 2) << 16; };
+    if (n < 52 || std::memcmp(elf, "\x7f" "ELF", 4) != 0) { err = "not an ELF file"; return RK_ERR_INVALID; }
+    if (elf[4] != 1 || elf[5] != 1) { err = "not a 32-bit little-endian ELF"; return RK_ERR_INVALID; }
+    if (rd16(18) != 243) { err = "not a RISC-V ELF (e_machine != 243)"; return RK_ERR_INVALID; }
+    m.pc = rd32(24);
+    uint32_t phoff = rd32(28), phentsize = rd16(42), phnum = rd16(44);
+    if (phentsize < 32 || (uint64_t)phoff + (uint64_t)phentsize * phnum > n) { err = "program headers out of range"; return RK_ERR_INVALID; }
+    for (uint32_t i = 0; i < phnum; i++) {
+        size_t ph = phoff + (size_t)i * phentsize;
+        if (rd32(ph) != 1) continue;  // PT_LOAD
+        uint32_t off = rd32(ph + 4), vaddr = rd32(ph + 8), filesz = rd32(ph + 16), memsz = rd32(ph + 20);
+        if ((uint64_t)off + filesz > n || filesz > memsz || (uint64_t)vaddr + memsz > 0x100000000ull) {
+            err = "PT_LOAD segment out of range";
+            return RK_ERR_INVALID;
+        }
+        for (uint32_t b = 0; b < filesz; b++) m.store_byte(vaddr + b, elf[off + b]);
+    }
+    if (m.pc & 3) { err = "misaligned entry point"; return RK_ERR_INVALID; }
+    return RK_OK;
+}
+
+inline int32_t sext(uint32_t v, unsigned bits) { return (int32_t)(v << (32 - bits)) >> (32 - bits); }
+
+// one instruction; returns 0 to go on, 1 halted, negative rk_status on a trap
+int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::string& err) {
+    const uint32_t pc = m.pc, ins = m.load_word(pc);
+    const uint32_t opc = ins & 0x7f, rd = (ins >> 7) & 31, f3 = (ins >> 12) & 7, rs1 = (ins >> 15) & 31, rs2 = (ins >> 20) & 31,
+                   f7 = ins >> 25;
+    const uint32_t a = m.x[rs1], b = m.x[rs2];
+    uint32_t next = pc + 4, res = 0;
+    bool wr = false;
+    auto trap = [&](const char* what) {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "%s at pc 0x%08x (instruction 0x%08x)", what, pc, ins);
+        err = buf;
+        return RK_ERR_INVALID;
+    };
+    switch (opc) {
+        case 0x37: res = ins & 0xfffff000u; wr = true; break;                       // LUI
+        case 0x17: res = pc + (ins & 0xfffff000u); wr = true; break;                // AUIPC
+        case 0x6f: {                                                                 // JAL
+            uint32_t imm = ((ins >> 31) << 20) | (((ins >> 12) & 0xff) << 12) | (((ins >> 20) & 1) << 11) | (((ins >> 21) & 0x3ff) << 1);
+            res = pc + 4; wr = true; next = pc + (uint32_t)sext(imm, 21);
+            break;
+        }
+        case 0x67:                                                                   // JALR
+            if (f3 != 0) return trap("illegal instruction");
+            res = pc + 4; wr = true; next = (a + (uint32_t)sext(ins >> 20, 12)) & ~1u;
+            break;
+        case 0x63: {                                                                 // branches
+            uint32_t imm = ((ins >> 31) << 12) | (((ins >> 7) & 1) << 11) | (((ins >> 25) & 0x3f) << 5) | (((ins >> 8) & 0xf) << 1);
+            bool t;
+            switch (f3) {
+                case 0: t = a == b; break;
+                case 1: t = a != b; break;
+                case 4: t = (int32_t)a < (int32_t)b; break;
+                case 5: t = (int32_t)a >= (int32_t)b; break;
+                case 6: t = a < b; break;
+                case 7: t = a >= b; break;
+                default: return trap("illegal instruction");
+            }
+            if (t) next = pc + (uint32_t)sext(imm, 13);
+            break;
+        }
+        case 0x03: {                                                                 // loads
+            uint32_t addr = a + (uint32_t)sext(ins >> 20, 12);
+            switch (f3) {
+                case 0: res = (uint32_t)(int32_t)(int8_t)m.load_byte(addr); break;
+                case 4: res = m.load_byte(addr); break;
+                case 1: case 5: {
+                    if (addr & 1) return trap("misaligned halfword load");
+                    uint32_t h = m.load_byte(addr) | (uint32_t)m.load_byte(addr + 1) << 8;
+                    res = f3 == 1 ? (uint32_t)sext(h, 16) : h;
+                    break;
+                }
+                case 2:
+                    if (addr & 3) return trap("misaligned word load");
+                    res = m.load_word(addr);
+                    break;
+                default: return trap("illegal instruction");
+            }
+            wr = true;
+            break;
+        }
+        case 0x23: {                                                                 // stores
+            uint32_t addr = a + (uint32_t)sext(((ins >> 25) << 5) | ((ins >> 7) & 31), 12);
+            switch (f3) {
+                case 0: m.store_byte(addr, (uint8_t)b); break;
+                case 1:
+                    if (addr & 1) return trap("misaligned halfword store");
+                    m.store_byte(addr, (uint8_t)b); m.store_byte(addr + 1, (uint8_t)(b >> 8));
+                    break;
+                case 2:
+                    if (addr & 3) return trap("misaligned word store");
+                    *m.word_ptr(addr) = b;
+                    break;
+                default: return trap("illegal instruction");
+            }
+            break;
+        }
+        case 0x13: {                                                                 // OP-IMM
+            uint32_t imm = (uint32_t)sext(ins >> 20, 12), sh = rs2;
+            switch (f3) {
+                case 0: res = a + imm; break;
+                case 2: res = (int32_t)a < (int32_t)imm; break;
+                case 3: res = a < imm; break;
+                case 4: res = a ^ imm; break;
+                case 6: res = a | imm; break;
+                case 7: res = a & imm; break;
+                case 1: if (f7 != 0) return trap("illegal instruction"); res = a << sh; break;
+                case 5:
+                    if (f7 == 0) res = a >> sh;
+                    else if (f7 == 0x20) res = (uint32_t)((int32_t)a >> sh);
+                    else return trap("illegal instruction");
+                    break;
+            }
+            wr = true;
+            break;
+        }
+        case 0x33: {                                                                 // OP (RV32I + M)
+            if (f7 == 1) {
+                const int64_t sa = (int32_t)a, sb = (int32_t)b;
+                switch (f3) {
+                    case 0: res = a * b; break;                                                   // MUL
+                    case 1: res = (uint32_t)((uint64_t)(sa * sb) >> 32); break;                   // MULH
+                    case 2: res = (uint32_t)((uint64_t)(sa * (int64_t)(uint64_t)b) >> 32); break; // MULHSU
+                    case 3: res = (uint32_t)(((uint64_t)a * b) >> 32); break;                     // MULHU
+                    case 4: res = b == 0 ? 0xffffffffu : (a == 0x80000000u && b == 0xffffffffu) ? a : (uint32_t)((int32_t)a / (int32_t)b); break;
+                    case 5: res = b == 0 ? 0xffffffffu : a / b; break;
+                    case 6: res = b == 0 ? a : (a == 0x80000000u && b == 0xffffffffu) ? 0 : (uint32_t)((int32_t)a % (int32_t)b); break;
+                    case 7: res = b == 0 ? a : a % b; break;
+                }
+            } else if (f7 == 0 || f7 == 0x20) {
+                const bool alt = f7 == 0x20;
+                switch (f3) {
+                    case 0: res = alt ? a - b : a + b; break;
+                    case 5: res = alt ? (uint32_t)((int32_t)a >> (b & 31)) : a >> (b & 31); break;
+                    default:
+                        if (alt) return trap("illegal instruction");
+                        switch (f3) {
+                            case 1: res = a << (b & 31); break;
+                            case 2: res = (int32_t)a < (int32_t)b; break;
+                            case 3: res = a < b; break;
+                            case 4: res = a ^ b; break;
+                            case 6: res = a | b; break;
+                            case 7: res = a & b; break;
+                        }
+                }
+            } else {
+                return trap("illegal instruction");
+            }
+            wr = true;
+            break;
+        }
+        case 0x0f: break;                                                            // FENCE: no-op
+        case 0x73: {                                                                 // SYSTEM
+            if (ins != 0x00000073u) return trap(ins == 0x00100073u ? "ebreak" : "illegal instruction");
+            // the stand-in ecall table: t0 selects the call
+            switch (m.x[5]) {
+                case RK_ECALL_HALT:
+                    ex.summary.exit_code = m.x[10];
+                    m.pc = next;
+                    return 1;
+                case RK_ECALL_READ: {  // a0 = destination (word aligned), a1 = capacity in words -> a0 = words read
+                    uint32_t dst = m.x[10], cap = m.x[11], got = 0;
+                    if (dst & 3) return trap("misaligned read destination");
+                    while (got < cap && in_pos < o.n_input_words) {
+                        *m.word_ptr(dst + 4 * got) = o.input_words[in_pos++];
+                        got++;
+                    }
+                    m.x[10] = got;
+                    break;
+                }
+                case RK_ECALL_COMMIT: {  // a0 = source, a1 = bytes: appended to the journal
+                    uint32_t src = m.x[10], len = m.x[11];
+                    if (ex.journal.size() + (size_t)len > ((size_t)1 << 24)) return trap("journal larger than 16 MiB");
+                    for (uint32_t i = 0; i < len; i++) ex.journal.push_back(m.load_byte(src + i));
+                    break;
+                }
+                default: return trap("unknown ecall");
+            }
+            break;
+        }
+        default: return trap("illegal instruction");
+    }
+    if (wr && rd != 0) m.x[rd] = res;
+    if (next & 3) return trap("misaligned jump target");
+    m.pc = next;
+    return 0;
+}
+
+int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exec** out) {
+    if (!out) return RK_ERR_INVALID;
+    *out = nullptr;
+    if (!elf || !o || o->struct_size != sizeof(rk_exec_opts)) return RK_ERR_INVALID;
+    if (o->segment_limit_po2 < MIN_PO2 || o->segment_limit_po2 > 24) return RK_ERR_INVALID;
+    if (o->n_input_words && !o->input_words) return RK_ERR_INVALID;
+    auto ex = std::make_unique<rk_exec>();
+    Machine m;
+    int st = load_elf(m, elf, elf_bytes, ex->error);
+    // the default Poseidon2 instance commits to the machine state at every segment boundary
+    rk::Sys sys;
+    auto k = std::make_unique<p2::Any>();
+    rk_params def;
+    rk::params_preset(&def, RK_PRESET_RISC0);
+    if (st == RK_OK) st = rk::resolve_params(&def, &sys, k.get());
+    const uint64_t limit = (uint64_t)1 << o->segment_limit_po2;
+    uint64_t total = 0;
+    size_t in_pos = 0;
+    bool halted = false;
+    while (st == RK_OK && !halted) {
+        rk_exec_segment seg{};
+        seg.index = (uint32_t)ex->segments.size();
+        seg.start_pc = m.pc;
+        state_digest(*k, m, seg.pre_state);
+        uint64_t cycles = 0;
+        while (cycles < limit) {
+            if (o->session_limit && total >= o->session_limit) {
+                ex->error = "session limit reached";
+                st = RK_ERR_CAPACITY;
+                break;
+            }
+            int r = step(m, *ex, *o, in_pos, ex->error);
+            if (r < 0) { st = r; break; }
+            cycles++;
+            total++;
+            if (r == 1) { halted = true; break; }
+        }
+        if (st != RK_OK) break;
+        seg.cycles = cycles;
+        uint32_t po2 = MIN_PO2;
+        while (((uint64_t)1 << po2) < cycles) po2++;
+        seg.po2 = po2;
+        seg.end_pc = m.pc;
+        seg.exit = halted ? RK_EXIT_HALTED : RK_EXIT_SYSTEM_SPLIT;
+        state_digest(*k, m, seg.post_state);
+        ex->segments.push_back(seg);
+        if (ex->segments.size() > (1u << 20)) { ex->error = "more than 2^20 segments"; st = RK_ERR_CAPACITY; }
+    }
+    ex->summary.total_cycles = total;
+    ex->summary.n_segments = (uint32_t)ex->segments.size();
+    ex->summary.journal_bytes = ex->journal.size();
+    ex->summary.input_words_read = in_pos;
+    ex->summary.status = st;
+    *out = ex.release();  // also on failure: the caller reads the error text, then frees
+    return st;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out) {
+    RK_GUARD_BEGIN
+    return exec_elf(elf, elf_bytes, opts, out);
+    RK_GUARD_END
+}
+int rk_exec_summary_get(const rk_exec* ex, rk_exec_summary* out) {
+    if (!ex || !out) return RK_ERR_INVALID;
+    *out = ex->summary;
+    return RK_OK;
+}
+int rk_exec_segment_get(const rk_exec* ex, uint32_t index, rk_exec_segment* out) {
+    if (!ex || !out || index >= ex->segments.size()) return RK_ERR_INVALID;
+    *out = ex->segments[index];
+    return RK_OK;
+}
+int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* len) {
+    if (!ex || !len) return RK_ERR_INVALID;
+    *len = ex->journal.size();
+    if (ex->journal.size() > capacity || (!out && !ex->journal.empty())) return RK_ERR_CAPACITY;
+    if (!ex->journal.empty()) std::memcpy(out, ex->journal.data(), ex->journal.size());
+    return RK_OK;
+}
+const char* rk_exec_error(const rk_exec* ex) { return ex ? ex->error.c_str() : ""; }
+int rk_exec_free(rk_exec* ex) {
+    delete ex;
+    return RK_OK;
+}
+
+}  // extern "C"

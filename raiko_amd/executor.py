@@ -1,0 +1,107 @@
+"""The executor + segmenter in front of the proving path: binding of rk_exec_* (raiko_amd/csrc/
+executor.cpp) and `execute_and_prove`, the shape of `prove_locally` (reference
+provers/risc0/driver/src/bonsai.rs:230-272): run the guest ELF, cut the run into segments of at
+most 2^po2 cycles, prove every segment, return the receipt.
+
+What the library restates is the public part (RV32IM, ELF32, power-of-two segments); the cycle
+model, the ecall table and the state digest are stand-ins and the rv32im circuit's witness layout
+is not available (risc0-circuit-rv32im is outside the reference tree), so the segments handed to
+the prover carry SYNTHETIC trace columns of the executed segment's size -- seeded by the
+segment's state digests, so a different run gives different seals.  See include/raiko_hip.h."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .segment import Segment, synthetic_segment
+
+
+RkExecOpts, RkExecSummary, RkExecSegment = _lib.RkExecOpts, _lib.RkExecSummary, _lib.RkExecSegment
+
+
+@dataclass
+class ExecSegment:
+    index: int
+    po2: int
+    cycles: int
+    start_pc: int
+    end_pc: int
+    exit: int
+    pre_state: Tuple[int, ...]
+    post_state: Tuple[int, ...]
+
+
+@dataclass
+class Execution:
+    """`risc0_zkvm::Session` as far as this backend has it: segment list, journal, exit code"""
+    segments: List[ExecSegment]
+    journal: bytes
+    exit_code: int
+    total_cycles: int
+    input_words_read: int
+
+
+class ExecutorError(RuntimeError):
+    pass
+
+
+def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20, session_limit: int = 0) -> Execution:
+    """`ExecutorImpl::from_elf(env, elf).run()` (bonsai.rs:246-269).  Raises ExecutorError on a trap
+    (illegal instruction, misaligned access, unknown ecall, session limit)."""
+    lib = _lib.load()
+    words = np.ascontiguousarray(input_words, dtype=np.uint32)
+    opts = RkExecOpts(struct_size=C.sizeof(RkExecOpts), segment_limit_po2=segment_limit_po2, session_limit=session_limit,
+                      input_words=words.ctypes.data_as(_lib.u32p), n_input_words=words.size)
+    handle = C.c_void_p()
+    st = lib.rk_exec_elf(bytes(elf), len(elf), C.byref(opts), C.byref(handle))
+    try:
+        if st != 0:
+            detail = lib.rk_exec_error(handle).decode() if handle else ""
+            raise ExecutorError("%s%s" % (lib.rk_strerror(st).decode(), ": " + detail if detail else ""))
+        summ = RkExecSummary()
+        lib.rk_exec_summary_get(handle, C.byref(summ))
+        segs = []
+        for i in range(summ.n_segments):
+            s = RkExecSegment()
+            lib.rk_exec_segment_get(handle, i, C.byref(s))
+            segs.append(ExecSegment(s.index, s.po2, int(s.cycles), s.start_pc, s.end_pc, s.exit,
+                                    tuple(s.pre_state), tuple(s.post_state)))
+        buf = C.create_string_buffer(max(int(summ.journal_bytes), 1))
+        n = C.c_size_t(0)
+        lib.rk_exec_journal(handle, buf, summ.journal_bytes, C.byref(n))
+        return Execution(segs, buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read))
+    finally:
+        if handle:
+            lib.rk_exec_free(handle)
+
+
+def segments_for_proving(ex: Execution, widths: Tuple[int, int, int] = (16, 16, 224)) -> List[Segment]:
+    """One prover segment per executed segment, of the executed size (2^po2 rows); the trace columns
+    are the synthetic stand-in (no rv32im witness layout here), seeded by the segment's digests and
+    carrying them as globals, so the seal binds the state transition the executor saw."""
+    out = []
+    for s in ex.segments:
+        seed = int.from_bytes(np.array(s.pre_state + s.post_state, dtype="<u4").tobytes()[:8], "little")
+        seg = synthetic_segment(s.po2, widths, seed=seed % (1 << 62), n_globals=0)
+        seg.globals_ = np.array(list(s.pre_state) + list(s.post_state) + [s.start_pc % 2013265921, s.exit], dtype=np.uint32)
+        out.append(seg)
+    return out
+
+
+def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20,
+                      widths: Tuple[int, int, int] = (16, 16, 224), device: int = 0, inflight: int = 3):
+    """`prove_locally` end to end (bonsai.rs:230-272): execute, segment, prove every segment through
+    rk_prove_session, assemble the receipt around the journal the guest committed.
+    Returns (Execution, Receipt)."""
+    from .hal import prove_session
+    from .receipt import Receipt, SegmentReceipt
+    ex = execute(elf, input_words, segment_limit_po2=segment_limit_po2)
+    segs = segments_for_proving(ex, widths)
+    seals = prove_session(segs, device=device, inflight=inflight)
+    n = len(seals)
+    receipts = [SegmentReceipt(seal=s, index=i, po2=segs[i].po2,
+                               exit_code=("Halted", ex.exit_code) if i + 1 == n else ("SystemSplit", None))
+                for i, s in enumerate(seals)]
+    return ex, Receipt(segments=receipts, journal=ex.journal)

@@ -1,0 +1,163 @@
+"""The RV32IM executor + segmenter (raiko_amd/csrc/executor.cpp, the step before the proving path:
+reference provers/risc0/driver/src/bonsai.rs:246-269) against the pure-Python restatement
+oracle/or_rv32.py, on hand-assembled programs (tests/rv32_asm.py -- the prebuilt guest ELFs of the
+reference are not run, and the image has no RISC-V toolchain) and on random instruction streams."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import or_rv32  # noqa: E402
+import rv32_asm as A  # noqa: E402
+from raiko_amd import executor as X  # noqa: E402
+
+HALT = A.li("t0", 0) + [("ecall",)]
+
+
+def both(code_prog, inputs=(), po2=13, data=b""):
+    code, labels = A.assemble(code_prog)
+    image = A.elf(code, data=data)
+    got = X.execute(image, inputs, segment_limit_po2=po2)
+    want = or_rv32.run(image, list(inputs), segment_limit_po2=po2)
+    assert got.total_cycles == want["total_cycles"]
+    assert got.exit_code == want["exit_code"] and got.journal == want["journal"]
+    assert got.input_words_read == want["input_words_read"]
+    assert [(s.cycles, s.po2, s.start_pc, s.end_pc, s.exit) for s in got.segments] == want["segments"]
+    # the state digests chain: what one segment ends in is what the next starts from
+    for a, b in zip(got.segments, got.segments[1:]):
+        assert a.post_state == b.pre_state and a.exit == 2
+    assert got.segments[-1].exit == 0
+    return got, want
+
+
+def commit_reg(reg):
+    """store `reg` at 0x300100 and commit those 4 bytes to the journal"""
+    return A.li("t1", 0x300100) + [("sw", reg, 0, "t1")] + A.li("t0", 2) + [("addi", "a0", "t1", 0), ("addi", "a1", "zero", 4), ("ecall",)]
+
+
+def test_fibonacci_and_journal():
+    prog = A.li("a2", 30) + [("addi", "a3", "zero", 0), ("addi", "a4", "zero", 1), "loop:",
+                             ("add", "a5", "a3", "a4"), ("addi", "a3", "a4", 0), ("addi", "a4", "a5", 0),
+                             ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + commit_reg("a3") + \
+        [("addi", "a0", "zero", 7)] + HALT
+    got, _ = both(prog)
+    assert got.journal == (832040).to_bytes(4, "little") and got.exit_code == 7
+    assert len(got.segments) == 1 and got.segments[0].po2 == 13
+
+
+def test_input_words_memory_and_byte_accesses():
+    # read 5 words, sum them, then exercise sb/sh/lb/lbu/lh/lhu sign extension through memory
+    prog = A.li("t0", 1) + A.li("a0", 0x300000) + [("addi", "a1", "zero", 8), ("ecall",), ("addi", "s2", "a0", 0)] + \
+        A.li("t1", 0x300000) + [("addi", "s3", "zero", 0), "sum:", ("lw", "t2", 0, "t1"), ("add", "s3", "s3", "t2"),
+                                ("addi", "t1", "t1", 4), ("addi", "s2", "s2", -1), ("bne", "s2", "zero", "sum")] + \
+        commit_reg("s3") + A.li("t1", 0x300200) + A.li("t2", 0xFFFF80F0) + \
+        [("sw", "t2", 0, "t1"), ("lb", "a2", 0, "t1"), ("lbu", "a3", 0, "t1"), ("lh", "a4", 0, "t1"), ("lhu", "a5", 2, "t1"),
+         ("sb", "a2", 5, "t1"), ("sh", "a4", 6, "t1"), ("lw", "a6", 4, "t1"), ("add", "a2", "a2", "a3"), ("add", "a2", "a2", "a4"),
+         ("add", "a2", "a2", "a5"), ("add", "a2", "a2", "a6")] + commit_reg("a2") + HALT
+    got, _ = both(prog, inputs=[5, 0xFFFFFFFF, 7, 1 << 31, 11])
+    assert got.input_words_read == 5
+    assert int.from_bytes(got.journal[:4], "little") == (5 + 0xFFFFFFFF + 7 + (1 << 31) + 11) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("a,b", [(7, 3), (-7, 3), (7, -3), (0x80000000, 0xFFFFFFFF), (123456789, 0), (0, 5), (0xFFFFFFFF, 0xFFFFFFFF),
+                                 (0x7FFFFFFF, 0x7FFFFFFF), (0x80000000, 2)])
+def test_m_extension_edge_cases(a, b):
+    ops = ["mul", "mulh", "mulhsu", "mulhu", "div", "divu", "rem", "remu"]
+    prog = A.li("s2", a) + A.li("s3", b) + A.li("t1", 0x300000)
+    for i, op in enumerate(ops):
+        prog += [(op, "a2", "s2", "s3"), ("sw", "a2", 4 * i, "t1")]
+    prog += A.li("t0", 2) + [("addi", "a0", "t1", 0), ("addi", "a1", "zero", 32), ("ecall",)] + HALT
+    got, _ = both(prog)
+    au, bu = a & 0xFFFFFFFF, b & 0xFFFFFFFF
+    sa, sb = or_rv32.s32(au), or_rv32.s32(bu)
+    vals = np.frombuffer(got.journal, dtype="<u4")
+    assert int(vals[0]) == (au * bu) & 0xFFFFFFFF and int(vals[3]) == (au * bu) >> 32
+    assert int(vals[1]) == ((sa * sb) >> 32) & 0xFFFFFFFF and int(vals[2]) == ((sa * bu) >> 32) & 0xFFFFFFFF
+    if bu:
+        assert int(vals[5]) == au // bu and int(vals[7]) == au % bu
+    else:
+        assert int(vals[4]) == 0xFFFFFFFF and int(vals[5]) == 0xFFFFFFFF and int(vals[6]) == au and int(vals[7]) == au
+
+
+def test_jumps_and_function_call():
+    prog = [("jal", "ra", "func"), ("addi", "s2", "a0", 0), ("auipc", "t2", 0), ("jalr", "zero", 12, "t2"), ("addi", "s2", "zero", 99),
+            ("jal", "zero", "done"), "func:", ("addi", "a0", "zero", 41), ("addi", "a0", "a0", 1), ("jalr", "zero", 0, "ra"),
+            "done:"] + commit_reg("s2") + HALT
+    got, _ = both(prog)
+    assert got.journal == (42).to_bytes(4, "little")
+
+
+def test_segments_split_at_the_limit():
+    # a loop of 5 instructions x 9000 iterations (+ prologue): several 2^13-cycle segments, the last one short
+    prog = A.li("a2", 9000) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("slli", "a5", "a4", 1),
+                               ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + commit_reg("a4") + HALT
+    got, want = both(prog, po2=13)
+    assert got.total_cycles > 45000 and len(got.segments) == -(-got.total_cycles // 8192)
+    assert all(s.cycles == 8192 and s.po2 == 13 for s in got.segments[:-1])
+    assert got.segments[-1].cycles == got.total_cycles - 8192 * (len(got.segments) - 1)
+    assert len({s.pre_state for s in got.segments}) == len(got.segments)       # every boundary state is distinct
+    # the same run under a larger limit: one segment, same journal
+    one = X.execute(A.elf(A.assemble(prog)[0]), segment_limit_po2=16)
+    assert len(one.segments) == 1 and one.segments[0].po2 == 16 and one.journal == got.journal
+    assert one.segments[0].pre_state == got.segments[0].pre_state and one.segments[0].post_state == got.segments[-1].post_state
+
+
+def test_random_alu_streams():
+    """seeded random straight-line RV32IM code over all registers, then every register committed"""
+    rng = np.random.default_rng(7)
+    r_ops, i_ops, sh_ops = list(A.R_OPS), list(A.I_OPS), list(A.SH_OPS)
+    for case in range(6):
+        prog = []
+        for r in range(1, 32):
+            prog += A.li(r, int(rng.integers(0, 1 << 32)))
+        for _ in range(400):
+            kind = int(rng.integers(0, 4))
+            rd, rs1, rs2 = (int(x) for x in rng.integers(0, 32, 3))
+            if kind == 0:
+                prog.append((r_ops[int(rng.integers(0, len(r_ops)))], rd, rs1, rs2))
+            elif kind == 1:
+                prog.append((i_ops[int(rng.integers(0, len(i_ops)))], rd, rs1, int(rng.integers(-2048, 2048))))
+            elif kind == 2:
+                prog.append((sh_ops[int(rng.integers(0, len(sh_ops)))], rd, rs1, int(rng.integers(0, 32))))
+            else:
+                prog.append(("lui", rd, int(rng.integers(0, 1 << 20))))
+        prog += A.li("t1", 0x300000)[:1]          # lui t1 (address 0x300000): clobbers t1 only
+        for r in range(32):
+            if r != 6:
+                prog.append(("sw", r, 4 * r, "t1"))
+        prog += A.li("t0", 2) + [("addi", "a0", "t1", 0), ("addi", "a1", "zero", 128), ("ecall",)] + HALT
+        both(prog)
+
+
+def test_traps_are_errors_not_crashes():
+    for prog, what in (([("word", 0xFFFFFFFF)], "illegal"), (A.li("t1", 0x300001) + [("lw", "a0", 0, "t1")], "misaligned"),
+                       (A.li("t0", 9) + [("ecall",)], "ecall"), ([("ebreak",)], "ebreak"),
+                       (A.li("t1", 0x200802) + [("jalr", "zero", 0, "t1")], "misaligned")):
+        image = A.elf(A.assemble(prog)[0])
+        with pytest.raises(X.ExecutorError) as ei:
+            X.execute(image)
+        assert what in str(ei.value)
+        with pytest.raises(or_rv32.Trap):
+            or_rv32.run(image)
+    with pytest.raises(X.ExecutorError):
+        X.execute(b"not an elf at all" * 10)
+    loop = A.elf(A.assemble(["spin:", ("jal", "zero", "spin")])[0])
+    with pytest.raises(X.ExecutorError) as ei:
+        X.execute(loop, session_limit=100000)
+    assert "session limit" in str(ei.value)
+    with pytest.raises(X.ExecutorError):
+        X.execute(loop, segment_limit_po2=12)     # below the smallest segment
+
+
+def test_segments_for_proving_follow_the_execution():
+    prog = A.li("a2", 3000) + ["loop:", ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + HALT
+    ex = X.execute(A.elf(A.assemble(prog)[0]), segment_limit_po2=13)
+    segs = X.segments_for_proving(ex, widths=(4, 4, 8))
+    assert [s.po2 for s in segs] == [s.po2 for s in ex.segments]
+    assert all(tuple(int(x) for x in s.globals_[:8]) == e.pre_state for s, e in zip(segs, ex.segments))
+    other = X.execute(A.elf(A.assemble(A.li("a2", 3001) + prog[len(A.li("a2", 3000)):])[0]), segment_limit_po2=13)
+    assert X.segments_for_proving(other, widths=(4, 4, 8))[0].globals_.tolist() != segs[0].globals_.tolist() or \
+        X.segments_for_proving(other, widths=(4, 4, 8))[-1].globals_.tolist() != segs[-1].globals_.tolist()

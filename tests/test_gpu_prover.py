@@ -271,3 +271,30 @@ def test_tiny_segments(hal, po2, widths):
     assert o.oracle_verify(seg, got) == 0
     with pytest.raises(RkError):
         hal.prove_segment(synthetic_segment(1, widths, seed=1))
+
+
+def test_execute_segment_and_prove_an_elf(hal):
+    """bonsai.rs:246-272 in one go: the RV32IM executor runs a hand-assembled guest, the run is cut into
+    2^13-cycle segments, every segment is proven (rk_prove_session) and the receipt carries the journal
+    the guest committed; seals equal the oracle's for the same segments"""
+    import rv32_asm as A
+    from raiko_amd import executor as X
+    from raiko_amd import receipt as rc
+    prog = A.li("a2", 5000) + [("addi", "a3", "zero", 0), ("addi", "a4", "zero", 1), "loop:",
+                               ("add", "a5", "a3", "a4"), ("addi", "a3", "a4", 0), ("addi", "a4", "a5", 0),
+                               ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + \
+        A.li("t1", 0x300100) + [("sw", "a3", 0, "t1")] + A.li("t0", 2) + \
+        [("addi", "a0", "t1", 0), ("addi", "a1", "zero", 4), ("ecall",), ("addi", "a0", "zero", 0)] + A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    ex, receipt = X.execute_and_prove(image, segment_limit_po2=13, widths=(4, 4, 12), inflight=2)
+    assert len(ex.segments) == 4 and ex.total_cycles == 5 * 5000 + 13
+    fib = [0, 1]
+    for _ in range(5000):
+        fib = [fib[1], (fib[0] + fib[1]) & 0xFFFFFFFF]
+    assert receipt.journal == fib[0].to_bytes(4, "little")
+    segs = X.segments_for_proving(ex, widths=(4, 4, 12))
+    for seg, seal in zip(segs, receipt.seals):
+        assert np.array_equal(seal, o.oracle_prove(seg))
+    assert [s.exit_code[0] for s in receipt.segments] == ["SystemSplit"] * 3 + ["Halted"]
+    uuid, back = rc.deserialize(rc.serialize("", receipt))
+    assert back.journal == receipt.journal and len(back.seals) == 4

@@ -22,6 +22,9 @@ SCALARS = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8"
            "double": "f64", "char": "c_char", "void": "c_void"}
 
 
+OPAQUE = set()   # `typedef struct X X;` handles, filled by parse_header
+
+
 def strip_comments(src):
     return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
 
@@ -38,7 +41,7 @@ def rust_type(ctype, structs_enums, fn_types):
         return "Option<%s>" % base
     if base in SCALARS:
         rbase = SCALARS[base]
-    elif base in structs_enums or base == "rk_ctx":
+    elif base in structs_enums or base in OPAQUE:
         rbase = base
     else:
         raise ValueError("unknown C type %r" % base)
@@ -65,6 +68,23 @@ def split_decl(decl):
 def parse_header(src):
     src = strip_comments(src)
     enums, structs, fn_types, funcs = {}, {}, {}, []
+    OPAQUE.clear()
+    OPAQUE.update(re.findall(r"typedef struct (\w+) \1;", src))
+    # anonymous `enum { A = 0, B = 1 };` blocks: plain constants
+    for k, m in enumerate(re.finditer(r"^enum \{(.*?)\};", src, flags=re.S | re.M)):
+        vals, nxt = [], 0
+        for item in m.group(1).split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, v = [x.strip() for x in item.split("=")]
+                nxt = int(v, 0)
+            else:
+                name = item
+            vals.append((name, nxt))
+            nxt += 1
+        enums["__anon%d" % k] = vals
     for m in re.finditer(r"typedef enum \{(.*?)\}\s*(\w+);", src, flags=re.S):
         vals, nxt = [], 0
         for item in m.group(1).split(","):
@@ -103,6 +123,7 @@ def parse_header(src):
         fields.sort(key=lambda f: f[4])
         structs[name] = fields
     body = re.sub(r"typedef (enum|struct) \{.*?\}\s*\w+;", "", src, flags=re.S)
+    body = re.sub(r"^enum \{.*?\};", "", body, flags=re.S | re.M)
     body = re.sub(r"typedef .*?;", "", body, flags=re.S)
     for m in re.finditer(r"^([A-Za-z_][A-Za-z_0-9 \*]*?)\b(rk_[a-z0-9_]+)\s*\((.*?)\);", body, flags=re.S | re.M):
         funcs.append((m.group(2), m.group(1).strip(), m.group(3)))
@@ -125,17 +146,20 @@ def params_to_rust(params, known, fn_types):
 
 def emit(header_src):
     enums, structs, fn_types, funcs = parse_header(header_src)
-    known = set(enums) | set(structs)
+    known = {e for e in enums if not e.startswith('__anon')} | set(structs)
     lines = []
     for name, vals in enums.items():
-        lines.append("pub type %s = c_int;" % name)
+        tname = "c_int" if name.startswith("__anon") else name
+        if tname != "c_int":
+            lines.append("pub type %s = c_int;" % name)
         for vn, v in vals:
-            lines.append("pub const %s: %s = %d;" % (vn, name, v))
+            lines.append("pub const %s: %s = %d;" % (vn, tname, v))
         lines.append("")
     for m in re.finditer(r"^#define (RK_[A-Z0-9_]+) (\d+)\s*$", strip_comments(header_src), flags=re.M):
         lines.append("pub const %s: u32 = %s;" % (m.group(1), m.group(2)))
     lines.append("")
-    lines.append("#[repr(C)]\npub struct rk_ctx {\n    _private: [u8; 0],\n}\n")
+    for name in sorted(OPAQUE):
+        lines.append("#[repr(C)]\npub struct %s {\n    _private: [u8; 0],\n}\n" % name)
     for name, (ret, params) in fn_types.items():
         ps = ", ".join("%s: %s" % p for p in params_to_rust(params, known, fn_types))
         lines.append("pub type %s = unsafe extern \"C\" fn(%s) -> %s;" % (name, ps, rust_type(ret, known, fn_types)))
