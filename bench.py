@@ -198,7 +198,7 @@ def main():
             "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
             "serial_avg_launch_ms": round(calib[dom_name]["ms"] / max(calib[dom_name]["launches"], 1), 4),
             "note": "Poseidon2 hashing is integer-ALU-bound (about 1.36k modular multiplies per 64 B absorbed, "
-                    "~7.2k VALU instructions per permutation at 16 lanes/clk/SIMD: see `alu`); the HBM fraction is "
+                    "~6.7k VALU instructions per permutation at 16 lanes/clk/SIMD: see `alu`); the HBM fraction is "
                     "reported because it is the contract figure",
         }
         if dom_name == "hash_rows_kernel" and dom["ms"] > 0:

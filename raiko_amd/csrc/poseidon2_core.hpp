@@ -1,5 +1,5 @@
-// Poseidon2 over BabyBear, width 24, rate 16, x^7, R_F = 8, R_P = 21 -- the
-// permutation of risc0's default "poseidon2" hash suite (risc0-zkp
+// Poseidon2 over BabyBear, x^7, R_F = 8 -- width 24 / rate 16 / R_P = 21 is the
+// permutation of risc0's default "poseidon2" hash suite; width 16 / R_P = 13 is SP1's shape (risc0-zkp
 // core/hash/poseidon2, un-vendored; reached from the reference through
 // `session.prove()` at provers/risc0/driver/src/bonsai.rs:271).  Constants come
 // from tools/gen_poseidon2_consts.py (Grain LFSR + published diagonal).
@@ -21,7 +21,8 @@
 //     partial rounds (one product for cell 0), the second block's by one product per OUTPUT cell
 //     after the last layer, so a caller that keeps only some cells (digest, sponge capacity)
 //     pays only for those;
-//   * internal layers: all 21 partial rounds in closed form (see partial_rounds()).
+//   * internal layers: three instructions per cell per partial round, the addition of the cell sum
+//     riding inside the Montgomery reduction (see partial_rounds()).
 #pragma once
 #include "bb.hpp"
 
@@ -131,8 +132,12 @@ static constexpr int ROUNDS_PARTIAL = RP;
 static constexpr int M4_KIND = M4K;
 
 // per round r: 23 pairs d_i^r, r pairs c_(r-1-j), then d_0 + 1; at the end 23 x (d_i^21, d_i^(20-j))
+#if defined(RK_P2_CLOSED_FORM)
 static constexpr int PR_STREAM_USED = ROUNDS_PARTIAL * (2 * (CELLS - 1) + 1) + ROUNDS_PARTIAL * (ROUNDS_PARTIAL - 1) +
                                (CELLS - 1) * 2 * (ROUNDS_PARTIAL + 1);
+#else
+static constexpr int PR_STREAM_USED = ROUNDS_PARTIAL * CELLS;  // one multiplier per cell per round
+#endif
 static constexpr int PR_STREAM_WORDS = (PR_STREAM_USED + 15) / 16 * 16 + 16;
 
 struct Consts {
@@ -147,6 +152,8 @@ struct Consts {
     uint32_t fix[2];                                   // block-end rescale constants 2^(32 (2 - e_end)), plain residues
     uint32_t fix0_nq;                                  // fix[0] * (-p^-1) mod 2^32 (bb::umul_const companion)
     uint32_t fix1_q;                                   // fix[1] * p^-1 mod 2^32 (bb::smul_const companion)
+    uint32_t sig0_c, sig0_nq;                          // fix[0] * 2^32 and its companion: entry sum -> Montgomery form
+    uint32_t r3_c, r3_nq;                              // 2^96 mod p and its companion: S -> S * 2^32 (see partial_rounds())
     // partial rounds in closed form (see partial_rounds()): the constants in the order the
     // code consumes them, each as a pair {c, c * 2^16 mod p} for the low / high 16-bit halves
     // of the variable it multiplies (+ one chunk of padding for the read-ahead)
@@ -187,6 +194,11 @@ static inline void derive(Consts& k) {
     }
     k.fix0_nq = k.fix[0] * (0u - bb::MPRIME);
     k.fix1_q = k.fix[1] * bb::MPRIME;
+    k.sig0_c = bb::encode(k.fix[0]);
+    k.sig0_nq = k.sig0_c * (0u - bb::MPRIME);
+    k.r3_c = bb::encode(bb::encode(bb::ONE));
+    k.r3_nq = k.r3_c * (0u - bb::MPRIME);
+#if defined(RK_P2_CLOSED_FORM)
     // closed-form partial rounds: powers of the diagonal (Montgomery residues: they multiply a
     // Montgomery-form variable and the sum goes through one REDC).  The constants that multiply
     // the ENTRY cells also carry fix[0]: those cells arrive scaled by the first block.
@@ -212,6 +224,13 @@ static inline void derive(Consts& k) {
         put(bb::mul(pw[i][ROUNDS_PARTIAL], k.fix[0]));
         for (int j = 0; j < ROUNDS_PARTIAL; j++) put(pw[i][ROUNDS_PARTIAL - 1 - j]);
     }
+#else
+    // direct partial rounds: round r, cell i multiplies by d_i (Montgomery residue); in round 0 the cells
+    // other than 0 still carry the first block's scale, so their multiplier is d_i * fix[0] / 2^32
+    int n = 0;
+    for (int r = 0; r < ROUNDS_PARTIAL; r++)
+        for (int i = 0; i < CELLS; i++) k.pr_stream[n++] = (r == 0 && i > 0) ? bb::mul(k.diag[i], k.fix[0]) : k.diag[i];
+#endif
     while (n < PR_STREAM_WORDS) k.pr_stream[n++] = 0;
 }
 
@@ -326,6 +345,7 @@ static RK_HD void full_round(uint32_t* s, const Consts& k, int r) {
 // 16 are fetched with s_load_dwordx16 one chunk ahead of their use (the compiler's own scheduling
 // of ~2400 scalar loads spills SGPRs), and the wait is attached to the chunk's registers so that
 // no use can move above it.  Positions are consumed strictly in order.
+#if defined(RK_P2_CLOSED_FORM)
 static RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
     constexpr int NV = CELLS - 1;
     uint32_t vlo[NV], vhi[NV], slo[ROUNDS_PARTIAL], shi[ROUNDS_PARTIAL];
@@ -381,6 +401,56 @@ static RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
     });
     ks.drain();
 }
+
+#else
+// The partial rounds, one at a time, at three instructions per cell per round.  With S the sum of
+// the cells (after the S-box on cell 0) the layer is y_i = d_i x_i + S.  In Montgomery form
+// (everything times 2^32) and with SM2 = S * 2^32 (mod p) as a plain 32-bit addend,
+//     y_i = REDC(d_i * x_i + SM2) = (d_i x_i + S 2^32) / 2^32
+// is one v_mad_u64_u32 whose 64-bit addend is SM2 zero-extended, plus the two instructions of the
+// REDC: the addition of S rides inside the reduction, and no canonicalisation is needed because
+// the product tolerates any 32-bit x (d_i * x + SM2 + q p < 2^64 for x, SM2 < 2^32 - p).  Per round:
+// 17 for the S-box chain of cell 0, 6 to turn the 64-bit sum into SM2 (REDC, then a product by
+// 2^96), 3 x CELLS for the cells and CELLS - 1 to accumulate the next sum: 118 at width 24 against
+// ~144 for the closed form this replaces (all rounds as dot products with constant vectors:
+// ~3.0 k instructions for 21 rounds, kept behind RK_P2_CLOSED_FORM).
+// Entry: any 32-bit representatives scaled by the first block (see permute()); exit: Montgomery
+// form, canonical.
+static RK_HD void partial_rounds(uint32_t* s, const Consts& k) {
+    KStream ks(k.pr_stream);
+    // cell 0 feeds an S-box: its true (Montgomery) value, one product by fix[0]
+    uint32_t x0 = bb::ucanon(bb::umul_const(s[0], k.fix[0], k.fix0_nq));
+    // sum of the other cells: their representatives add up in 64 bits; REDC and one product by
+    // fix[0] * 2^32 give the sum in Montgomery form (< 2p)
+    uint64_t sig = 0;
+#pragma unroll
+    for (int i = 1; i < CELLS; i++) sig = bb::acc_u32(sig, s[i]);
+    sig = bb::umul_const(bb::uredc64(sig), k.sig0_c, k.sig0_nq);
+    static_for<0, ROUNDS_PARTIAL>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int R = decltype(rc)::value;
+        constexpr int BASE = R * CELLS;
+        const uint32_t y0 = bb::canon(sbox7_lazy(x0, k.rc_int_mp[R]));
+        const uint64_t S = bb::acc_u32(sig, y0);                                       // < 2^38
+        const uint32_t sm2 = bb::umul_const(bb::uredc64(S), k.r3_c, k.r3_nq);          // S * 2^32 mod p, < 2p
+        uint64_t t0 = sm2;
+        pr_fma<BASE>(ks, t0, y0);
+        x0 = bb::ucanon(bb::uredc64(t0));
+        uint64_t nsig = 0;
+        static_for<1, CELLS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            uint64_t t = sm2;
+            pr_fma<BASE + I>(ks, t, s[I]);
+            s[I] = bb::uredc64(t);  // <= 2p
+            nsig = bb::acc_u32(nsig, s[I]);
+        });
+        sig = nsig;
+    });
+    s[0] = x0;
+#pragma unroll
+    for (int i = 1; i < CELLS; i++) s[i] = bb::ucanon(s[i]);
+    ks.drain();
+}
+#endif
 
 static RK_HD void permute(uint32_t* s, const Consts& k) {
     m_ext_redc(s);  // canonical Montgomery input -> plain residues (scale 2^0), cells in [0, p + 53)

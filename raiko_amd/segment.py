@@ -158,9 +158,10 @@ def algorithmic_bytes(po2: int, widths: Sequence[int]) -> dict:
 
 
 # VALU instructions of one Poseidon2 permutation as shipped (tools/census_p2.py on the gfx950 ISA of
-# poseidon2_core.hpp: 7159 dynamic v_* instructions with all 24 output cells live; kernels that keep
-# only the digest / capacity cells run slightly fewer)
-P2_VALU_PER_PERMUTATION = 7159
+# poseidon2_core.hpp: 6737 dynamic v_* instructions with all 24 output cells live -- 7159 with the
+# closed-form partial rounds of round 1; kernels that keep only the digest / capacity cells run
+# slightly fewer)
+P2_VALU_PER_PERMUTATION = 6737
 
 
 def poseidon2_permutations(po2: int, widths: Sequence[int]) -> dict:

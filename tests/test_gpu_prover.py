@@ -287,7 +287,11 @@ def test_execute_segment_and_prove_an_elf(hal):
         [("addi", "a0", "t1", 0), ("addi", "a1", "zero", 4), ("ecall",), ("addi", "a0", "zero", 0)] + A.li("t0", 0) + [("ecall",)]
     image = A.elf(A.assemble(prog)[0])
     ex, receipt = X.execute_and_prove(image, segment_limit_po2=13, widths=(4, 4, 12), inflight=2)
-    assert len(ex.segments) == 4 and ex.total_cycles == 5 * 5000 + 13
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import or_rv32
+    ref = or_rv32.run(image, [], segment_limit_po2=13)
+    assert len(ex.segments) == 4 and ex.total_cycles == ref["total_cycles"] and ex.journal == ref["journal"]
     fib = [0, 1]
     for _ in range(5000):
         fib = [fib[1], (fib[0] + fib[1]) & 0xFFFFFFFF]
