@@ -185,6 +185,7 @@ typedef struct {
     const uint32_t* mix;           /* host: the n_accum_mix elements drawn before the accum commit */
     uint32_t n_mix;
 } rk_circuit_view;
+typedef struct rk_program rk_program;   /* a circuit's constraint polynomial as data, see below */
 typedef struct {
     void* user;
     /* CircuitHal::accumulate: write the accum group, column-major 2^po2 x group_size[0], to d_accum */
@@ -192,7 +193,62 @@ typedef struct {
     /* CircuitHal::eval_check: write 4 x 4*2^po2 values (component e of point i at e*4*2^po2 + i):
      * sum_k poly_mix^k * constraint_k at x_i = 3*w^i, divided by (x_i^(2^po2) - 1) */
     int (*eval_check)(void* user, const rk_circuit_view* view, const uint32_t poly_mix[4], uint32_t* d_check);
+    /* used when eval_check is NULL: the library evaluates the step program on the GPU
+     * (rk_program_eval_check) -- no circuit-specific kernel needed */
+    const rk_program* program;
 } rk_circuit_hooks;
+
+/* ---- the constraint polynomial as data: risc0-zkp 1.0.1 adapter.rs `PolyExtStepDef` ----
+ * risc0 ships every circuit's mixed constraint polynomial as a list of steps over two growing
+ * value lists (RECALLED from the crate; it is outside the reference tree): field values
+ * (CONST / GET / GET_GLOBAL / ADD / SUB / MUL push one) and mix states {tot, mul} (TRUE /
+ * AND_EQZ / AND_COND push one); operands are positions in the list of their kind:
+ *   CONST a            value a (a canonical integer)
+ *   GET a              tap a: eval_u[a] (rk_poly_ext_fn's order: registers by (group, offset), backs in combo order)
+ *   GET_GLOBAL a b     args[a][b]: a = 0 the segment's globals, a = 1 the accum mix
+ *   ADD|SUB|MUL a b    field values a, b
+ *   TRUE               {tot 0, mul 1}
+ *   AND_EQZ a b        x = mix state a, v = field value b:   {x.tot + x.mul * v,  x.mul * poly_mix}
+ *   AND_COND a b c     x = mix state a, cond = field value b, inner = mix state c:
+ *                      {x.tot + cond * inner.tot * x.mul,  x.mul * inner.mul}
+ * and `ret` names the mix state whose tot is the result.  The verifier interprets the list on the
+ * tap openings (CircuitDef::poly_ext); risc0's eval_check kernels are the same list turned into
+ * straight-line code by its build.  Here the list is an operand: rk_program_create validates it,
+ * drops dead steps, folds every `mul` into a compile-time power of poly_mix, assigns the live
+ * intermediate values to reusable slots, and the result serves both sides --
+ * rk_program_eval_check runs it for all 4 * 2^po2 points of the LDE domain on the GPU (one point per
+ * lane, slots in LDS, the step list read through the scalar cache), rk_program_poly_ext runs it on
+ * extension elements on the host.  tools/circuit_gen.py turns the same list into straight-line HIP
+ * (what risc0's build does) when the interpreter's per-step overhead matters. */
+typedef enum {
+    RK_STEP_CONST = 0, RK_STEP_GET = 1, RK_STEP_GET_GLOBAL = 2, RK_STEP_ADD = 3, RK_STEP_SUB = 4, RK_STEP_MUL = 5,
+    RK_STEP_TRUE = 6, RK_STEP_AND_EQZ = 7, RK_STEP_AND_COND = 8
+} rk_step_op;
+typedef struct { uint32_t op, a, b, c; } rk_poly_step;
+typedef struct {
+    uint64_t n_steps;          /* as given */
+    uint64_t n_ops;            /* arithmetic steps left after dead-code elimination (what a point costs) */
+    uint32_t n_fp_slots;       /* slots the live field values need at the same time */
+    uint32_t n_mix_slots;      /* ... and the live mix states (4 words each) */
+    uint32_t n_consts;         /* distinct constants */
+    uint32_t n_mix_powers;     /* distinct powers of poly_mix */
+    uint32_t max_power;        /* the highest of them = number of constraints on the longest path */
+    uint32_t n_taps;           /* taps of the tap set it was created against */
+} rk_program_info;
+/* taps: the tap set the GET indices refer to (copied).  RK_ERR_INVALID for an operand that names a
+ * value not yet pushed, a tap / argument list that does not exist, or an unknown op. */
+int rk_program_create(const rk_poly_step* steps, size_t n_steps, uint32_t ret, const rk_taps* taps, rk_program** out);
+int rk_program_destroy(rk_program* prog);
+int rk_program_get_info(const rk_program* prog, rk_program_info* out);
+/* CircuitHal::eval_check from the program, on view->ctx / view->stream (what the prover calls for
+ * hooks with `program` set; a hook of the caller's may call it too) */
+int rk_program_eval_check(const rk_program* prog, const rk_circuit_view* view, const uint32_t poly_mix[4],
+                          uint32_t* d_check);
+/* CircuitDef::poly_ext from the program (host): the value rk_poly_ext_fn returns.  ext_w: canonical W
+ * of the extension (rk_params.ext_w; 0 = risc0's) */
+int rk_program_poly_ext(const rk_program* prog, uint32_t ext_w, const uint32_t poly_mix[4], const uint32_t* eval_u_ext,
+                        size_t n_taps, const uint32_t* globals, uint32_t n_globals, const uint32_t* mix, uint32_t n_mix,
+                        uint32_t out_ext[4]);
 
 typedef struct {
     uint32_t po2;                  /* segment has 2^po2 rows */
@@ -226,7 +282,7 @@ int rk_verify_segment(const rk_segment* pub, const uint32_t* seal, size_t seal_w
  * CircuitDef::poly_ext -- the circuit's mixed constraint polynomial on the tap openings; when
  * given, the verifier also checks the constraint identity
  *     poly_ext(poly_mix, eval_u, globals, mix) == check(z) * ((3z)^(2^po2) - 1)
- * (reason code 70 on mismatch).  eval_u holds one extension element per tap, registers in
+ * (reason code 70 on mismatch; the same with `program` in place of the callback).  eval_u holds one extension element per tap, registers in
  * (group, offset) order, each register's backs in combo order: the value of the register's
  * polynomial at 3*z*w^-back. */
 typedef int (*rk_poly_ext_fn)(void* user, const rk_segment* pub, const uint32_t poly_mix[4], const uint32_t* eval_u_ext,
@@ -237,6 +293,7 @@ typedef struct {
     const uint32_t* p2_diag;       /* 24 */
     rk_poly_ext_fn poly_ext;
     void* user;
+    const rk_program* program;     /* used when poly_ext is NULL: the constraint identity from the step program */
     const rk_params* params;       /* optional: the parameter blob the seal was produced under (field, Poseidon2
                                     * instance incl. width 16, queries); overrides the three p2_* pointers */
 } rk_verify_opts;

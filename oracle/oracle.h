@@ -180,6 +180,14 @@ int or_verify_segment_circuit(const or_segment* pub_only, const uint32_t* seal, 
 const or_circuit_hooks* or_toy_hooks(void);
 int or_toy_poly_ext(void* user, const or_segment* pub, const fp* poly_mix, const fp4* eval_u, size_t n_taps,
                     const fp* mix, uint32_t n_mix, fp* out);
+/* ---- the constraint polynomial as a step list (oracle/or_program.c): literal interpretation of
+ * risc0-zkp adapter.rs PolyExtStepDef, the checker of raiko_amd/csrc/circuit_program.hip ---- */
+typedef struct { uint32_t op, a, b, c; } or_step;
+typedef struct { const or_step* steps; size_t n_steps; uint32_t ret; const or_taps* taps; } or_program;
+/* or_circuit_hooks.eval_check / or_poly_ext_fn with user = an or_program */
+int or_program_eval_check(void* user, const or_circuit_view* v, const fp* poly_mix, fp* check);
+int or_program_poly_ext(void* user, const or_segment* pub, const fp* poly_mix, const fp4* eval_u, size_t n_taps,
+                        const fp* mix, uint32_t n_mix, fp* out);
 void or_free(void* p);
 int or_max_threads(void);
 void or_set_threads(int n);

@@ -31,6 +31,17 @@ pub type rk_preset = c_int;
 pub const RK_PRESET_RISC0: rk_preset = 0;
 pub const RK_PRESET_SP1: rk_preset = 1;
 
+pub type rk_step_op = c_int;
+pub const RK_STEP_CONST: rk_step_op = 0;
+pub const RK_STEP_GET: rk_step_op = 1;
+pub const RK_STEP_GET_GLOBAL: rk_step_op = 2;
+pub const RK_STEP_ADD: rk_step_op = 3;
+pub const RK_STEP_SUB: rk_step_op = 4;
+pub const RK_STEP_MUL: rk_step_op = 5;
+pub const RK_STEP_TRUE: rk_step_op = 6;
+pub const RK_STEP_AND_EQZ: rk_step_op = 7;
+pub const RK_STEP_AND_COND: rk_step_op = 8;
+
 pub type rk_kclass = c_int;
 pub const RK_KCLASS_HASH_ROWS: rk_kclass = 0;
 pub const RK_KCLASS_HASH_FOLD: rk_kclass = 1;
@@ -48,6 +59,11 @@ pub struct rk_ctx {
 
 #[repr(C)]
 pub struct rk_exec {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct rk_program {
     _private: [u8; 0],
 }
 
@@ -106,6 +122,29 @@ pub struct rk_circuit_hooks {
     pub user: *mut c_void,
     pub accumulate: Option<unsafe extern "C" fn(user: *mut c_void, view: *const rk_circuit_view, d_accum: *mut u32) -> c_int>,
     pub eval_check: Option<unsafe extern "C" fn(user: *mut c_void, view: *const rk_circuit_view, poly_mix: *const u32, d_check: *mut u32) -> c_int>,
+    pub program: *const rk_program,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_poly_step {
+    pub op: u32,
+    pub a: u32,
+    pub b: u32,
+    pub c: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_program_info {
+    pub n_steps: u64,
+    pub n_ops: u64,
+    pub n_fp_slots: u32,
+    pub n_mix_slots: u32,
+    pub n_consts: u32,
+    pub n_mix_powers: u32,
+    pub max_power: u32,
+    pub n_taps: u32,
 }
 
 #[repr(C)]
@@ -132,6 +171,7 @@ pub struct rk_verify_opts {
     pub p2_diag: *const u32,
     pub poly_ext: Option<rk_poly_ext_fn>,
     pub user: *mut c_void,
+    pub program: *const rk_program,
     pub params: *const rk_params,
 }
 
@@ -237,6 +277,11 @@ extern "C" {
     pub fn rk_scatter(ctx: *mut rk_ctx, d_into: *mut u32, into_words: usize, h_index: *const u32, n_cycles: usize, h_offsets: *const u32, h_values: *const u32) -> c_int;
     pub fn rk_merkle_build(ctx: *mut rk_ctx, d_nodes: *mut u32, d_matrix: *const u32, rows: usize, cols: usize) -> c_int;
     pub fn rk_poly_divide(ctx: *mut rk_ctx, d_polys_ext: *mut u32, count: usize, z: *const u32, h_rem: *mut u32) -> c_int;
+    pub fn rk_program_create(steps: *const rk_poly_step, n_steps: usize, ret: u32, taps: *const rk_taps, out: *mut *mut rk_program) -> c_int;
+    pub fn rk_program_destroy(prog: *mut rk_program) -> c_int;
+    pub fn rk_program_get_info(prog: *const rk_program, out: *mut rk_program_info) -> c_int;
+    pub fn rk_program_eval_check(prog: *const rk_program, view: *const rk_circuit_view, poly_mix: *const u32, d_check: *mut u32) -> c_int;
+    pub fn rk_program_poly_ext(prog: *const rk_program, ext_w: u32, poly_mix: *const u32, eval_u_ext: *const u32, n_taps: usize, globals: *const u32, n_globals: u32, mix: *const u32, n_mix: u32, out_ext: *mut u32) -> c_int;
     pub fn rk_prove_segment(ctx: *mut rk_ctx, seg: *const rk_segment, h_seal: *mut u32, seal_capacity_words: usize, seal_words: *mut usize) -> c_int;
     pub fn rk_verify_segment(pub_: *const rk_segment, seal: *const u32, seal_words: usize) -> c_int;
     pub fn rk_verify_segment_ex(pub_: *const rk_segment, opts: *const rk_verify_opts, seal: *const u32, seal_words: usize) -> c_int;

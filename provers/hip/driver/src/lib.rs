@@ -190,6 +190,7 @@ fn prove_locally(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Re
         p2_diag: ptr::null(),
         poly_ext: Some(circuit::poly_ext_trampoline),
         user: ptr::null_mut(),
+        program: ptr::null(), // the callback above is risc0's own CircuitDef::poly_ext; a program would do as well
         params: ptr::null(), // risc0's parameter set is the library default
     };
     let opts = rk_session_opts {
@@ -354,6 +355,40 @@ mod circuit {
         t
     }
 
+    /// The circuit's constraint polynomial as an `rk_program`, created once per process.
+    /// RECALLED: risc0-circuit-rv32im 1.0.1 keeps the list as `poly_ext::DEF: PolyExtStepDef`
+    /// (`block: &[PolyExtStep]`, `ret`), which `impl PolyExt for CircuitImpl` interprets; the module
+    /// is private in the published crate, so this feature needs the one-line visibility patch
+    /// (`pub mod poly_ext;`) on a vendored copy.  Null when the feature is off or creation fails.
+    pub fn program() -> *const rk_program {
+        #[cfg(feature = "step-program")]
+        {
+            use risc0_zkp::adapter::PolyExtStep as S;
+            static PROGRAM: std::sync::OnceLock<usize> = std::sync::OnceLock::new();
+            return *PROGRAM.get_or_init(|| {
+                let def = &risc0_circuit_rv32im::poly_ext::DEF;
+                let st = |op: rk_step_op, a: usize, b: usize, c: usize| rk_poly_step { op: op as u32, a: a as u32, b: b as u32, c: c as u32 };
+                let steps: Vec<rk_poly_step> = def.block.iter().map(|s| match *s {
+                    S::Const(v) => st(RK_STEP_CONST, v as usize, 0, 0),
+                    S::Get(tap) => st(RK_STEP_GET, tap, 0, 0),
+                    S::GetGlobal(base, off) => st(RK_STEP_GET_GLOBAL, base, off, 0),
+                    S::Add(a, b) => st(RK_STEP_ADD, a, b, 0),
+                    S::Sub(a, b) => st(RK_STEP_SUB, a, b, 0),
+                    S::Mul(a, b) => st(RK_STEP_MUL, a, b, 0),
+                    S::True => st(RK_STEP_TRUE, 0, 0, 0),
+                    S::AndEqz(x, v) => st(RK_STEP_AND_EQZ, x, v, 0),
+                    S::AndCond(x, cond, inner) => st(RK_STEP_AND_COND, x, cond, inner),
+                }).collect();
+                let taps = tapset();
+                let mut prog: *mut rk_program = ptr::null_mut();
+                let rc = unsafe { rk_program_create(steps.as_ptr(), steps.len(), def.ret as u32, &taps.as_rk_taps(), &mut prog) };
+                if rc == RK_OK { prog as usize } else { 0 }
+            }) as *const rk_program;
+        }
+        #[cfg(not(feature = "step-program"))]
+        ptr::null()
+    }
+
     /// Witness generation: what `SegmentProverImpl::prove_segment` does before its first commit.
     pub fn witness(segment: &Segment) -> Result<Witness, String> {
         let trace = PreflightTrace::new(segment).map_err(|e| e.to_string())?;
@@ -362,7 +397,15 @@ mod circuit {
                                            &CpuCircuitHal::new(), segment.po2, &io, trace);
         let steps = 1usize << segment.po2;
         let mut hook = Box::new(CircuitHook {
-            hooks: rk_circuit_hooks { user: ptr::null_mut(), accumulate: Some(accumulate), eval_check: Some(eval_check) },
+            // eval_check: with the step list (feature `step-program`) the library evaluates the
+            // constraint polynomial on the GPU from the LDE it already holds -- no download, no
+            // circuit-specific kernel; otherwise risc0's CPU evaluator on host copies
+            hooks: rk_circuit_hooks {
+                user: ptr::null_mut(),
+                accumulate: Some(accumulate),
+                eval_check: if program().is_null() { Some(eval_check) } else { None },
+                program: program(),
+            },
             steps,
         });
         hook.hooks.user = &mut *hook as *mut CircuitHook as *mut c_void;
@@ -481,7 +524,7 @@ mod test {
     /// The reference's own smoke test shape (provers/risc0/driver/src/lib.rs:131-137): prove, then verify.
     #[test]
     fn abi_matches_and_a_gpu_is_visible() {
-        assert_eq!(unsafe { rk_abi_version() }, 2);
+        assert_eq!(unsafe { rk_abi_version() }, 3);
         let mut n = 0;
         assert_eq!(unsafe { rk_device_count(&mut n) }, RK_OK);
         assert!(n > 0, "no MI355X visible: the hip backend has no CPU fallback");

@@ -73,7 +73,8 @@ POLY_EXT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(RkSegment), u32p, u32p,
 
 
 class RkCircuitHooks(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("accumulate", ACCUMULATE_FN), ("eval_check", EVAL_CHECK_FN)]
+    _fields_ = [("user", C.c_void_p), ("accumulate", ACCUMULATE_FN), ("eval_check", EVAL_CHECK_FN),
+                ("program", C.c_void_p)]
 
 
 class RkParams(C.Structure):
@@ -89,7 +90,7 @@ RK_PRESET_RISC0, RK_PRESET_SP1 = 0, 1
 
 class RkVerifyOpts(C.Structure):
     _fields_ = [("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p), ("poly_ext", POLY_EXT_FN),
-                ("user", C.c_void_p), ("params", C.POINTER(RkParams))]
+                ("user", C.c_void_p), ("program", C.c_void_p), ("params", C.POINTER(RkParams))]
 
 
 class RkSessionOpts(C.Structure):
@@ -184,6 +185,11 @@ SYMBOLS = {
     "rk_exec_journal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rk_exec_error": (C.c_char_p, [C.c_void_p]),
     "rk_exec_free": (C.c_int, [C.c_void_p]),
+    "rk_program_create": (C.c_int, [_vp, _sz, _u32, C.POINTER(RkTaps), C.POINTER(_vp)]),
+    "rk_program_destroy": (C.c_int, [_vp]),
+    "rk_program_get_info": (C.c_int, [_vp, _vp]),
+    "rk_program_eval_check": (C.c_int, [_vp, C.POINTER(RkCircuitView), u32p, _vp]),
+    "rk_program_poly_ext": (C.c_int, [_vp, _u32, u32p, u32p, _sz, u32p, _u32, u32p, _u32, u32p]),
     "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
     "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),
 }

@@ -1,0 +1,636 @@
+// The constraint polynomial as data (include/raiko_hip.h, rk_program): compiler, GPU evaluator
+// and host evaluator for risc0-zkp 1.0.1's `PolyExtStepDef` step lists (adapter.rs; RECALLED -- the
+// crate is outside the reference tree, the call that reaches it is `session.prove()` at reference
+// provers/risc0/driver/src/bonsai.rs:271 -> CircuitHal::eval_check, and `receipt.verify()` at
+// provers/risc0/driver/src/lib.rs:136 -> CircuitDef::poly_ext).
+//
+// Compile (host, once per circuit):
+//   * validate operands, mark what `ret` depends on, drop the rest;
+//   * every mix state's `mul` is a power of poly_mix that does not depend on the data
+//     (TRUE: 0, AND_EQZ: +1, AND_COND: k(x) + k(inner)), so only `tot` is computed per point and
+//     the powers become one small table per proof;
+//   * CONST / GET / GET_GLOBAL are operands, not steps: a tap is re-read from the LDE where it is
+//     used (L2 / L1 hits) instead of occupying a slot for the rest of the program;
+//   * live ADD / SUB / MUL results and mix tots get slots by a linear scan over last uses, lowest
+//     free number first, so the busiest slots are the low ones.
+// Evaluate (GPU): one LDE point per lane, 256 lanes per workgroup, no synchronisation at all (a
+// lane only touches its own column of the slot array).  Slots below the LDS budget live in LDS as
+// [slot][lane] (consecutive lanes, consecutive banks), the rest in a global scratch matrix
+// [slot][point].  The op list, constants and powers are wave-uniform and come through the scalar
+// cache; every branch on an opcode or operand kind is a scalar branch.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+
+#include "internal.hpp"
+
+namespace {
+
+using bb::Ext;
+
+constexpr uint32_t NONE = 0xffffffffu;
+// operand = kind << 29 | index
+enum : uint32_t { K_SLOT = 0, K_TAP = 1, K_CONST = 2, K_GLOBAL = 3, K_MIX = 4 };
+constexpr uint32_t IDX_MASK = (1u << 29) - 1;
+inline uint32_t operand(uint32_t kind, uint32_t idx) { return (kind << 29) | idx; }
+// op.x = opcode | dst << 8
+enum : uint32_t { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_EQZ = 3, OP_COND = 4 };
+constexpr uint32_t MAX_SLOTS = 1u << 24, MAX_MIX_SLOTS = 1u << 12, MAX_POWERS = 1u << 20;
+
+constexpr int WG = 256;
+constexpr uint32_t LDS_WORDS_PER_LANE = 60;  // 60 KB per workgroup at most: two workgroups per CU
+constexpr uint32_t LDS_MIX_SLOTS = 6;
+
+struct Tap {
+    uint32_t group, offset, back;
+};
+
+}  // namespace
+
+struct rk_program {
+    std::vector<rk_poly_step> steps;
+    uint32_t ret = 0;
+    std::vector<Tap> taps;
+    uint32_t group_min[3] = {0, 0, 0};  // columns a view must have per group
+
+    std::vector<uint4> code;
+    std::vector<uint32_t> consts;   // Montgomery
+    std::vector<uint32_t> powers;   // distinct exponents of poly_mix, ascending
+    uint32_t n_fp_slots = 0, n_mix_slots = 0;
+    uint32_t ret_slot = NONE;       // NONE: the result is identically zero
+    uint32_t need_globals = 0, need_mix = 0;
+    rk_program_info info{};
+
+    std::mutex mu;
+    std::map<int, void*> d_code;    // per device
+};
+
+namespace {
+
+struct FpVar {
+    uint32_t op = 0, a = 0, b = 0;
+    uint32_t opnd = NONE;  // operand encoding once materialised (leaf kinds at once, slots when emitted)
+    bool live = false;
+    size_t last_use = 0;
+};
+struct MixVar {
+    uint32_t op = 0, x = 0, v = 0, inner = 0;
+    uint64_t k = 0;        // mul = poly_mix^k
+    bool zero = false;     // tot is identically zero
+    bool live = false;
+    size_t last_use = 0;
+    uint32_t slot = NONE;
+};
+
+int compile(rk_program* pg) {
+    const size_t n = pg->steps.size();
+    std::vector<FpVar> fp;
+    std::vector<MixVar> mx;
+    std::vector<std::pair<bool, uint32_t>> where(n);  // step -> (is_mix, index in its list)
+    fp.reserve(n);
+    std::map<uint32_t, uint32_t> const_idx;
+    auto intern_const = [&](uint32_t canon) {
+        uint32_t m = bb::encode(canon);
+        auto it = const_idx.find(m);
+        if (it != const_idx.end()) return it->second;
+        uint32_t i = (uint32_t)pg->consts.size();
+        pg->consts.push_back(m);
+        const_idx[m] = i;
+        return i;
+    };
+    for (size_t s = 0; s < n; s++) {
+        const rk_poly_step& st = pg->steps[s];
+        switch (st.op) {
+            case RK_STEP_CONST:
+            case RK_STEP_GET:
+            case RK_STEP_GET_GLOBAL:
+            case RK_STEP_ADD:
+            case RK_STEP_SUB:
+            case RK_STEP_MUL: {
+                FpVar v;
+                v.op = st.op;
+                v.a = st.a;
+                v.b = st.b;
+                if (st.op == RK_STEP_GET) {
+                    if (st.a >= pg->taps.size()) return RK_ERR_INVALID;
+                } else if (st.op == RK_STEP_GET_GLOBAL) {
+                    if (st.a > 1 || st.b > IDX_MASK) return RK_ERR_INVALID;
+                } else if (st.op != RK_STEP_CONST) {
+                    if (st.a >= fp.size() || st.b >= fp.size()) return RK_ERR_INVALID;
+                }
+                where[s] = {false, (uint32_t)fp.size()};
+                fp.push_back(v);
+                break;
+            }
+            case RK_STEP_TRUE:
+            case RK_STEP_AND_EQZ:
+            case RK_STEP_AND_COND: {
+                MixVar m;
+                m.op = st.op;
+                if (st.op == RK_STEP_TRUE) {
+                    m.zero = true;
+                } else {
+                    if (st.a >= mx.size() || st.b >= fp.size()) return RK_ERR_INVALID;
+                    m.x = st.a;
+                    m.v = st.b;
+                    if (st.op == RK_STEP_AND_COND) {
+                        if (st.c >= mx.size()) return RK_ERR_INVALID;
+                        m.inner = st.c;
+                        m.k = mx[m.x].k + mx[m.inner].k;
+                        m.zero = mx[m.x].zero && mx[m.inner].zero;
+                    } else {
+                        m.k = mx[m.x].k + 1;
+                    }
+                    if (m.k >= ((uint64_t)1 << 32)) return RK_ERR_INVALID;
+                }
+                where[s] = {true, (uint32_t)mx.size()};
+                mx.push_back(m);
+                break;
+            }
+            default:
+                return RK_ERR_INVALID;
+        }
+    }
+    if (pg->ret >= mx.size()) return RK_ERR_INVALID;
+
+    // what the result depends on (operands always precede their users: one backward sweep)
+    mx[pg->ret].live = true;
+    for (size_t s = n; s-- > 0;) {
+        if (where[s].first) {
+            const MixVar& m = mx[where[s].second];
+            if (!m.live || m.op == RK_STEP_TRUE) continue;
+            mx[m.x].live = true;
+            if (m.op == RK_STEP_AND_EQZ) {
+                fp[m.v].live = true;
+            } else if (!mx[m.inner].zero) {  // cond * 0: neither cond nor inner is needed
+                mx[m.inner].live = true;
+                fp[m.v].live = true;
+            }
+        } else {
+            const FpVar& v = fp[where[s].second];
+            if (!v.live) continue;
+            if (v.op == RK_STEP_ADD || v.op == RK_STEP_SUB || v.op == RK_STEP_MUL) fp[v.a].live = fp[v.b].live = true;
+        }
+    }
+    // last uses, in step positions
+    for (size_t s = 0; s < n; s++) {
+        if (where[s].first) {
+            const MixVar& m = mx[where[s].second];
+            if (!m.live || m.op == RK_STEP_TRUE) continue;
+            mx[m.x].last_use = s;
+            if (m.op == RK_STEP_AND_EQZ || !mx[m.inner].zero) fp[m.v].last_use = s;
+            if (m.op == RK_STEP_AND_COND && !mx[m.inner].zero) mx[m.inner].last_use = s;
+        } else {
+            const FpVar& v = fp[where[s].second];
+            if (!v.live) continue;
+            if (v.op == RK_STEP_ADD || v.op == RK_STEP_SUB || v.op == RK_STEP_MUL) fp[v.a].last_use = fp[v.b].last_use = s;
+        }
+    }
+    mx[pg->ret].last_use = n;  // read after the last step
+
+    std::map<uint64_t, uint32_t> power_idx;
+    for (size_t s = 0; s < n; s++)
+        if (where[s].first) {
+            const MixVar& m = mx[where[s].second];
+            if (m.live && m.op != RK_STEP_TRUE && !m.zero) power_idx[mx[m.x].k] = 0;
+        }
+    if (power_idx.size() > MAX_POWERS) return RK_ERR_CAPACITY;
+    for (auto& kv : power_idx) {
+        kv.second = (uint32_t)pg->powers.size();
+        pg->powers.push_back((uint32_t)kv.first);
+    }
+
+    // slots: lowest free number first
+    struct Pool {
+        std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> free_list;
+        uint32_t next = 0;
+        uint32_t take() {
+            if (!free_list.empty()) {
+                uint32_t s = free_list.top();
+                free_list.pop();
+                return s;
+            }
+            return next++;
+        }
+        void give(uint32_t s) { free_list.push(s); }
+    } fp_pool, mx_pool;
+    auto fp_operand = [&](uint32_t i) { return fp[i].opnd; };
+    auto release_fp = [&](uint32_t i, size_t s) {
+        if (fp[i].last_use == s && (fp[i].opnd >> 29) == K_SLOT && fp[i].opnd != NONE) {
+            fp_pool.give(fp[i].opnd & IDX_MASK);
+            fp[i].last_use = (size_t)-1;  // an operand named twice by one step is released once
+        }
+    };
+    auto release_mx = [&](uint32_t i, size_t s) {
+        if (mx[i].last_use == s && mx[i].slot != NONE) {
+            mx_pool.give(mx[i].slot);
+            mx[i].last_use = (size_t)-1;
+        }
+    };
+    uint64_t n_ops = 0;
+    for (size_t s = 0; s < n; s++) {
+        if (!where[s].first) {
+            FpVar& v = fp[where[s].second];
+            if (!v.live) continue;
+            switch (v.op) {
+                case RK_STEP_CONST:
+                    v.opnd = operand(K_CONST, intern_const(v.a));
+                    break;
+                case RK_STEP_GET: {
+                    v.opnd = operand(K_TAP, v.a);
+                    const Tap& t = pg->taps[v.a];
+                    pg->group_min[t.group] = std::max(pg->group_min[t.group], t.offset + 1);
+                    break;
+                }
+                case RK_STEP_GET_GLOBAL:
+                    v.opnd = operand(v.a == 0 ? K_GLOBAL : K_MIX, v.b);
+                    if (v.a == 0) pg->need_globals = std::max(pg->need_globals, v.b + 1);
+                    else pg->need_mix = std::max(pg->need_mix, v.b + 1);
+                    break;
+                default: {
+                    uint32_t oa = fp_operand(v.a), ob = fp_operand(v.b);
+                    release_fp(v.a, s);
+                    release_fp(v.b, s);
+                    uint32_t dst = fp_pool.take();
+                    if (dst >= MAX_SLOTS) return RK_ERR_CAPACITY;
+                    v.opnd = operand(K_SLOT, dst);
+                    uint32_t oc = v.op == RK_STEP_ADD ? OP_ADD : v.op == RK_STEP_SUB ? OP_SUB : OP_MUL;
+                    pg->code.push_back(make_uint4(oc | (dst << 8), oa, ob, 0));
+                    n_ops++;
+                }
+            }
+        } else {
+            MixVar& m = mx[where[s].second];
+            if (!m.live || m.op == RK_STEP_TRUE || m.zero) continue;
+            const MixVar& x = mx[m.x];
+            uint32_t xs = x.zero ? NONE : x.slot;
+            const uint32_t pw = power_idx[x.k];
+            // AND_COND with an identically-zero inner state: x.tot + cond * 0 * x.mul, the state of x under
+            // a new name -- emitted as x.tot + power * 0 so that slot lifetimes stay one-to-one
+            const bool copy_x = m.op == RK_STEP_AND_COND && mx[m.inner].zero;
+            const uint32_t ov = copy_x ? operand(K_CONST, intern_const(0)) : fp_operand(m.v);
+            if (m.op == RK_STEP_AND_EQZ || copy_x) {
+                if (!copy_x) release_fp(m.v, s);
+                release_mx(m.x, s);
+                uint32_t dst = mx_pool.take();
+                if (dst >= MAX_MIX_SLOTS) return RK_ERR_CAPACITY;
+                m.slot = dst;
+                pg->code.push_back(make_uint4(OP_EQZ | (dst << 8), xs, ov, pw));
+            } else {
+                uint32_t is = mx[m.inner].slot;
+                release_fp(m.v, s);
+                release_mx(m.x, s);
+                release_mx(m.inner, s);
+                uint32_t dst = mx_pool.take();
+                if (dst >= MAX_MIX_SLOTS) return RK_ERR_CAPACITY;
+                m.slot = dst;
+                pg->code.push_back(make_uint4(OP_COND | (dst << 8), xs, ov, pw | (is << 20)));
+            }
+            n_ops++;
+        }
+    }
+    pg->n_fp_slots = fp_pool.next;
+    pg->n_mix_slots = mx_pool.next;
+    pg->ret_slot = mx[pg->ret].zero ? NONE : mx[pg->ret].slot;
+    pg->info.n_steps = n;
+    pg->info.n_ops = n_ops;
+    pg->info.n_fp_slots = pg->n_fp_slots;
+    pg->info.n_mix_slots = pg->n_mix_slots;
+    pg->info.n_consts = (uint32_t)pg->consts.size();
+    pg->info.n_mix_powers = (uint32_t)pg->powers.size();
+    pg->info.max_power = (uint32_t)mx[pg->ret].k;
+    pg->info.n_taps = (uint32_t)pg->taps.size();
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-uniform read-only tables: read through the scalar cache (address space 4 = constant: the
+// backend then always selects s_load, whatever it can prove about the kernel's own stores)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RK_CONST_AS __attribute__((address_space(4)))
+#else
+#define RK_CONST_AS
+#endif
+typedef const RK_CONST_AS uint4* const_u4;
+typedef const RK_CONST_AS uint32_t* const_u32;
+typedef const RK_CONST_AS uint64_t* const_u64;
+
+struct EvalArgs {
+    uint64_t code;       // uint4 per op
+    uint64_t consts;     // program constants | globals | accum mix
+    uint64_t powers;     // 4 words per distinct power of poly_mix
+    uint64_t tap_ptr;    // column base of every tap (u64)
+    uint64_t tap_shift;  // 4 * back (u32)
+    uint32_t* spill;
+    uint32_t* check;
+    size_t d;
+    uint32_t n_ops, glob_base, mix_base;
+    uint32_t lds_fp, lds_mix, n_fp_slots;
+    uint32_t ret_slot, wm;
+    uint32_t inv_den[4];
+};
+
+struct Lane {
+    const EvalArgs& a;
+    uint32_t* lds;
+    size_t i;
+    const_u32 consts;
+    const_u64 tap_ptr;
+    const_u32 tap_shift;
+    __device__ __forceinline__ uint32_t fetch(uint32_t opnd) const {
+        const uint32_t kind = opnd >> 29, idx = opnd & IDX_MASK;
+        switch (kind) {
+            case K_SLOT:
+                return idx < a.lds_fp ? lds[idx * WG] : a.spill[(size_t)(idx - a.lds_fp) * a.d + i];
+            case K_TAP: {
+                const uint32_t* col = reinterpret_cast<const uint32_t*>(tap_ptr[idx]);
+                return col[(i + a.d - tap_shift[idx]) & (a.d - 1)];
+            }
+            case K_CONST:
+                return consts[idx];
+            case K_GLOBAL:
+                return consts[a.glob_base + idx];
+            default:
+                return consts[a.mix_base + idx];
+        }
+    }
+    __device__ __forceinline__ void store(uint32_t slot, uint32_t v) const {
+        if (slot < a.lds_fp) lds[slot * WG] = v;
+        else a.spill[(size_t)(slot - a.lds_fp) * a.d + i] = v;
+    }
+    __device__ __forceinline__ Ext load_mix(uint32_t slot) const {
+        Ext r;
+        if (slot < a.lds_mix) {
+            const uint32_t* p = lds + (size_t)(a.lds_fp + 4 * slot) * WG;
+#pragma unroll
+            for (int e = 0; e < 4; e++) r.c[e] = p[e * WG];
+        } else {
+            const uint32_t* p = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+#pragma unroll
+            for (int e = 0; e < 4; e++) r.c[e] = p[(size_t)e * a.d];
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store_mix(uint32_t slot, const Ext& v) const {
+        if (slot < a.lds_mix) {
+            uint32_t* p = lds + (size_t)(a.lds_fp + 4 * slot) * WG;
+#pragma unroll
+            for (int e = 0; e < 4; e++) p[e * WG] = v.c[e];
+        } else {
+            uint32_t* p = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+#pragma unroll
+            for (int e = 0; e < 4; e++) p[(size_t)e * a.d] = v.c[e];
+        }
+    }
+};
+
+__global__ __launch_bounds__(WG) void program_kernel(EvalArgs a) {
+    extern __shared__ uint32_t lds_all[];
+    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= a.d) return;  // no barrier anywhere below
+    Lane ln{a, lds_all + threadIdx.x, i, (const_u32)a.consts, (const_u64)a.tap_ptr, (const_u32)a.tap_shift};
+    const const_u4 code = (const_u4)a.code;
+    const const_u32 powers = (const_u32)a.powers;
+    for (uint32_t pc = 0; pc < a.n_ops; pc++) {
+        const uint4 op = code[pc];
+        const uint32_t oc = op.x & 0xffu, dst = op.x >> 8;
+        if (oc <= OP_MUL) {
+            const uint32_t x = ln.fetch(op.y), y = ln.fetch(op.z);
+            const uint32_t r = oc == OP_ADD ? bb::add(x, y) : oc == OP_SUB ? bb::sub(x, y) : bb::mul(x, y);
+            ln.store(dst, r);
+        } else {
+            const const_u32 pw = powers + (size_t)(op.w & 0xfffffu) * 4;
+            Ext t = bb::scale(Ext{{pw[0], pw[1], pw[2], pw[3]}}, ln.fetch(op.z));
+            if (oc == OP_COND) t = bb::mul(t, ln.load_mix(op.w >> 20), a.wm);
+            if (op.y != NONE) t = bb::add(t, ln.load_mix(op.y));
+            ln.store_mix(dst, t);
+        }
+    }
+    Ext tot = a.ret_slot == NONE ? bb::ext_zero() : bb::scale(ln.load_mix(a.ret_slot), a.inv_den[i & 3]);
+#pragma unroll
+    for (int e = 0; e < 4; e++) a.check[(size_t)e * a.d + i] = tot.c[e];
+}
+
+int device_code(rk_program* pg, rk_ctx* ctx, const uint4** out) {
+    std::lock_guard<std::mutex> lk(pg->mu);
+    auto it = pg->d_code.find(ctx->device);
+    if (it == pg->d_code.end()) {
+        void* d = nullptr;
+        size_t bytes = std::max<size_t>(pg->code.size(), 1) * sizeof(uint4);
+        RK_HIP_TRY(ctx, hipMalloc(&d, bytes));
+        hipError_t e = hipMemcpy(d, pg->code.data(), pg->code.size() * sizeof(uint4), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            ctx->last_error = std::string("program upload: ") + hipGetErrorString(e);
+            return RK_ERR_HIP;
+        }
+        it = pg->d_code.emplace(ctx->device, d).first;
+    }
+    *out = (const uint4*)it->second;
+    return RK_OK;
+}
+
+}  // namespace
+
+namespace rk {
+
+int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const uint32_t poly_mix[4], uint32_t* d_check) {
+    rk_program* pg = const_cast<rk_program*>(cprog);  // the device copy of the op list is cached inside
+    if (!pg || !v || !v->ctx || !poly_mix || !d_check) return RK_ERR_INVALID;
+    rk_ctx* ctx = v->ctx;
+    if (v->po2 < 1 || v->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
+    if (v->n_globals < pg->need_globals || v->n_mix < pg->need_mix) return RK_ERR_INVALID;
+    if ((v->n_globals && !v->globals) || (v->n_mix && !v->mix)) return RK_ERR_INVALID;
+    for (int g = 0; g < 3; g++)
+        if (pg->group_min[g] && (!v->d_lde[g] || v->group_size[g] < pg->group_min[g])) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << v->po2, d = 4 * n;
+    const uint32_t wm = ctx->sys.wm;
+
+    EvalArgs a{};
+    const uint4* d_ops = nullptr;
+    RK_TRY(device_code(pg, ctx, &d_ops));
+    a.code = (uint64_t)(uintptr_t)d_ops;
+    // per-proof tables in one upload: constants | globals | mix | powers | tap shifts | tap columns
+    const size_t nc = pg->consts.size(), ntap = pg->taps.size(), npw = pg->powers.size();
+    const size_t o_glob = nc, o_mix = o_glob + v->n_globals, o_pw = (o_mix + v->n_mix + 3) & ~(size_t)3;
+    const size_t o_shift = o_pw + 4 * npw, o_ptr = (o_shift + ntap + 1) & ~(size_t)1, words = o_ptr + 2 * ntap;
+    std::vector<uint32_t> pack(words + 2, 0);
+    std::memcpy(pack.data(), pg->consts.data(), nc * 4);
+    if (v->n_globals) std::memcpy(&pack[o_glob], v->globals, (size_t)v->n_globals * 4);
+    if (v->n_mix) std::memcpy(&pack[o_mix], v->mix, (size_t)v->n_mix * 4);
+    {
+        Ext pm, cur = bb::ext_one();
+        std::memcpy(pm.c, poly_mix, 16);
+        uint32_t at = 0;
+        for (size_t j = 0; j < npw; j++) {  // ascending exponents: one running power
+            cur = bb::mul(cur, bb::pow(pm, pg->powers[j] - at, wm), wm);
+            at = pg->powers[j];
+            std::memcpy(&pack[o_pw + 4 * j], cur.c, 16);
+        }
+    }
+    for (size_t t = 0; t < ntap; t++) {
+        const Tap& tp = pg->taps[t];
+        pack[o_shift + t] = (uint32_t)((4 * (size_t)tp.back) & (d - 1));
+        uint64_t p = 0;
+        if (tp.group < 3 && v->d_lde[tp.group] && tp.offset < v->group_size[tp.group])
+            p = (uint64_t)(uintptr_t)(v->d_lde[tp.group] + (size_t)tp.offset * d);
+        std::memcpy(&pack[o_ptr + 2 * t], &p, 8);
+    }
+    void* d_pack = nullptr;
+    RK_TRY(scratch(ctx, words * 4 + 16, &d_pack));
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d_pack, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack is a stack-lifetime host buffer
+    const uint32_t* dp = (const uint32_t*)d_pack;
+    a.consts = (uint64_t)(uintptr_t)dp;
+    a.glob_base = (uint32_t)o_glob;
+    a.mix_base = (uint32_t)o_mix;
+    a.powers = (uint64_t)(uintptr_t)(dp + o_pw);
+    a.tap_shift = (uint64_t)(uintptr_t)(dp + o_shift);
+    a.tap_ptr = (uint64_t)(uintptr_t)(dp + o_ptr);
+    a.check = d_check;
+    a.d = d;
+    a.n_ops = (uint32_t)pg->code.size();
+    a.lds_mix = std::min(pg->n_mix_slots, LDS_MIX_SLOTS);
+    a.lds_fp = std::min(pg->n_fp_slots, LDS_WORDS_PER_LANE - 4 * a.lds_mix);
+    a.n_fp_slots = pg->n_fp_slots;
+    a.ret_slot = pg->ret_slot;
+    a.wm = wm;
+    // x_i^N for x_i = shift * w_D^i takes four values: shift^N * w_4^(i mod 4)
+    const uint32_t sn = bb::pow(ctx->sys.shiftm, n), w4 = bb::pow(ctx->sys.root27m, (uint64_t)1 << 25);
+    for (int r = 0; r < 4; r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(w4, r)), bb::ONE));
+    const size_t spill_words = ((size_t)(pg->n_fp_slots - a.lds_fp) + 4 * (size_t)(pg->n_mix_slots - a.lds_mix)) * d;
+    void* d_spill = nullptr;
+    if (spill_words) RK_TRY(dev_alloc(ctx, spill_words * 4, &d_spill));
+    a.spill = (uint32_t*)d_spill;
+    const size_t lds_bytes = (size_t)(a.lds_fp + 4 * a.lds_mix) * WG * 4;
+    hipLaunchKernelGGL(program_kernel, dim3((unsigned)((d + WG - 1) / WG)), dim3(WG), lds_bytes, ctx->stream, a);
+    int rc = post_launch(ctx, "program_kernel");
+    if (d_spill) {
+        int fr = dev_free(ctx, d_spill);  // drains the stream first
+        if (rc == RK_OK) rc = fr;
+    }
+    return rc;
+}
+
+// CircuitDef::poly_ext: the step list as written, on extension elements (no compile products used
+// except the validated list itself, so this doubles as a check of the compiler)
+int program_poly_ext(const rk_program* pg, uint32_t wm, const uint32_t poly_mix[4], const uint32_t* eval_u_ext, size_t n_taps,
+                     const uint32_t* globals, uint32_t n_globals, const uint32_t* mix, uint32_t n_mix, uint32_t out_ext[4]) {
+    if (!pg || !poly_mix || !out_ext || (n_taps && !eval_u_ext)) return RK_ERR_INVALID;
+    if (n_taps != pg->taps.size() || n_globals < pg->need_globals || n_mix < pg->need_mix) return RK_ERR_INVALID;
+    const Ext* u = reinterpret_cast<const Ext*>(eval_u_ext);
+    Ext pm;
+    std::memcpy(pm.c, poly_mix, 16);
+    struct Mix {
+        Ext tot, mul;
+    };
+    std::vector<Ext> fp;
+    std::vector<Mix> mx;
+    fp.reserve(pg->steps.size());
+    for (const rk_poly_step& st : pg->steps) {
+        switch (st.op) {
+            case RK_STEP_CONST:
+                fp.push_back(bb::ext_from(bb::encode(st.a)));
+                break;
+            case RK_STEP_GET:
+                fp.push_back(u[st.a]);
+                break;
+            case RK_STEP_GET_GLOBAL: {
+                // an argument the result does not depend on may lie beyond what the caller has
+                uint32_t val = st.a == 0 ? (st.b < n_globals ? globals[st.b] : 0) : (st.b < n_mix ? mix[st.b] : 0);
+                fp.push_back(bb::ext_from(val));
+                break;
+            }
+            case RK_STEP_ADD:
+                fp.push_back(bb::add(fp[st.a], fp[st.b]));
+                break;
+            case RK_STEP_SUB:
+                fp.push_back(bb::sub(fp[st.a], fp[st.b]));
+                break;
+            case RK_STEP_MUL:
+                fp.push_back(bb::mul(fp[st.a], fp[st.b], wm));
+                break;
+            case RK_STEP_TRUE:
+                mx.push_back(Mix{bb::ext_zero(), bb::ext_one()});
+                break;
+            case RK_STEP_AND_EQZ: {
+                const Mix x = mx[st.a];
+                mx.push_back(Mix{bb::add(x.tot, bb::mul(x.mul, fp[st.b], wm)), bb::mul(x.mul, pm, wm)});
+                break;
+            }
+            case RK_STEP_AND_COND: {
+                const Mix x = mx[st.a], in = mx[st.c];
+                mx.push_back(Mix{bb::add(x.tot, bb::mul(bb::mul(fp[st.b], in.tot, wm), x.mul, wm)), bb::mul(x.mul, in.mul, wm)});
+                break;
+            }
+            default:
+                return RK_ERR_INVALID;
+        }
+    }
+    std::memcpy(out_ext, mx[pg->ret].tot.c, 16);
+    return RK_OK;
+}
+
+}  // namespace rk
+
+extern "C" {
+
+int rk_program_create(const rk_poly_step* steps, size_t n_steps, uint32_t ret, const rk_taps* taps, rk_program** out) {
+    RK_GUARD_BEGIN
+    if (!out) return RK_ERR_INVALID;
+    *out = nullptr;
+    if (!steps || n_steps == 0 || n_steps > ((size_t)1 << 28) || !taps) return RK_ERR_INVALID;
+    RK_TRY(rk::check_taps(*taps));
+    std::unique_ptr<rk_program> pg(new rk_program);
+    pg->steps.assign(steps, steps + n_steps);
+    pg->ret = ret;
+    for (uint32_t r = 0; r < taps->n_regs; r++) {
+        const uint32_t cb = taps->reg_combo[r];
+        for (uint32_t b = taps->combo_off[cb]; b < taps->combo_off[cb + 1]; b++)
+            pg->taps.push_back(Tap{taps->reg_group[r], taps->reg_offset[r], taps->combo_backs[b]});
+    }
+    if (pg->taps.size() > IDX_MASK) return RK_ERR_INVALID;
+    RK_TRY(compile(pg.get()));
+    *out = pg.release();
+    return RK_OK;
+    RK_GUARD_END
+}
+
+int rk_program_destroy(rk_program* pg) {
+    RK_GUARD_BEGIN
+    if (!pg) return RK_OK;
+    for (auto& kv : pg->d_code) {
+        if (hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second);
+    }
+    delete pg;
+    return RK_OK;
+    RK_GUARD_END
+}
+
+int rk_program_get_info(const rk_program* pg, rk_program_info* out) {
+    if (!pg || !out) return RK_ERR_INVALID;
+    *out = pg->info;
+    return RK_OK;
+}
+
+int rk_program_eval_check(const rk_program* pg, const rk_circuit_view* view, const uint32_t poly_mix[4], uint32_t* d_check) {
+    RK_GUARD_BEGIN
+    return rk::program_eval_check(pg, view, poly_mix, d_check);
+    RK_GUARD_END
+}
+
+int rk_program_poly_ext(const rk_program* pg, uint32_t ext_w, const uint32_t poly_mix[4], const uint32_t* eval_u_ext,
+                        size_t n_taps, const uint32_t* globals, uint32_t n_globals, const uint32_t* mix, uint32_t n_mix,
+                        uint32_t out_ext[4]) {
+    RK_GUARD_BEGIN
+    if (ext_w >= bb::P) return RK_ERR_INVALID;
+    return rk::program_poly_ext(pg, ext_w ? bb::encode(ext_w) : bb::WM_RISC0, poly_mix, eval_u_ext, n_taps, globals, n_globals,
+                                mix, n_mix, out_ext);
+    RK_GUARD_END
+}
+
+}  // extern "C"

@@ -129,7 +129,7 @@ static int upload_p2(rk_ctx* ctx) {
 
 extern "C" {
 
-int rk_abi_version(void) { return 2; }
+int rk_abi_version(void) { return 3; }
 
 const char* rk_strerror(int s) {
     switch (s) {

@@ -140,6 +140,10 @@ int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size
 int prefix_products(rk_ctx* ctx, uint32_t* d_io_ext, size_t count);
 int scatter(rk_ctx* ctx, uint32_t* d_into, size_t into_words, const uint32_t* h_index, size_t n_cycles,
             const uint32_t* h_offsets, const uint32_t* h_values);
+// circuit_program.hip: the step program behind rk_circuit_hooks.program / rk_verify_opts.program
+int program_eval_check(const rk_program* prog, const rk_circuit_view* view, const uint32_t poly_mix[4], uint32_t* d_check);
+int program_poly_ext(const rk_program* prog, uint32_t wm, const uint32_t poly_mix[4], const uint32_t* eval_u_ext, size_t n_taps,
+                     const uint32_t* globals, uint32_t n_globals, const uint32_t* mix, uint32_t n_mix, uint32_t out_ext[4]);
 // d_ext[idx[i]] -= delta[i]
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n);
 

@@ -224,7 +224,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     RK_TRY(rk::check_taps(taps));
     if (seg->po2 < 1 || seg->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
     const rk_circuit_hooks* hooks = seg->hooks;
-    const bool hook_accum = hooks && hooks->accumulate, hook_check = hooks && hooks->eval_check;
+    const bool hook_accum = hooks && hooks->accumulate, hook_check = hooks && (hooks->eval_check || hooks->program);
     for (int g = 0; g < 3; g++) {
         if (taps.group_size[g] == 0) return RK_ERR_INVALID;
         if (!seg->group[g] && !(g == 0 && hook_accum)) return RK_ERR_INVALID;
@@ -351,9 +351,14 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         RK_TRY(check.coeffs.alloc(ctx, 4 * D * 4));
         for (int g = 0; g < 3; g++) view.d_lde[g] = groups[g].evaluated.u32();
         sw.start();
-        if (hooks->eval_check(hooks->user, &view, poly_mix.c, check.coeffs.u32()) != 0) {
-            ctx->last_error = "circuit hook `eval_check` failed";
-            return RK_ERR_CALLBACK;
+        if (hooks->eval_check) {
+            if (hooks->eval_check(hooks->user, &view, poly_mix.c, check.coeffs.u32()) != 0) {
+                ctx->last_error = "circuit hook `eval_check` failed";
+                return RK_ERR_CALLBACK;
+            }
+        } else {
+            // the circuit's step program, evaluated by the library (circuit_program.hip)
+            RK_TRY(rk::program_eval_check(hooks->program, &view, poly_mix.c, check.coeffs.u32()));
         }
         sw.stop(&ctx->timing.circuit);
     } else {

@@ -139,7 +139,7 @@ struct Run {
 
 bool needs_staging(const rk_segment& s) { return s.on_device == 0; }
 bool hook_accum(const rk_segment& s) { return s.hooks && s.hooks->accumulate; }
-bool hook_check(const rk_segment& s) { return s.hooks && s.hooks->eval_check; }
+bool hook_check(const rk_segment& s) { return s.hooks && (s.hooks->eval_check || s.hooks->program); }
 
 // claims segments for one GPU and stages the host-resident ones
 void feeder(Run* run, size_t d) {

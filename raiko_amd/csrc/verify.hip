@@ -163,7 +163,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     k.hash_elems((const uint32_t*)coeff_u.data(), coeff_u.size() * 4, digest);
     rng.mix(digest);
     if (r.short_read) return 60;
-    if (opts && opts->poly_ext) {
+    if (opts && (opts->poly_ext || opts->program)) {
         // verify/mod.rs: U polynomials back to evaluation form, the circuit's mixed constraint
         // polynomial on them, against check(z) * ((3z)^N - 1) with check(z) = sum_i z^i * g_i(z^4),
         // g_i = the extension element whose component e is opened in check column 4e + remap[i]
@@ -179,9 +179,14 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
             pos += sz;
         }
         Ext result;
-        if (opts->poly_ext(opts->user, pub, poly_mix.c, (const uint32_t*)eval_u.data(), tot_taps, accum_mix.data(),
-                           pub->n_accum_mix, result.c) != 0)
+        if (opts->poly_ext) {
+            if (opts->poly_ext(opts->user, pub, poly_mix.c, (const uint32_t*)eval_u.data(), tot_taps, accum_mix.data(),
+                               pub->n_accum_mix, result.c) != 0)
+                return 71;
+        } else if (rk::program_poly_ext(opts->program, wm, poly_mix.c, (const uint32_t*)eval_u.data(), tot_taps, pub->globals,
+                                        pub->n_globals, accum_mix.data(), pub->n_accum_mix, result.c) != RK_OK) {
             return 71;
+        }
         static const int remap[4] = {0, 2, 1, 3};
         Ext check = bb::ext_zero(), zi = bb::ext_one();
         for (int i = 0; i < 4; i++) {

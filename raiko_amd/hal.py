@@ -234,7 +234,7 @@ class HipHal:
 
 
 def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: int = 2, verify: bool = True,
-                  device_inputs=None, devices: Optional[Sequence[int]] = None, poly_ext=None, poseidon2=None):
+                  device_inputs=None, devices: Optional[Sequence[int]] = None, poly_ext=None, poseidon2=None, program=None):
     """Seals of all `segments`, in order, through rk_prove_session: `inflight` proofs in flight on
     each GPU (`devices`: several GPUs of the node share one work queue of segments), host-resident
     traces staged `upload_ahead` segments ahead on a separate stream, every seal verified on a host
@@ -269,8 +269,8 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
         opts.devices = dev_arr
         opts.n_devices = len(devices)
         keep.append(dev_arr)
-    if poly_ext is not None or poseidon2 is not None:
-        vopts, vkeep = make_verify_opts(poly_ext, poseidon2)
+    if poly_ext is not None or poseidon2 is not None or program is not None:
+        vopts, vkeep = make_verify_opts(poly_ext, poseidon2, program=program)
         opts.verify_opts = C.pointer(vopts)
         keep.append((vopts, vkeep))
     failed = C.c_size_t(0)
@@ -323,7 +323,7 @@ def session_kernel_stats(device: int) -> dict:
     return out
 
 
-def make_verify_opts(poly_ext=None, poseidon2=None, params=None):
+def make_verify_opts(poly_ext=None, poseidon2=None, params=None, program=None):
     """rk_verify_opts: `poly_ext` = a _lib.POLY_EXT_FN (the circuit's constraint polynomial: the
     verifier then checks the constraint identity); `poseidon2` = (rc_ext[192], rc_int[21], diag[24])
     the seal was produced under (default: the compiled-in instance).  Returns (opts, keepalive)."""
@@ -338,13 +338,16 @@ def make_verify_opts(poly_ext=None, poseidon2=None, params=None):
     if poly_ext is not None:
         o.poly_ext = poly_ext
         keep.append(poly_ext)
+    if program is not None:  # a circuit_program.Program: the constraint identity from the step list
+        o.program = program.handle
+        keep.append(program)
     if params is not None:  # the whole blob the seal was produced under (overrides `poseidon2`)
         o.params = C.pointer(params)
         keep.append(params)
     return o, keep
 
 
-def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None, params=None) -> int:
+def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None, params=None, program=None) -> int:
     """Host-side check of a seal against the public data of `seg` (no GPU needed): 0 = valid,
     positive = reason code of the first failed check (raiko_amd/csrc/verify.hip)."""
     lib = _lib.load()
@@ -360,9 +363,9 @@ def verify_segment(seg: Segment, seal: np.ndarray, poly_ext=None, poseidon2=None
         c.proof_system_info[i] = seg.proof_system_info[i]
         c.circuit_info[i] = seg.circuit_info[i]
     s = np.ascontiguousarray(seal, dtype=np.uint32)
-    if poly_ext is None and poseidon2 is None and params is None:
+    if poly_ext is None and poseidon2 is None and params is None and program is None:
         return int(lib.rk_verify_segment(C.byref(c), _u32p(s), s.size))
-    opts, k2 = make_verify_opts(poly_ext, poseidon2, params)
+    opts, k2 = make_verify_opts(poly_ext, poseidon2, params, program)
     rc = int(lib.rk_verify_segment_ex(C.byref(c), C.byref(opts), _u32p(s), s.size))
     del k2
     return rc
@@ -383,9 +386,11 @@ def fill_c_taps(c_taps, taps: TapSet, keep: list):
 
 def hooks_address(seg: Segment) -> int:
     h = getattr(seg, "hooks", None)
-    if h is None:
-        return 0
-    return int(h() if callable(h) else h)
+    base = 0 if h is None else int(h() if callable(h) else h)
+    prog = getattr(seg, "program", None)
+    if prog is not None:  # eval_check from the step program, accumulate from `hooks`
+        return prog.hooks(base)
+    return base
 
 
 def make_c_segment(seg: Segment, device_inputs=None):

@@ -102,6 +102,8 @@ class Segment:
     # address of an rk_circuit_hooks (or a callable returning it): accum (groups[0]) and check are then
     # produced inside the proof by CircuitHal::accumulate / eval_check and may be None here
     hooks: object = None
+    # a circuit_program.Program: eval_check then comes from the step list (hooks keeps `accumulate`)
+    program: object = None
 
     @property
     def rows(self) -> int:

@@ -48,6 +48,14 @@ class OrSegment(C.Structure):
                 ("proof_system_info", C.c_uint8 * 16), ("circuit_info", C.c_uint8 * 16), ("hooks", C.c_void_p)]
 
 
+class OrCircuitHooks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("accumulate", C.c_void_p), ("eval_check", C.c_void_p)]
+
+
+class OrProgram(C.Structure):
+    _fields_ = [("steps", C.c_void_p), ("n_steps", C.c_size_t), ("ret", C.c_uint32), ("taps", C.POINTER(OrTaps))]
+
+
 class OrParams(C.Structure):
     _fields_ = [("ext_w", C.c_uint32), ("root_2_27", C.c_uint32), ("coset_shift", C.c_uint32),
                 ("p2_width", C.c_uint32), ("p2_m4", C.c_uint32), ("p2_pad_free", C.c_uint32),
@@ -109,6 +117,8 @@ def oracle():
             "or_verify_segment": (C.c_int, [C.POINTER(OrSegment), u32p, sz]),
             "or_verify_segment_circuit": (C.c_int, [C.POINTER(OrSegment), u32p, sz, vp, vp]),
             "or_toy_hooks": (vp, []),
+            "or_program_eval_check": (C.c_int, [vp, vp, vp, vp]),
+            "or_program_poly_ext": (C.c_int, [vp, vp, vp, vp, sz, vp, u32, vp]),
             "or_set_fast": (None, [C.c_int]), "or_get_fast": (C.c_int, []),
             "or_params_preset": (None, [C.POINTER(OrParams), C.c_int]), "or_set_params": (C.c_int, [C.POINTER(OrParams)]),
             "or_prefix_products": (None, [vp, sz]),
@@ -207,6 +217,13 @@ def make_or_segment(seg):
         c.check = chk.ctypes.data
     if getattr(seg, "hooks", None) is not None:  # the toy circuit is the only one: its CPU restatement
         c.hooks = oracle().or_toy_hooks()
+    if getattr(seg, "program", None) is not None:  # eval_check from the step list (oracle/or_program.c)
+        prog, hooks = or_program_of(seg.program, c.taps, keep)
+        toy = C.cast(C.c_void_p(oracle().or_toy_hooks()), C.POINTER(OrCircuitHooks)).contents
+        hooks.user = C.addressof(prog)
+        hooks.accumulate = toy.accumulate
+        hooks.eval_check = C.cast(oracle().or_program_eval_check, C.c_void_p).value
+        c.hooks = C.addressof(hooks)
     gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)
     keep.append(gl)
     c.globals = gl.ctypes.data_as(u32p)
@@ -216,6 +233,15 @@ def make_or_segment(seg):
         c.proof_system_info[i] = seg.proof_system_info[i]
         c.circuit_info[i] = seg.circuit_info[i]
     return c, keep
+
+
+def or_program_of(program, c_taps, keep):
+    """(OrProgram, OrCircuitHooks) for a raiko_amd.circuit_program.Program (its step array, as written)"""
+    steps = np.ascontiguousarray(program.steps, dtype=np.uint32)
+    prog = OrProgram(steps=steps.ctypes.data, n_steps=steps.shape[0], ret=program.ret, taps=C.pointer(c_taps))
+    hooks = OrCircuitHooks()
+    keep += [steps, prog, hooks]
+    return prog, hooks
 
 
 def oracle_prove(seg, threads=0, fast=False):
@@ -240,7 +266,11 @@ def oracle_verify(seg, seal, toy_identity=False) -> int:
     lib = oracle()
     c, keep = make_or_segment(seg)
     s = np.ascontiguousarray(seal, dtype=np.uint32)
-    if toy_identity:
+    if getattr(seg, "program", None) is not None and toy_identity:  # the identity from the step list
+        prog, _ = or_program_of(seg.program, c.taps, keep)
+        fn = C.cast(lib.or_program_poly_ext, C.c_void_p)
+        rc = lib.or_verify_segment_circuit(C.byref(c), s.ctypes.data_as(u32p), s.size, fn, C.addressof(prog))
+    elif toy_identity:
         fn = C.cast(lib.or_toy_poly_ext, C.c_void_p)
         rc = lib.or_verify_segment_circuit(C.byref(c), s.ctypes.data_as(u32p), s.size, fn, None)
     else:

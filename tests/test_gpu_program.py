@@ -1,0 +1,204 @@
+"""GPU parity of the step-program evaluator (rk_program; risc0-zkp adapter.rs PolyExtStepDef, RECALLED):
+CircuitHal::eval_check computed by the library from the circuit's constraint list -- the flow of
+`session.prove()` (reference provers/risc0/driver/src/bonsai.rs:271) without a circuit-specific
+kernel.  The GPU evaluation must equal the oracle's literal interpretation (oracle/or_program.c)
+word for word, for the toy circuit's list inside a whole proof and for random lists on random LDE
+data, including lists that keep more values alive than the LDS slot budget (spill to HBM)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from program_util import random_program
+from raiko_amd import _lib, circuit_program as cp, toy_circuit
+from raiko_amd.hal import prove_session, verify_segment
+from raiko_amd.segment import synthetic_tapset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy():
+    toy_circuit.load()
+    return toy_circuit
+
+
+def toy_with_program(toy, po2, widths=(8, 4, 8), **kw):
+    seg = toy.toy_segment(po2, widths, **kw)
+    steps, ret = cp.toy_program(seg.taps, seg.n_accum_mix)
+    seg.program = cp.Program(steps, ret, seg.taps)
+    return seg
+
+
+@pytest.mark.parametrize("po2,widths", [(4, (4, 3, 4)), (9, (8, 4, 8)), (12, (16, 16, 40)), (14, (5, 3, 21))])
+def test_toy_program_seal_bit_exact(hal, toy, po2, widths):
+    seg = toy_with_program(toy, po2, widths, seed=200 + po2)
+    want = o.oracle_prove(seg)
+    got = hal.prove_segment(seg)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert hal.last_timing()["circuit"] > 0
+    assert verify_segment(seg, got, program=seg.program) == 0
+    assert o.oracle_verify(seg, got, toy_identity=True) == 0
+
+
+def test_broken_witness_and_session(toy):
+    """one circuit, one program: every prover thread of the session evaluates it on its own context"""
+    segs = [toy.toy_segment(9 + (i % 3), (8, 4, 8), seed=60 + i) for i in range(5)]
+    prog = cp.Program(*cp.toy_program(segs[0].taps, segs[0].n_accum_mix), segs[0].taps)
+    for s in segs:
+        s.program = prog
+    seals = prove_session(segs, inflight=3, upload_ahead=2, verify=True, program=prog)
+    for seg, seal in zip(segs, seals):
+        assert np.array_equal(seal, o.oracle_prove(seg))
+    bad = toy_with_program(toy, 8, break_row=17)
+    seal = prove_session([bad], verify=False)[0]
+    assert verify_segment(bad, seal) == 0
+    assert verify_segment(bad, seal, program=bad.program) == 70
+    with pytest.raises(_lib.RkError) as ei:
+        prove_session([bad], program=bad.program)
+    assert ei.value.status == _lib.RK_ERR_VERIFY and ei.value.segment == 0
+
+
+def run_eval_check(hal, prog, po2, lde, globals_, mix, poly_mix):
+    """rk_program_eval_check on `lde` = three (cols, 4 << po2) arrays -> (4, 4 << po2)"""
+    lib = _lib.load()
+    d = 4 << po2
+    bufs = [hal.copy_from_elem(a) for a in lde]
+    out = hal.alloc_elem(4 * d)
+    gl = np.ascontiguousarray(globals_, dtype=np.uint32)
+    mx = np.ascontiguousarray(mix, dtype=np.uint32)
+    pm = np.ascontiguousarray(poly_mix, dtype=np.uint32)
+    v = _lib.RkCircuitView()
+    v.ctx = hal._ctx
+    v.po2 = po2
+    for g in range(3):
+        v.group_size[g] = lde[g].shape[0]
+        v.d_lde[g] = bufs[g].ptr
+    v.globals, v.n_globals = gl.ctypes.data_as(_lib.u32p), gl.size
+    v.mix, v.n_mix = mx.ctypes.data_as(_lib.u32p), mx.size
+    st = lib.rk_program_eval_check(prog.handle, C.byref(v), pm.ctypes.data_as(_lib.u32p), out.ptr)
+    _lib.check(hal._ctx, st)
+    return out.to_host().reshape(4, d)
+
+
+def oracle_eval_check(prog, taps, po2, lde, globals_, mix, poly_mix):
+    lib = o.oracle()
+    keep = []
+    c_taps = o.OrTaps()
+    for name in ("reg_group", "reg_offset", "reg_combo", "combo_off", "combo_backs"):
+        a = np.ascontiguousarray(getattr(taps, name), dtype=np.uint32)
+        keep.append(a)
+        setattr(c_taps, name, a.ctypes.data_as(o.u32p))
+    for g in range(3):
+        c_taps.group_size[g] = int(taps.group_size[g])
+    c_taps.n_regs, c_taps.n_combos = taps.n_regs, taps.n_combos
+    p, _ = o.or_program_of(prog, c_taps, keep)
+
+    class View(C.Structure):
+        _fields_ = [("po2", C.c_uint32), ("group_size", C.c_uint32 * 3), ("trace", C.c_void_p * 3), ("lde", C.c_void_p * 3),
+                    ("globals", C.c_void_p), ("n_globals", C.c_uint32), ("mix", C.c_void_p), ("n_mix", C.c_uint32)]
+    v = View()
+    v.po2 = po2
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in lde]
+    for g in range(3):
+        v.group_size[g] = arrs[g].shape[0]
+        v.lde[g] = arrs[g].ctypes.data
+    gl = np.ascontiguousarray(globals_, dtype=np.uint32)
+    mx = np.ascontiguousarray(mix, dtype=np.uint32)
+    pm = np.ascontiguousarray(poly_mix, dtype=np.uint32)
+    v.globals, v.n_globals, v.mix, v.n_mix = gl.ctypes.data, gl.size, mx.ctypes.data, mx.size
+    out = np.zeros((4, 4 << po2), dtype=np.uint32)
+    assert lib.or_program_eval_check(C.addressof(p), C.addressof(v), o.ptr(pm), o.ptr(out)) == 0
+    return out
+
+
+@pytest.mark.parametrize("seed,po2,n_live", [(0, 3, 0), (1, 6, 10), (2, 8, 70), (3, 10, 150), (4, 7, 300), (5, 11, 40)])
+def test_random_programs_match_the_literal_interpreter(hal, seed, po2, n_live):
+    rng = np.random.default_rng(1000 + seed)
+    taps = synthetic_tapset(int(rng.integers(4, 12)), int(rng.integers(3, 9)), int(rng.integers(4, 40)))
+    n_globals, n_mix = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    steps, ret = random_program(rng, taps, n_globals, n_mix, n_fp_ops=int(rng.integers(50, 600)), n_live=n_live,
+                                depth=3, n_constraints=40)
+    prog = cp.Program(steps, ret, taps)
+    info = prog.info()
+    if n_live >= 70:
+        assert info["n_fp_slots"] > 60          # more than the LDS budget: the spill path runs
+    d = 4 << po2
+    lde = [o.rand_elems(rng, (int(w), d)) for w in taps.group_size]
+    globals_, mix, pm = o.rand_elems(rng, (n_globals,)), o.rand_elems(rng, (n_mix,)), o.rand_elems(rng, (4,))
+    want = oracle_eval_check(prog, taps, po2, lde, globals_, mix, pm)
+    got = run_eval_check(hal, prog, po2, lde, globals_, mix, pm)
+    assert np.array_equal(got, want), info
+
+
+def test_deeply_nested_blocks_spill_mix_states(hal):
+    """AND_COND blocks nested deeper than the mix-state slots kept in LDS"""
+    rng = np.random.default_rng(77)
+    taps = synthetic_tapset(4, 3, 8)
+    b = cp.ProgramBuilder(taps)
+    vals = [b.get_tap(int(t)) for t in range(12)]
+
+    def nest(level):
+        x = b.and_eqz(b.true(), vals[level % 12])
+        if level < 10:
+            inner = nest(level + 1)
+            x = b.and_cond(x, vals[(level + 3) % 12], inner)
+        return b.and_eqz(x, vals[(level + 5) % 12])
+
+    # outer states stay alive while the inner ones are built: build inner first to stack them up
+    def stack(level):
+        if level == 10:
+            return b.and_eqz(b.true(), vals[0])
+        outer = b.and_eqz(b.true(), vals[level % 12])
+        inner = stack(level + 1)
+        return b.and_cond(outer, vals[(level + 1) % 12], inner)
+
+    ret = stack(0)
+    prog = cp.Program(b.array(), ret, taps)
+    assert prog.info()["n_mix_slots"] > 6
+    po2 = 5
+    lde = [o.rand_elems(rng, (int(w), 4 << po2)) for w in taps.group_size]
+    pm = o.rand_elems(rng, (4,))
+    want = oracle_eval_check(prog, taps, po2, lde, [], [], pm)
+    got = run_eval_check(hal, prog, po2, lde, [], [], pm)
+    assert np.array_equal(got, want)
+    ret2 = nest(0)
+    prog2 = cp.Program(b.array(), ret2, taps)
+    assert np.array_equal(run_eval_check(hal, prog2, po2, lde, [], [], pm), oracle_eval_check(prog2, taps, po2, lde, [], [], pm))
+
+
+def test_program_rejects_views_it_cannot_serve(hal):
+    taps = synthetic_tapset(8, 4, 8)
+    steps, ret = cp.toy_program(taps, 8)
+    prog = cp.Program(steps, ret, taps)
+    rng = np.random.default_rng(5)
+    po2 = 4
+    lde = [o.rand_elems(rng, (int(w), 4 << po2)) for w in taps.group_size]
+    pm = o.rand_elems(rng, (4,))
+    with pytest.raises(_lib.RkError) as e:               # the list reads mix[0..7]
+        run_eval_check(hal, prog, po2, lde, [], o.rand_elems(rng, (3,)), pm)
+    assert e.value.status == _lib.RK_ERR_INVALID
+    with pytest.raises(_lib.RkError):                    # a group narrower than the taps it reads
+        run_eval_check(hal, prog, po2, [lde[0][:3], lde[1], lde[2]], [], o.rand_elems(rng, (8,)), pm)
+
+
+def test_toy_program_under_the_sp1_field(hal, toy):
+    """the evaluator follows rk_params: extension x^4 - 11, coset shift 31, Plonky3's root generator"""
+    seg = toy.toy_segment(8, (8, 4, 8), seed=9)
+    steps, ret = cp.toy_program(seg.taps, seg.n_accum_mix, ext_w=11)
+    prog = cp.Program(steps, ret, seg.taps)
+    field = dict(ext_w=11, root_2_27=0x1a427a41, coset_shift=31)
+    hal.set_params(0, **field)
+    o.oracle_set_params(0, **field)
+    try:
+        rng = np.random.default_rng(8)
+        po2 = 6
+        lde = [o.rand_elems(rng, (int(w), 4 << po2)) for w in seg.taps.group_size]
+        mix, pm = o.rand_elems(rng, (8,)), o.rand_elems(rng, (4,))
+        want = oracle_eval_check(prog, seg.taps, po2, lde, [], mix, pm)
+        got = run_eval_check(hal, prog, po2, lde, [], mix, pm)
+        assert np.array_equal(got, want)
+    finally:
+        hal.set_params(0)
+        o.oracle_set_params(0)

@@ -110,7 +110,7 @@ def parse_header(src):
         plain = re.sub(r"\w+ \(\*\w+\)\(.*?\);", lambda mm: " " * len(mm.group(0)), body, flags=re.S)
         pos = 0
         for stmt in plain.split(";"):
-            start = pos
+            start = pos + (len(stmt) - len(stmt.lstrip()))   # where the declaration itself begins
             pos += len(stmt) + 1
             stmt = stmt.strip()
             if not stmt:
