@@ -32,8 +32,10 @@ namespace {
 using bb::Ext;
 
 constexpr uint32_t NONE = 0xffffffffu;
-// operand = kind << 29 | index
+// operand = kind << 29 | index; a tap's index is group << 27 | back << 20 | column, so that the
+// evaluator needs no table to find it
 enum : uint32_t { K_SLOT = 0, K_TAP = 1, K_CONST = 2, K_GLOBAL = 3, K_MIX = 4 };
+constexpr uint32_t TAP_MAX_BACK = 127, TAP_MAX_COLUMN = (1u << 20) - 1;
 constexpr uint32_t IDX_MASK = (1u << 29) - 1;
 inline uint32_t operand(uint32_t kind, uint32_t idx) { return (kind << 29) | idx; }
 // op.x = opcode | dst << 8
@@ -240,8 +242,9 @@ int compile(rk_program* pg) {
                     v.opnd = operand(K_CONST, intern_const(v.a));
                     break;
                 case RK_STEP_GET: {
-                    v.opnd = operand(K_TAP, v.a);
                     const Tap& t = pg->taps[v.a];
+                    if (t.back > TAP_MAX_BACK || t.offset > TAP_MAX_COLUMN) return RK_ERR_CAPACITY;
+                    v.opnd = operand(K_TAP, (t.group << 27) | (t.back << 20) | t.offset);
                     pg->group_min[t.group] = std::max(pg->group_min[t.group], t.offset + 1);
                     break;
                 }
@@ -322,8 +325,7 @@ struct EvalArgs {
     uint64_t code;       // uint4 per op
     uint64_t consts;     // program constants | globals | accum mix
     uint64_t powers;     // 4 words per distinct power of poly_mix
-    uint64_t tap_ptr;    // column base of every tap (u64)
-    uint64_t tap_shift;  // 4 * back (u32)
+    const uint32_t* lde[3];
     uint32_t* spill;
     uint32_t* check;
     size_t d;
@@ -338,16 +340,15 @@ struct Lane {
     uint32_t* lds;
     size_t i;
     const_u32 consts;
-    const_u64 tap_ptr;
-    const_u32 tap_shift;
     __device__ __forceinline__ uint32_t fetch(uint32_t opnd) const {
         const uint32_t kind = opnd >> 29, idx = opnd & IDX_MASK;
         switch (kind) {
             case K_SLOT:
                 return idx < a.lds_fp ? lds[idx * WG] : a.spill[(size_t)(idx - a.lds_fp) * a.d + i];
             case K_TAP: {
-                const uint32_t* col = reinterpret_cast<const uint32_t*>(tap_ptr[idx]);
-                return col[(i + a.d - tap_shift[idx]) & (a.d - 1)];
+                const uint32_t g = idx >> 27, back = (idx >> 20) & TAP_MAX_BACK, column = idx & TAP_MAX_COLUMN;
+                const uint32_t* base = g == 0 ? a.lde[0] : g == 1 ? a.lde[1] : a.lde[2];
+                return base[(size_t)column * a.d + ((i + a.d - 4 * (size_t)back) & (a.d - 1))];
             }
             case K_CONST:
                 return consts[idx];
@@ -391,11 +392,13 @@ __global__ __launch_bounds__(WG) void program_kernel(EvalArgs a) {
     extern __shared__ uint32_t lds_all[];
     const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
     if (i >= a.d) return;  // no barrier anywhere below
-    Lane ln{a, lds_all + threadIdx.x, i, (const_u32)a.consts, (const_u64)a.tap_ptr, (const_u32)a.tap_shift};
+    Lane ln{a, lds_all + threadIdx.x, i, (const_u32)a.consts};
     const const_u4 code = (const_u4)a.code;
     const const_u32 powers = (const_u32)a.powers;
+    uint4 next = code[0];  // the list has a spare entry at the end: the fetch of op pc + 1 runs under op pc
     for (uint32_t pc = 0; pc < a.n_ops; pc++) {
-        const uint4 op = code[pc];
+        const uint4 op = next;
+        next = code[pc + 1];
         const uint32_t oc = op.x & 0xffu, dst = op.x >> 8;
         if (oc <= OP_MUL) {
             const uint32_t x = ln.fetch(op.y), y = ln.fetch(op.z);
@@ -419,9 +422,10 @@ int device_code(rk_program* pg, rk_ctx* ctx, const uint4** out) {
     auto it = pg->d_code.find(ctx->device);
     if (it == pg->d_code.end()) {
         void* d = nullptr;
-        size_t bytes = std::max<size_t>(pg->code.size(), 1) * sizeof(uint4);
+        size_t bytes = (pg->code.size() + 1) * sizeof(uint4);  // one spare entry: the evaluator fetches one op ahead
         RK_HIP_TRY(ctx, hipMalloc(&d, bytes));
-        hipError_t e = hipMemcpy(d, pg->code.data(), pg->code.size() * sizeof(uint4), hipMemcpyHostToDevice);
+        hipError_t e = hipMemset(d, 0, bytes);
+        if (e == hipSuccess) e = hipMemcpy(d, pg->code.data(), pg->code.size() * sizeof(uint4), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(d);
             ctx->last_error = std::string("program upload: ") + hipGetErrorString(e);
@@ -454,11 +458,11 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     const uint4* d_ops = nullptr;
     RK_TRY(device_code(pg, ctx, &d_ops));
     a.code = (uint64_t)(uintptr_t)d_ops;
-    // per-proof tables in one upload: constants | globals | mix | powers | tap shifts | tap columns
-    const size_t nc = pg->consts.size(), ntap = pg->taps.size(), npw = pg->powers.size();
+    // per-proof tables in one upload: constants | globals | mix | powers
+    const size_t nc = pg->consts.size(), npw = pg->powers.size();
     const size_t o_glob = nc, o_mix = o_glob + v->n_globals, o_pw = (o_mix + v->n_mix + 3) & ~(size_t)3;
-    const size_t o_shift = o_pw + 4 * npw, o_ptr = (o_shift + ntap + 1) & ~(size_t)1, words = o_ptr + 2 * ntap;
-    std::vector<uint32_t> pack(words + 2, 0);
+    const size_t words = o_pw + 4 * npw;
+    std::vector<uint32_t> pack(words + 4, 0);
     std::memcpy(pack.data(), pg->consts.data(), nc * 4);
     if (v->n_globals) std::memcpy(&pack[o_glob], v->globals, (size_t)v->n_globals * 4);
     if (v->n_mix) std::memcpy(&pack[o_mix], v->mix, (size_t)v->n_mix * 4);
@@ -472,14 +476,7 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
             std::memcpy(&pack[o_pw + 4 * j], cur.c, 16);
         }
     }
-    for (size_t t = 0; t < ntap; t++) {
-        const Tap& tp = pg->taps[t];
-        pack[o_shift + t] = (uint32_t)((4 * (size_t)tp.back) & (d - 1));
-        uint64_t p = 0;
-        if (tp.group < 3 && v->d_lde[tp.group] && tp.offset < v->group_size[tp.group])
-            p = (uint64_t)(uintptr_t)(v->d_lde[tp.group] + (size_t)tp.offset * d);
-        std::memcpy(&pack[o_ptr + 2 * t], &p, 8);
-    }
+    for (int g = 0; g < 3; g++) a.lde[g] = v->d_lde[g];
     void* d_pack = nullptr;
     RK_TRY(scratch(ctx, words * 4 + 16, &d_pack));
     RK_HIP_TRY(ctx, hipMemcpyAsync(d_pack, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -489,8 +486,6 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     a.glob_base = (uint32_t)o_glob;
     a.mix_base = (uint32_t)o_mix;
     a.powers = (uint64_t)(uintptr_t)(dp + o_pw);
-    a.tap_shift = (uint64_t)(uintptr_t)(dp + o_shift);
-    a.tap_ptr = (uint64_t)(uintptr_t)(dp + o_ptr);
     a.check = d_check;
     a.d = d;
     a.n_ops = (uint32_t)pg->code.size();

@@ -18,12 +18,22 @@ from .segment import P, Segment, synthetic_tapset
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TOY_DIR = os.path.join(os.path.dirname(_HERE), "examples", "toy_circuit")
 TOY_SO = os.path.join(TOY_DIR, "_build", "libtoy_circuit.so")
+# the same circuit's constraint list (circuit_program.toy_program at widths 8/4/8, 8 mix elements) turned
+# into straight-line HIP by tools/circuit_gen.py
+GEN_SO = os.path.join(TOY_DIR, "_build", "libtoy_gen.so")
+GEN_WIDTHS, GEN_N_MIX = (8, 4, 8), 8
 _toy = None
+_gen = None
+_gen_hooks = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(TOY_DIR, f) for f in ("toy_circuit.hip", "toy_circuit.h", "Makefile")] + [_lib.LIB_PATH]
-    if force or not os.path.exists(TOY_SO) or any(os.path.getmtime(s) > os.path.getmtime(TOY_SO) for s in srcs):
+    root = os.path.dirname(_HERE)
+    srcs = [os.path.join(TOY_DIR, f) for f in ("toy_circuit.hip", "toy_circuit.h", "Makefile")] + [
+        _lib.LIB_PATH, os.path.join(root, "tools", "circuit_gen.py"), os.path.join(_HERE, "circuit_program.py")]
+    outs = (TOY_SO, GEN_SO)
+    if force or not all(os.path.exists(x) for x in outs) or any(
+            os.path.getmtime(s) > min(os.path.getmtime(x) for x in outs) for s in srcs):
         r = subprocess.run(["make", "-C", TOY_DIR], capture_output=True, text=True)
         if r.returncode != 0:
             raise _lib.HipLibraryError("building libtoy_circuit.so failed:\n" + r.stderr[-2000:])
@@ -46,6 +56,34 @@ def load():
 
 def hooks_ptr() -> int:
     return int(load().toy_circuit_hooks())
+
+
+def load_gen():
+    """libtoy_gen.so: eval_check / poly_ext generated from the toy circuit's constraint list"""
+    global _gen
+    if _gen is None:
+        load()
+        if not os.path.exists(GEN_SO):
+            raise _lib.HipLibraryError(f"{GEN_SO} not found: run `make -C examples/toy_circuit`")
+        _gen = C.CDLL(GEN_SO)
+    return _gen
+
+
+def gen_hooks_ptr() -> int:
+    """rk_circuit_hooks {accumulate: the hand-written one, eval_check: the generated straight-line kernel}"""
+    global _gen_hooks
+    if _gen_hooks is None:
+        src = C.cast(C.c_void_p(hooks_ptr()), C.POINTER(_lib.RkCircuitHooks)).contents
+        h = _lib.RkCircuitHooks()
+        h.user = src.user
+        h.accumulate = src.accumulate
+        h.eval_check = C.cast(load_gen().toy_gen_eval_check, _lib.EVAL_CHECK_FN)
+        _gen_hooks = h
+    return C.addressof(_gen_hooks)
+
+
+def gen_poly_ext_fn():
+    return C.cast(load_gen().toy_gen_poly_ext, _lib.POLY_EXT_FN)
 
 
 def poly_ext_fn():

@@ -202,3 +202,24 @@ def test_toy_program_under_the_sp1_field(hal, toy):
     finally:
         hal.set_params(0)
         o.oracle_set_params(0)
+
+
+@pytest.mark.parametrize("po2", [5, 10, 13])
+def test_generated_straight_line_code_equals_the_interpreter(hal, toy, po2):
+    """tools/circuit_gen.py: the same list as straight-line HIP (what risc0's build does for its own
+    kernels).  Three evaluators of one list -- oracle interpreter, GPU interpreter, generated kernel --
+    give the same seal, and the generated poly_ext accepts it."""
+    widths, n_mix = toy.GEN_WIDTHS, toy.GEN_N_MIX
+    seg = toy_with_program(toy, po2, widths, seed=300 + po2, n_accum_mix=n_mix)
+    want = o.oracle_prove(seg)
+    by_interpreter = hal.prove_segment(seg)
+    prog = seg.program
+    seg.program = None
+    seg.hooks = toy.gen_hooks_ptr
+    by_generated = hal.prove_segment(seg)
+    assert np.array_equal(by_interpreter, want) and np.array_equal(by_generated, want)
+    assert verify_segment(seg, by_generated, poly_ext=toy.gen_poly_ext_fn()) == 0
+    assert verify_segment(seg, by_generated, program=prog) == 0
+    bad = by_generated.copy()
+    bad[-1] ^= 1
+    assert verify_segment(seg, bad, poly_ext=toy.gen_poly_ext_fn()) != 0

@@ -139,3 +139,25 @@ def test_broken_witness_is_caught_by_the_program_identity(cpu_toy, row):
     assert hal.verify_segment(seg, seal) == 0              # commitments, DEEP and FRI are consistent
     assert hal.verify_segment(seg, seal, program=seg.program) == 70
     assert o.oracle_verify(seg, seal, toy_identity=True) == 70
+
+
+def test_generated_poly_ext_equals_the_program(cpu_toy):
+    """tools/circuit_gen.py output for the toy circuit (host half): same value as the compiled program and
+    as the oracle's literal interpreter on random openings"""
+    import ctypes as C
+    from raiko_amd import toy_circuit as real_toy
+    real_toy.build()
+    fn = real_toy.gen_poly_ext_fn()
+    taps = synthetic_tapset(*real_toy.GEN_WIDTHS)
+    steps, ret = cp.toy_program(taps, real_toy.GEN_N_MIX)
+    prog = cp.Program(steps, ret, taps)
+    rng = np.random.default_rng(4)
+    for _ in range(5):
+        eval_u = o.rand_elems(rng, (taps.tot_taps, 4))
+        mix, pm = o.rand_elems(rng, (real_toy.GEN_N_MIX,)), o.rand_elems(rng, (4,))
+        seg = _lib.RkSegment()
+        out = np.zeros(4, dtype=np.uint32)
+        p = lambda a: a.ctypes.data_as(_lib.u32p)
+        assert fn(None, C.pointer(seg), p(pm), p(eval_u), taps.tot_taps, p(mix), mix.size, p(out)) == 0
+        assert np.array_equal(out, prog.poly_ext(pm, eval_u, [], mix))
+        assert np.array_equal(out, or_poly_ext(prog, taps, pm, eval_u, [], mix))
