@@ -27,10 +27,10 @@ __device__ __forceinline__ Ext add_base(Ext a, uint32_t b) {
 }
 
 // t[i] = (m + d2[i]) / (m + d3[i])
-__global__ void ratio_kernel(uint32_t* t_ext, const uint32_t* data, size_t n, Ext m) {
+__global__ void ratio_kernel(uint32_t* t_ext, const uint32_t* data, size_t n, Ext m, uint32_t wm) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Ext r = bb::mul(add_base(m, data[2 * n + i]), bb::inv(add_base(m, data[3 * n + i])));
+    Ext r = bb::mul(add_base(m, data[2 * n + i]), bb::inv(add_base(m, data[3 * n + i]), wm), wm);
     *reinterpret_cast<uint4*>(t_ext + i * 4) = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
 }
 // accum columns from the running product and the plain data columns
@@ -51,14 +51,16 @@ struct CheckArgs {
     size_t d;
     uint32_t wa, wd;
     Ext poly_mix, m;
-    uint32_t inv_den[4];
+    uint32_t wm;         // Montgomery form of the extension's W (rk_params.ext_w)
+    uint32_t blow;       // log2 of the blow-up (rk_params.blowup_log2): one row back = 1 << blow points back
+    uint32_t inv_den[16];
     ColMix cm;
 };
 __global__ void eval_check_kernel(uint32_t* check, CheckArgs a) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.d) return;
     const size_t d = a.d;
-    const size_t b1 = (i + d - 4) % d, b2 = (i + d - 8) % d;  // one / two rows back on the 4x domain
+    const size_t b1 = (i + d - ((size_t)1 << a.blow)) % d, b2 = (i + d - ((size_t)2 << a.blow)) % d;  // one / two rows back
     const uint32_t one = bb::ONE;
     uint32_t c0 = a.code[i], c1 = a.code[d + i], c2 = a.code[2 * d + i];
     uint32_t d0 = a.data[i], d0b1 = a.data[b1], d0b2 = a.data[b2];
@@ -69,21 +71,21 @@ __global__ void eval_check_kernel(uint32_t* check, CheckArgs a) {
     uint32_t k0 = bb::mul(bb::sub(bb::sub(one, c0), c1), bb::sub(bb::sub(d0, d0b1), d0b2));
     uint32_t k1 = bb::sub(d1, bb::mul(d0, d0b1));
     Ext prev = add_base(bb::scale(Ab, bb::sub(one, c0)), c0);
-    Ext k2 = bb::sub(bb::mul(A, add_base(a.m, d3)), bb::mul(prev, add_base(a.m, d2)));
+    Ext k2 = bb::sub(bb::mul(A, add_base(a.m, d3), a.wm), bb::mul(prev, add_base(a.m, d2), a.wm));
     Ext k3 = bb::scale(add_base(A, bb::neg(one)), c2);
     Ext pw = a.poly_mix;
     Ext tot = bb::ext_from(k0);
     tot = bb::add(tot, bb::scale(pw, k1));
-    pw = bb::mul(pw, a.poly_mix);
-    tot = bb::add(tot, bb::mul(pw, k2));
-    pw = bb::mul(pw, a.poly_mix);
-    tot = bb::add(tot, bb::mul(pw, k3));
+    pw = bb::mul(pw, a.poly_mix, a.wm);
+    tot = bb::add(tot, bb::mul(pw, k2, a.wm));
+    pw = bb::mul(pw, a.poly_mix, a.wm);
+    tot = bb::add(tot, bb::mul(pw, k3, a.wm));
     for (uint32_t k = 4; k < a.wa; k++) {
-        pw = bb::mul(pw, a.poly_mix);
+        pw = bb::mul(pw, a.poly_mix, a.wm);
         uint32_t kk = bb::sub(a.acc[(size_t)k * d + i], bb::mul(a.cm.m[k - 4], a.data[(size_t)(k % a.wd) * d + i]));
         tot = bb::add(tot, bb::scale(pw, kk));
     }
-    tot = bb::scale(tot, a.inv_den[i & 3]);
+    tot = bb::scale(tot, a.inv_den[i & ((1u << a.blow) - 1)]);
 #pragma unroll
     for (int e = 0; e < 4; e++) check[(size_t)e * d + i] = tot.c[e];
 }
@@ -98,11 +100,13 @@ int accumulate(void*, const rk_circuit_view* v, uint32_t* d_accum) {
     if (!shape_ok(v->group_size, v->n_mix) || !v->d_trace[2]) return 1;
     const size_t n = (size_t)1 << v->po2;
     hipStream_t stream = (hipStream_t)v->stream;
+    rk_params prm;
+    if (rk_get_params(v->ctx, &prm) != RK_OK) return 2;
     void* t = nullptr;
     if (rk_alloc(v->ctx, n * 16, &t) != RK_OK) return 2;
     Ext m{{v->mix[0], v->mix[1], v->mix[2], v->mix[3]}};
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(ratio_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t*)t, v->d_trace[2], n, m);
+    hipLaunchKernelGGL(ratio_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t*)t, v->d_trace[2], n, m, bb::encode(prm.ext_w));
     int rc = hipGetLastError() == hipSuccess ? 0 : 3;
     if (!rc && rk_prefix_products(v->ctx, (uint32_t*)t, n) != RK_OK) rc = 4;  // Hal::prefix_products
     if (!rc) {
@@ -116,20 +120,24 @@ int accumulate(void*, const rk_circuit_view* v, uint32_t* d_accum) {
 
 int eval_check(void*, const rk_circuit_view* v, const uint32_t poly_mix[4], uint32_t* d_check) {
     if (!shape_ok(v->group_size, v->n_mix) || !v->d_lde[0] || !v->d_lde[1] || !v->d_lde[2]) return 1;
-    const size_t n = (size_t)1 << v->po2, d = 4 * n;
+    rk_params prm;
+    if (rk_get_params(v->ctx, &prm) != RK_OK) return 2;
+    const size_t n = (size_t)1 << v->po2, d = n << prm.blowup_log2;
     CheckArgs a{};
     a.acc = v->d_lde[0];
     a.code = v->d_lde[1];
     a.data = v->d_lde[2];
     a.d = d;
+    a.blow = prm.blowup_log2;
+    a.wm = bb::encode(prm.ext_w);
     a.wa = v->group_size[0];
     a.wd = v->group_size[2];
     std::memcpy(a.poly_mix.c, poly_mix, 16);
     std::memcpy(a.m.c, v->mix, 16);
-    // x_i^N for x_i = 3 * w_D^i takes four values: 3^N * w_4^(i mod 4)
-    const uint32_t three_n = bb::pow(bb::encode(3), n);
-    const uint32_t w4 = bb::pow(bb::encode(137), (uint64_t)1 << 25);  // 137 has order 2^27
-    for (int r = 0; r < 4; r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(three_n, bb::pow(w4, r)), bb::ONE));
+    // x_i^N for x_i = shift * w_D^i takes D/N values: shift^N * w_(D/N)^(i mod D/N)
+    const uint32_t shift_n = bb::pow(bb::encode(prm.coset_shift), n);
+    const uint32_t wb = bb::pow(bb::encode(prm.root_2_27), (uint64_t)1 << (27 - prm.blowup_log2));
+    for (uint32_t r = 0; r < (1u << prm.blowup_log2); r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(shift_n, bb::pow(wb, r)), bb::ONE));
     a.cm = col_mix(v);
     hipLaunchKernelGGL(eval_check_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, (hipStream_t)v->stream, d_check,
                        a);

@@ -85,11 +85,12 @@ typedef struct {
     const uint32_t* p2_diag;     /* p2_width internal-diagonal entries (matrix 1 1^T + diag); NULL = defaults */
     /* protocol */
     uint32_t queries;            /* 50 (risc0), 100 (SP1 core) */
-    uint32_t blowup_log2;        /* 2 (risc0), 1 (SP1 core): rk_prove_segment accepts 2; the operators take
-                                  * expand_bits / sizes as arguments and serve both */
-    uint32_t fri_fold_log2;      /* 4 (risc0), 1 (Plonky3): rk_fri_fold folds by 2^fri_fold_log2 (1..4);
-                                  * rk_prove_segment accepts 4 */
-    uint32_t fri_min_degree;     /* 256 (risc0) */
+    uint32_t blowup_log2;        /* 2 (risc0), 1 (SP1 core); 1..4.  The LDE domain of a segment has 2^(po2 + blowup_log2)
+                                  * points, the check polynomial 4 * 2^blowup_log2 columns, hooks see that domain */
+    uint32_t fri_fold_log2;      /* 4 (risc0), 1 (Plonky3): FRI folds by 2^fri_fold_log2 per round (1..4) */
+    uint32_t fri_min_degree;     /* 256 (risc0), 1 (Plonky3: down to a constant): folding stops at this many coefficients */
+    uint32_t pow_bits;           /* 0 (risc0), 16 (SP1 core): proof-of-work bits ground before the queries are drawn
+                                  * (rk_pow_grind), 0..24 */
 } rk_params;
 int rk_params_preset(rk_params* out, int preset);
 int rk_set_params(rk_ctx* ctx, const rk_params* params);
@@ -141,6 +142,13 @@ int rk_prefix_products(rk_ctx* ctx, uint32_t* d_io_ext, size_t count);
 int rk_scatter(rk_ctx* ctx, uint32_t* d_into, size_t into_words, const uint32_t* h_index, size_t n_cycles,
                const uint32_t* h_offsets, const uint32_t* h_values);
 
+/* Proof of work on the transcript (Plonky3 challenger `grind` / `check_witness`, restated on this
+ * library's Poseidon2 transcript; risc0 has none): the smallest nonce w (a field element written as the
+ * u32 < p it is stored as) such that after absorbing hash([w]) the next random_bits(bits) are all
+ * zero.  sponge_cells = the transcript generator's p2_width state words right after a commit.  One
+ * lane per candidate, two permutations each. */
+int rk_pow_grind(rk_ctx* ctx, const uint32_t* sponge_cells, uint32_t bits, uint32_t* nonce);
+
 /* ---- fused building blocks (no single Hal counterpart) ---- */
 /* MerkleTreeProver::new (risc0-zkp prove/merkle.rs): hash_rows + every hash_fold level into
  * d_nodes (2*rows digests, heap order, root at index 1). */
@@ -179,7 +187,8 @@ typedef struct {
     const uint32_t* d_trace[3];    /* device, column-major 2^po2 x group_size[g]: the witness as handed in
                                     * ([1], [2]; valid in `accumulate` only, NULL otherwise) */
     const uint32_t* d_lde[3];      /* device, column-major 4*2^po2 x group_size[g]: evaluations on the coset
-                                    * 3*w^i, natural order (PolyGroup::evaluated); NULL until committed */
+                                    * 3*w^i, natural order (PolyGroup::evaluated); NULL until committed.
+                                    * (4 = 2^blowup_log2, 3 = coset_shift of the context's rk_params) */
     const uint32_t* globals;       /* host */
     uint32_t n_globals;
     const uint32_t* mix;           /* host: the n_accum_mix elements drawn before the accum commit */
@@ -302,6 +311,8 @@ int rk_verify_segment_ex(const rk_segment* pub, const rk_verify_opts* opts, cons
  * RK_MAX_QUERIES queries' worth of openings when called without parameters. */
 size_t rk_seal_bound_words(const rk_segment* seg);
 size_t rk_seal_bound_words_for(const rk_segment* seg, uint32_t queries);
+/* the same for a whole parameter set (queries, blow-up, fold arity, final degree, proof of work) */
+size_t rk_seal_bound_words_params(const rk_segment* seg, const rk_params* params);
 #define RK_MAX_QUERIES 256
 
 /* ---- whole-session prover: what replaces `session.prove()` (provers/risc0/driver/src/bonsai.rs:271,

@@ -100,9 +100,9 @@ int or_program_eval_check(void* user, const or_circuit_view* v, const fp* poly_m
     }
     fp4 pm;
     memcpy(&pm, poly_mix, 16);
-    fp inv_den[4];
-    fp shift_n = fp_pow(fp_from_u32(g_or.coset_shift), N), w4 = or_rou_fwd(2);
-    for (int r = 0; r < 4; r++) inv_den[r] = fp_inv(fp_sub(fp_mul(shift_n, fp_pow(w4, r)), fp_from_u32(1)));
+    fp inv_den[16];
+    fp shift_n = fp_pow(fp_from_u32(g_or.coset_shift), N), w4 = or_rou_fwd(OR_INV_RATE_PO2);
+    for (size_t r = 0; r < OR_INV_RATE; r++) inv_den[r] = fp_inv(fp_sub(fp_mul(shift_n, fp_pow(w4, r)), fp_from_u32(1)));
     int bad = 0;
 #pragma omp parallel
     {
@@ -113,7 +113,7 @@ int or_program_eval_check(void* user, const or_circuit_view* v, const fp* poly_m
         for (size_t i = 0; i < D; i++) {
             for (size_t k = 0; k < n_taps; k++) u[k] = col[k] ? col[k][(i + D - shift[k]) % D] : 0;
             fp4 tot = run_fp(pg, u, v->globals, v->n_globals, v->mix, v->n_mix, pm, vals, ms);
-            tot = fp4_scale(tot, inv_den[i & 3]);
+            tot = fp4_scale(tot, inv_den[i & (OR_INV_RATE - 1)]);
             for (int e = 0; e < 4; e++) check[(size_t)e * D + i] = tot.c[e];
         }
         free(u); free(vals); free(ms);

@@ -94,6 +94,19 @@ uint32_t or_iop_random_bits(or_iop* iop, unsigned bits) {
     return val & (uint32_t)(((uint64_t)1 << bits) - 1);
 }
 
+/* the literal definition: try w = 0, 1, 2, ... on a copy of the transcript generator -- write nothing,
+ * absorb hash([w]) as or_iop_commit does, draw the bits as or_iop_random_bits does */
+uint32_t or_pow_grind(const or_iop* iop, unsigned bits) {
+    for (uint32_t w = 0; w < OR_P; w++) {
+        or_iop t = *iop; /* shares `proof`, which the trial never touches */
+        uint32_t digest[8];
+        or_hash_elem_slice(&w, 1, 1, digest);
+        or_iop_commit(&t, digest);
+        if (or_iop_random_bits(&t, bits) == 0) return w;
+    }
+    return 0xffffffffu;
+}
+
 /* ---------------------------------------------------------- poly_group.rs */
 typedef struct {
     fp* coeffs;      /* count x size, natural order after construction */
@@ -107,7 +120,7 @@ static void polygroup_new(polygroup* g, fp* coeffs, size_t count, size_t size) {
     g->coeffs = coeffs; g->count = count; g->size = size;
     size_t domain = size * OR_INV_RATE;
     g->evaluated = (fp*)malloc(count * domain * sizeof(fp));
-    or_batch_expand_into_evaluate_ntt(g->evaluated, coeffs, size, count, ilog2(OR_INV_RATE));
+    or_batch_expand_into_evaluate_ntt(g->evaluated, coeffs, size, count, OR_INV_RATE_PO2);
     or_batch_bit_reverse(coeffs, size, count);
     double t1 = now_s();
     or_merkle_build(&g->merkle, g->evaluated, domain, count, OR_QUERIES);
@@ -136,7 +149,7 @@ static void fri_round_new(fri_round* r, or_iop* iop, const fp* coeffs, size_t co
     size_t domain = size * OR_INV_RATE;
     r->domain = domain;
     r->evaluated = (fp*)malloc(domain * OR_EXT * sizeof(fp));
-    or_batch_expand_into_evaluate_ntt(r->evaluated, coeffs, size, OR_EXT, ilog2(OR_INV_RATE));
+    or_batch_expand_into_evaluate_ntt(r->evaluated, coeffs, size, OR_EXT, OR_INV_RATE_PO2);
     or_merkle_build(&r->merkle, r->evaluated, domain / OR_FRI_FOLD, OR_FRI_FOLD * OR_EXT, OR_QUERIES);
     merkle_commit(&r->merkle, iop);
     fp4 fold_mix = or_iop_random_ext(iop);
@@ -148,10 +161,10 @@ typedef void (*inner_fn)(void* ctx, or_iop* iop, size_t idx);
 static void fri_prove(or_iop* iop, const fp* coeffs_in, size_t coeffs_size, inner_fn inner, void* ctx) {
     double t0 = now_s();
     size_t orig_domain = coeffs_size / OR_EXT * OR_INV_RATE;
-    fri_round rounds[16];
+    fri_round rounds[32];
     int n_rounds = 0;
     const fp* coeffs = coeffs_in;
-    while (coeffs_size / OR_EXT > OR_FRI_MIN_DEGREE) {
+    while (coeffs_size / OR_EXT > OR_FRI_MIN_DEGREE && coeffs_size / OR_EXT >= OR_FRI_FOLD) {
         fri_round_new(&rounds[n_rounds], iop, coeffs, coeffs_size);
         coeffs = rounds[n_rounds].coeffs;
         coeffs_size = rounds[n_rounds].coeffs_size;
@@ -165,6 +178,13 @@ static void fri_prove(or_iop* iop, const fp* coeffs_in, size_t coeffs_size, inne
     or_hash_elem_slice(final_coeffs, coeffs_size, 1, digest);
     or_iop_commit(iop, digest);
     free(final_coeffs);
+    if (g_or.pow_bits) { /* proof of work before the query positions exist; the nonce is absorbed hashed */
+        uint32_t nonce = or_pow_grind(iop, g_or.pow_bits);
+        or_iop_write(iop, &nonce, 1);
+        or_hash_elem_slice(&nonce, 1, 1, digest);
+        or_iop_commit(iop, digest);
+        (void)or_iop_random_bits(iop, g_or.pow_bits); /* zero by construction; the verifier draws them too */
+    }
     double t1 = now_s();
     g_timing.fri += t1 - t0;
     for (uint32_t q = 0; q < OR_QUERIES; q++) {
@@ -203,8 +223,8 @@ int or_prove_segment(const or_segment* seg, uint32_t** seal, size_t* seal_words,
     (void)threads;
 #endif
     memset(&g_timing, 0, sizeof g_timing);
-    /* the segment flow is risc0's: blow-up 4, fold 16, final degree 256 (field, hash and query count follow g_or) */
-    if (g_or.blowup_log2 != 2 || g_or.fri_fold_log2 != OR_FRI_FOLD_PO2 || g_or.fri_min_degree != OR_FRI_MIN_DEGREE) return -4;
+    /* the segment flow is risc0's; blow-up, fold arity, final degree, queries and proof of work follow g_or */
+    if (seg->po2 < 1 || seg->po2 + g_or.blowup_log2 > 24) return -4;
     double t_start = now_s();
     const or_taps* taps = &seg->taps;
     size_t N = (size_t)1 << seg->po2;
@@ -302,9 +322,9 @@ int or_prove_segment(const or_segment* seg, uint32_t** seal, size_t* seal_words,
         or_poly_interpolate(coeff_u + pos, all_xs + pos, eval_u + pos, sz);
         pos += sz;
     }
-    fp4 z_pow = fp4_pow(z, OR_EXT);
+    fp4 z_pow = fp4_pow(z, OR_INV_RATE);
     {
-        fp4 xs[OR_CHECK_SIZE];
+        fp4 xs[OR_MAX_CHECK_SIZE];
         for (uint32_t i = 0; i < OR_CHECK_SIZE; i++) { which[i] = i; xs[i] = z_pow; }
         or_batch_evaluate_any(check.coeffs, N, which, xs, OR_CHECK_SIZE, coeff_u + pos);
     }

@@ -87,9 +87,9 @@ static int toy_eval_check(void* user, const or_circuit_view* v, const fp* poly_m
     uint32_t wa = v->group_size[0], wd = v->group_size[2];
     fp4 pm = ext_of(poly_mix), m = ext_of(v->mix);
     /* x_i^N for x_i = 3*w_D^i takes 4 values: 3^N * w_4^(i mod 4) */
-    fp inv_den[4];
-    fp three_n = fp_pow(fp_from_u32(g_or.coset_shift), N), w4 = or_rou_fwd(2);
-    for (int r = 0; r < 4; r++) inv_den[r] = fp_inv(fp_sub(fp_mul(three_n, fp_pow(w4, r)), fp_from_u32(1)));
+    fp inv_den[16];
+    fp three_n = fp_pow(fp_from_u32(g_or.coset_shift), N), w4 = or_rou_fwd(OR_INV_RATE_PO2);
+    for (size_t r = 0; r < OR_INV_RATE; r++) inv_den[r] = fp_inv(fp_sub(fp_mul(three_n, fp_pow(w4, r)), fp_from_u32(1)));
     int bad = 0;
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < D; i++) {
@@ -106,7 +106,7 @@ static int toy_eval_check(void* user, const or_circuit_view* v, const fp* poly_m
             ed[k - 4] = fp4_from_fp(data[(size_t)(k % wd) * D + i]);
         }
         fp4 tot = toy_mix(&p, pm, m, ea, ed, v->mix, v->n_mix, wa, wd);
-        tot = fp4_scale(tot, inv_den[i & 3]);
+        tot = fp4_scale(tot, inv_den[i & (OR_INV_RATE - 1)]);
         for (int e = 0; e < 4; e++) check[(size_t)e * D + i] = tot.c[e];
     }
     return bad;

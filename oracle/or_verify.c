@@ -53,7 +53,7 @@ int or_verify_segment(const or_segment* seg, const uint32_t* seal, size_t seal_w
 int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_t seal_words,
                               or_poly_ext_fn poly_ext, void* user) {
     const or_taps* taps = &seg->taps;
-    if (g_or.blowup_log2 != 2 || g_or.fri_fold_log2 != OR_FRI_FOLD_PO2 || g_or.fri_min_degree != OR_FRI_MIN_DEGREE) return -4;
+    if (seg->po2 < 1 || seg->po2 + g_or.blowup_log2 > 24) return -4;
     riop r; memset(&r, 0, sizeof r);
     r.p = seal; r.len = seal_words;
     uint32_t digest[8];
@@ -108,13 +108,16 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
         }
         fp4 result;
         if (poly_ext(user, seg, poly_mix.c, eval_u, tot_taps, accum_mix, seg->n_accum_mix, result.c) != 0) identity_rc = 71;
-        static const int remap[4] = {0, 2, 1, 3};
+        /* part i of the check polynomial is in column bitrev(i) of each component ({0,2,1,3} for blow-up 4) */
+        size_t parts = OR_INV_RATE;
         fp4 check = fp4_zero(), zi = fp4_one();
-        for (int i = 0; i < 4; i++) {
+        for (size_t i = 0; i < parts; i++) {
+            size_t rev = 0;
+            for (unsigned b = 0; b < OR_INV_RATE_PO2; b++) rev |= ((i >> b) & 1) << (OR_INV_RATE_PO2 - 1 - b);
             for (int e = 0; e < 4; e++) {
                 fp4 basis = fp4_zero();
                 basis.c[e] = fp_from_u32(1);
-                check = fp4_add(check, fp4_mul(fp4_mul(coeff_u[tot_taps + remap[i] + 4 * e], zi), basis));
+                check = fp4_add(check, fp4_mul(fp4_mul(coeff_u[tot_taps + rev + parts * e], zi), basis));
             }
             zi = fp4_mul(zi, z);
         }
@@ -136,19 +139,19 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
             }
             cur = fp4_mul(cur, mix); pos += sz;
         }
-        for (int i = 0; i < OR_CHECK_SIZE; i++) {
+        for (size_t i = 0; i < OR_CHECK_SIZE; i++) {
             combo_u[tot_combo_backs] = fp4_add(combo_u[tot_combo_backs], fp4_mul(cur, coeff_u[pos++]));
             cur = fp4_mul(cur, mix);
         }
     }
-    fp4 z_pow = fp4_pow(z, OR_EXT);
+    fp4 z_pow = fp4_pow(z, OR_INV_RATE);
 
     /* ---- fri_verify ---- */
     int rc = identity_rc;
     size_t degree = N, domain = D, orig_domain = D;
-    struct { size_t domain; mverifier m; fp4 mix; } rounds[16];
+    struct { size_t domain; mverifier m; fp4 mix; } rounds[32];
     int n_rounds = 0;
-    while (degree > OR_FRI_MIN_DEGREE) {
+    while (degree > OR_FRI_MIN_DEGREE && degree >= OR_FRI_FOLD) {
         rounds[n_rounds].domain = domain;
         mv_new(&rounds[n_rounds].m, &r, domain / OR_FRI_FOLD, OR_FRI_FOLD * OR_EXT, OR_QUERIES);
         rounds[n_rounds].mix = or_iop_random_ext(&r.rng);
@@ -158,13 +161,19 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
     fp* final_coeffs = (fp*)malloc(OR_EXT * degree * 4);
     r_read(&r, final_coeffs, OR_EXT * degree);
     or_hash_elem_slice(final_coeffs, OR_EXT * degree, 1, digest); or_iop_commit(&r.rng, digest);
+    if (g_or.pow_bits) { /* proof of work: the nonce, absorbed hashed, must zero the next pow_bits random bits */
+        uint32_t nonce = 0;
+        r_read(&r, &nonce, 1);
+        or_hash_elem_slice(&nonce, 1, 1, digest); or_iop_commit(&r.rng, digest);
+        if (!r.err && (nonce >= OR_P || or_iop_random_bits(&r.rng, g_or.pow_bits) != 0) && !rc) rc = 62;
+    }
     fp gen = or_rou_fwd(ilog2(domain));
     fp gen0 = or_rou_fwd(ilog2(orig_domain));
     size_t maxw = taps->group_size[0];
     for (int g = 1; g < 3; g++) if (taps->group_size[g] > maxw) maxw = taps->group_size[g];
     fp* rows[3];
     for (int g = 0; g < 3; g++) rows[g] = (fp*)malloc((taps->group_size[g] + 1) * 4);
-    fp check_row[OR_CHECK_SIZE];
+    fp check_row[OR_MAX_CHECK_SIZE];
     fp4* tot = (fp4*)malloc((taps->n_combos + 1) * sizeof(fp4));
 
     for (uint32_t q = 0; q < OR_QUERIES && !rc && !r.err; q++) {
@@ -182,7 +191,7 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
             tot[taps->reg_combo[i]] = fp4_add(tot[taps->reg_combo[i]], fp4_scale(cur, v));
             cur = fp4_mul(cur, mix);
         }
-        for (int i = 0; i < OR_CHECK_SIZE; i++) {
+        for (size_t i = 0; i < OR_CHECK_SIZE; i++) {
             tot[taps->n_combos] = fp4_add(tot[taps->n_combos], fp4_scale(cur, check_row[i]));
             cur = fp4_mul(cur, mix);
         }
@@ -207,19 +216,19 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
         for (int k = 0; k < n_rounds && !rc; k++) {
             size_t dom = rounds[k].domain;
             size_t quot = pos / (dom / OR_FRI_FOLD), group = pos % (dom / OR_FRI_FOLD);
-            fp data[OR_FRI_FOLD * OR_EXT];
-            if (mv_verify(&rounds[k].m, &r, group, data)) { rc = 30 + k; break; }
-            fp4 de[OR_FRI_FOLD];
-            for (int i = 0; i < OR_FRI_FOLD; i++)
+            fp data[OR_MAX_FRI_FOLD * OR_EXT];
+            if (mv_verify(&rounds[k].m, &r, group, data)) { rc = 30 + (k < 9 ? k : 9); break; }
+            fp4 de[OR_MAX_FRI_FOLD];
+            for (size_t i = 0; i < OR_FRI_FOLD; i++)
                 for (int c = 0; c < 4; c++) de[i].c[c] = data[c * OR_FRI_FOLD + i];
-            if (!fp4_eq(de[quot], goal)) { rc = 40 + k; break; }
+            if (!fp4_eq(de[quot], goal)) { rc = 40 + (k < 9 ? k : 9); break; }
             /* fold_eval: inverse DFT of the 16 coset values, then evaluate at mix * w^-group */
             fp w16_inv = or_rou_rev(OR_FRI_FOLD_PO2);
             fp inv16 = fp_inv(fp_from_u32(OR_FRI_FOLD));
-            fp4 gco[OR_FRI_FOLD];
-            for (int i = 0; i < OR_FRI_FOLD; i++) {
+            fp4 gco[OR_MAX_FRI_FOLD];
+            for (size_t i = 0; i < OR_FRI_FOLD; i++) {
                 fp4 acc = fp4_zero();
-                for (int j = 0; j < OR_FRI_FOLD; j++)
+                for (size_t j = 0; j < OR_FRI_FOLD; j++)
                     acc = fp4_add(acc, fp4_scale(de[j], fp_pow(w16_inv, (uint64_t)((i * j) % OR_FRI_FOLD))));
                 gco[i] = fp4_scale(acc, inv16);
             }

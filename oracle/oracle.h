@@ -22,12 +22,16 @@
 extern "C" {
 #endif
 
-#define OR_INV_RATE 4
+/* protocol shape: risc0's values (4 / 16 / 256 / no proof of work) unless or_set_params says otherwise */
+#define OR_INV_RATE ((size_t)1 << g_or.blowup_log2)
+#define OR_INV_RATE_PO2 (g_or.blowup_log2)
 #define OR_QUERIES (g_or.queries)
 #define OR_MAX_QUERIES 256
-#define OR_FRI_FOLD 16
-#define OR_FRI_FOLD_PO2 4
-#define OR_FRI_MIN_DEGREE 256
+#define OR_FRI_FOLD ((size_t)1 << g_or.fri_fold_log2)
+#define OR_FRI_FOLD_PO2 (g_or.fri_fold_log2)
+#define OR_FRI_MIN_DEGREE ((size_t)g_or.fri_min_degree)
+#define OR_MAX_FRI_FOLD 16
+#define OR_MAX_CHECK_SIZE 64
 #define OR_DIGEST_WORDS 8
 #define OR_MAX_CELLS 24
 /* sponge width / rate of the configured Poseidon2 instance (24 / 16 by default) */
@@ -35,7 +39,7 @@ extern "C" {
 #define OR_CELLS_RATE (g_or.p2_width - 8)
 #define OR_CELLS_OUT 8
 #define OR_EXT 4
-#define OR_CHECK_SIZE 16
+#define OR_CHECK_SIZE ((size_t)OR_EXT << g_or.blowup_log2)
 
 /* ---- the parameter set (the oracle is configured process-wide, one set at a time) ----
  * Mirrors rk_params of include/raiko_hip.h: canonical field values, Montgomery Poseidon2 tables.
@@ -46,7 +50,7 @@ typedef struct {
     uint32_t ext_w, root_2_27, coset_shift;
     uint32_t p2_width, p2_m4, p2_pad_free;
     const fp *p2_rc_ext, *p2_rc_int, *p2_diag;   /* NULL = the derived defaults of the width */
-    uint32_t queries, blowup_log2, fri_fold_log2, fri_min_degree;
+    uint32_t queries, blowup_log2, fri_fold_log2, fri_min_degree, pow_bits;
 } or_params;
 extern or_params g_or;
 void or_params_preset(or_params* out, int preset);
@@ -121,6 +125,10 @@ void or_iop_write(or_iop* iop, const uint32_t* words, size_t n);
 uint32_t or_iop_random_bits(or_iop* iop, unsigned bits);
 fp or_iop_random_elem(or_iop* iop);
 fp4 or_iop_random_ext(or_iop* iop);
+
+/* proof of work on the transcript (Plonky3 `grind`, restated on this transcript; risc0 has none):
+ * the smallest nonce w such that after absorbing hash([w]) the next random_bits(bits) are zero */
+uint32_t or_pow_grind(const or_iop* iop, unsigned bits);
 
 /* ---- tap set (risc0-zkp taps.rs), supplied by the caller ---- */
 typedef struct {

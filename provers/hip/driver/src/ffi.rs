@@ -86,6 +86,7 @@ pub struct rk_params {
     pub blowup_log2: u32,
     pub fri_fold_log2: u32,
     pub fri_min_degree: u32,
+    pub pow_bits: u32,
 }
 
 #[repr(C)]
@@ -275,6 +276,7 @@ extern "C" {
     pub fn rk_gather_sample(ctx: *mut rk_ctx, d_dst: *mut u32, d_src: *const u32, idx: usize, size: usize, stride: usize) -> c_int;
     pub fn rk_prefix_products(ctx: *mut rk_ctx, d_io_ext: *mut u32, count: usize) -> c_int;
     pub fn rk_scatter(ctx: *mut rk_ctx, d_into: *mut u32, into_words: usize, h_index: *const u32, n_cycles: usize, h_offsets: *const u32, h_values: *const u32) -> c_int;
+    pub fn rk_pow_grind(ctx: *mut rk_ctx, sponge_cells: *const u32, bits: u32, nonce: *mut u32) -> c_int;
     pub fn rk_merkle_build(ctx: *mut rk_ctx, d_nodes: *mut u32, d_matrix: *const u32, rows: usize, cols: usize) -> c_int;
     pub fn rk_poly_divide(ctx: *mut rk_ctx, d_polys_ext: *mut u32, count: usize, z: *const u32, h_rem: *mut u32) -> c_int;
     pub fn rk_program_create(steps: *const rk_poly_step, n_steps: usize, ret: u32, taps: *const rk_taps, out: *mut *mut rk_program) -> c_int;
@@ -287,6 +289,7 @@ extern "C" {
     pub fn rk_verify_segment_ex(pub_: *const rk_segment, opts: *const rk_verify_opts, seal: *const u32, seal_words: usize) -> c_int;
     pub fn rk_seal_bound_words(seg: *const rk_segment) -> usize;
     pub fn rk_seal_bound_words_for(seg: *const rk_segment, queries: u32) -> usize;
+    pub fn rk_seal_bound_words_params(seg: *const rk_segment, params: *const rk_params) -> usize;
     pub fn rk_prove_session(opts: *const rk_session_opts, segs: *const rk_segment, n: usize, h_seals: *const *mut u32, seal_capacity_words: *const usize, seal_words: *mut usize, failed_index: *mut usize) -> c_int;
     pub fn rk_session_last_error(device: c_int) -> *const c_char;
     pub fn rk_session_release() -> c_int;

@@ -82,7 +82,7 @@ class RkParams(C.Structure):
                 ("p2_width", C.c_uint32), ("p2_m4", C.c_uint32), ("p2_pad_free", C.c_uint32),
                 ("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p),
                 ("queries", C.c_uint32), ("blowup_log2", C.c_uint32), ("fri_fold_log2", C.c_uint32),
-                ("fri_min_degree", C.c_uint32)]
+                ("fri_min_degree", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
 RK_PRESET_RISC0, RK_PRESET_SP1 = 0, 1
@@ -172,6 +172,8 @@ SYMBOLS = {
     "rk_scatter": (C.c_int, [_vp, _vp, _sz, u32p, _sz, u32p, u32p]),
     "rk_seal_bound_words": (_sz, [C.POINTER(RkSegment)]),
     "rk_seal_bound_words_for": (_sz, [C.POINTER(RkSegment), _u32]),
+    "rk_seal_bound_words_params": (_sz, [C.POINTER(RkSegment), C.POINTER(RkParams)]),
+    "rk_pow_grind": (C.c_int, [_vp, u32p, _u32, u32p]),
     "rk_params_preset": (C.c_int, [C.POINTER(RkParams), C.c_int]),
     "rk_set_params": (C.c_int, [_vp, C.POINTER(RkParams)]),
     "rk_get_params": (C.c_int, [_vp, C.POINTER(RkParams)]),

@@ -332,7 +332,8 @@ struct EvalArgs {
     uint32_t n_ops, glob_base, mix_base;
     uint32_t lds_fp, lds_mix, n_fp_slots;
     uint32_t ret_slot, wm;
-    uint32_t inv_den[4];
+    uint32_t blow;       // log2 of the blow-up: a tap `back` rows behind is back << blow points behind
+    uint32_t inv_den[16];
 };
 
 struct Lane {
@@ -348,7 +349,7 @@ struct Lane {
             case K_TAP: {
                 const uint32_t g = idx >> 27, back = (idx >> 20) & TAP_MAX_BACK, column = idx & TAP_MAX_COLUMN;
                 const uint32_t* base = g == 0 ? a.lde[0] : g == 1 ? a.lde[1] : a.lde[2];
-                return base[(size_t)column * a.d + ((i + a.d - 4 * (size_t)back) & (a.d - 1))];
+                return base[(size_t)column * a.d + ((i + a.d - ((size_t)back << a.blow)) & (a.d - 1))];
             }
             case K_CONST:
                 return consts[idx];
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(WG) void program_kernel(EvalArgs a) {
             ln.store_mix(dst, t);
         }
     }
-    Ext tot = a.ret_slot == NONE ? bb::ext_zero() : bb::scale(ln.load_mix(a.ret_slot), a.inv_den[i & 3]);
+    Ext tot = a.ret_slot == NONE ? bb::ext_zero() : bb::scale(ln.load_mix(a.ret_slot), a.inv_den[i & ((1u << a.blow) - 1)]);
 #pragma unroll
     for (int e = 0; e < 4; e++) a.check[(size_t)e * a.d + i] = tot.c[e];
 }
@@ -445,13 +446,14 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     rk_program* pg = const_cast<rk_program*>(cprog);  // the device copy of the op list is cached inside
     if (!pg || !v || !v->ctx || !poly_mix || !d_check) return RK_ERR_INVALID;
     rk_ctx* ctx = v->ctx;
-    if (v->po2 < 1 || v->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
+    const unsigned blow = ctx->sys.blowup_log2;
+    if (v->po2 < 1 || v->po2 + blow > ntt::LAMBDA) return RK_ERR_INVALID;
     if (v->n_globals < pg->need_globals || v->n_mix < pg->need_mix) return RK_ERR_INVALID;
     if ((v->n_globals && !v->globals) || (v->n_mix && !v->mix)) return RK_ERR_INVALID;
     for (int g = 0; g < 3; g++)
         if (pg->group_min[g] && (!v->d_lde[g] || v->group_size[g] < pg->group_min[g])) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n = (size_t)1 << v->po2, d = 4 * n;
+    const size_t n = (size_t)1 << v->po2, d = n << blow;
     const uint32_t wm = ctx->sys.wm;
 
     EvalArgs a{};
@@ -494,9 +496,10 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     a.n_fp_slots = pg->n_fp_slots;
     a.ret_slot = pg->ret_slot;
     a.wm = wm;
-    // x_i^N for x_i = shift * w_D^i takes four values: shift^N * w_4^(i mod 4)
-    const uint32_t sn = bb::pow(ctx->sys.shiftm, n), w4 = bb::pow(ctx->sys.root27m, (uint64_t)1 << 25);
-    for (int r = 0; r < 4; r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(w4, r)), bb::ONE));
+    // x_i^N for x_i = shift * w_D^i takes D/N values: shift^N * w_(D/N)^(i mod D/N)
+    a.blow = blow;
+    const uint32_t sn = bb::pow(ctx->sys.shiftm, n), wb = bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - blow));
+    for (unsigned r = 0; r < (1u << blow); r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(wb, r)), bb::ONE));
     const size_t spill_words = ((size_t)(pg->n_fp_slots - a.lds_fp) + 4 * (size_t)(pg->n_mix_slots - a.lds_mix)) * d;
     void* d_spill = nullptr;
     if (spill_words) RK_TRY(dev_alloc(ctx, spill_words * 4, &d_spill));

@@ -312,6 +312,7 @@ int rk_get_params(rk_ctx* ctx, rk_params* out) {
     out->blowup_log2 = ctx->sys.blowup_log2;
     out->fri_fold_log2 = ctx->sys.fri_fold_log2;
     out->fri_min_degree = ctx->sys.fri_min_degree;
+    out->pow_bits = ctx->sys.pow_bits;
     return RK_OK;
     RK_GUARD_END
 }

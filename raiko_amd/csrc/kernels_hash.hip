@@ -2,6 +2,9 @@
 // MerkleTreeProver::new of risc0-zkp 1.0.1).  Integer-ALU-bound: one lane owns one
 // sponge (24 state words in VGPRs), consecutive lanes own consecutive rows so every
 // column load is a coalesced 256-byte wave access of the column-major matrix.
+#include <algorithm>
+#include <cstring>
+
 #include "internal.hpp"
 
 namespace {
@@ -99,6 +102,33 @@ __global__ __launch_bounds__(TAIL_MAX) void hash_fold_tail_kernel(uint32_t* __re
     }
 }
 
+// Proof of work on the transcript: candidate w = base + lane.  digest = hash([w]) (one block of the
+// sponge), the generator absorbs it (cells[0..8) += digest, permute) and the next four outputs,
+// decoded and xor-ed, must be zero in their low `bits` bits -- exactly what Transcript::commit and
+// p2::Rng::random_bits do with pool_used = 0.  The smallest hit of the launch wins (atomicMin).
+template <class C>
+__global__ __launch_bounds__(HASH_BLOCK) void pow_grind_kernel(uint32_t* __restrict__ best, const uint32_t* __restrict__ cells,
+                                                               uint32_t base, uint32_t count, uint32_t mask,
+                                                               const typename C::Consts* __restrict__ kc) {
+    const uint32_t gid = blockIdx.x * HASH_BLOCK + threadIdx.x;
+    if (gid >= count) return;
+    const typename C::Consts& k = *kc;
+    const uint32_t w = base + gid;
+    uint32_t s[C::CELLS];
+    s[0] = w;
+#pragma unroll
+    for (int i = 1; i < C::CELLS; i++) s[i] = 0;
+    C::permute(s, k);
+    uint32_t c[C::CELLS];
+#pragma unroll
+    for (int i = 0; i < C::CELLS; i++) c[i] = cells[i];
+#pragma unroll
+    for (int i = 0; i < p2::OUT; i++) c[i] = bb::add(c[i], s[i]);
+    C::permute(c, k);
+    const uint32_t v = bb::decode(c[0]) ^ bb::decode(c[1]) ^ bb::decode(c[2]) ^ bb::decode(c[3]);
+    if ((v & mask) == 0) atomicMin(best, w);
+}
+
 // run F<Core> for the context's Poseidon2 instance
 #define RK_P2_DISPATCH(ctx, CALL)                         \
     switch ((ctx)->h_p2.kind) {                           \
@@ -142,6 +172,39 @@ int merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_
     return RK_OK;
 }
 
+int pow_grind(rk_ctx* ctx, const uint32_t* h_cells, unsigned bits, uint32_t* nonce) {
+    if (bits == 0 || bits > 24 || !h_cells || !nonce) return RK_ERR_INVALID;
+    const unsigned width = (unsigned)ctx->h_p2.cells();
+    void* d = nullptr;
+    RK_TRY(scratch(ctx, (p2::MAX_CELLS + 4) * 4, &d));
+    uint32_t* d_cells = (uint32_t*)d;
+    uint32_t* d_best = d_cells + p2::MAX_CELLS;
+    uint32_t host[p2::MAX_CELLS + 1] = {0};
+    std::memcpy(host, h_cells, width * 4);
+    host[p2::MAX_CELLS] = 0xffffffffu;
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d, host, sizeof host, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `host` is a stack buffer
+    // 2^(bits + 2) candidates per launch: four hits expected, so one launch almost always; candidates run
+    // up to p (a nonce is a field element), far beyond what 24 bits need
+    const uint64_t batch = (uint64_t)1 << (bits + 2 < 16 ? 16 : bits + 2);
+    const uint32_t mask = (uint32_t)(((uint64_t)1 << bits) - 1);
+    for (uint64_t base = 0; base < bb::P; base += batch) {
+        const uint32_t count = (uint32_t)std::min<uint64_t>(batch, bb::P - base);
+        const unsigned blocks = (count + HASH_BLOCK - 1) / HASH_BLOCK;
+        RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(pow_grind_kernel<C>, dim3(blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_best, d_cells,
+                                               (uint32_t)base, count, mask, (const typename C::Consts*)ctx->d_p2));
+        RK_TRY(post_launch(ctx, "pow_grind_kernel"));
+        uint32_t best = 0;
+        RK_HIP_TRY(ctx, hipMemcpyAsync(&best, d_best, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != 0xffffffffu) {
+            *nonce = best;
+            return RK_OK;
+        }
+    }
+    return RK_ERR_INTERNAL;
+}
+
 int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
     if (!is_pow2(top_output_size) || top_output_size > TAIL_MAX) return RK_ERR_INVALID;
     unsigned threads = top_output_size < 64 ? 64u : (unsigned)top_output_size;
@@ -167,6 +230,13 @@ int rk_hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t input_size, size_t outpu
     if (!ctx || !d_nodes || input_size != 2 * output_size) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::hash_fold(ctx, d_nodes, output_size);
+    RK_GUARD_END
+}
+int rk_pow_grind(rk_ctx* ctx, const uint32_t* sponge_cells, uint32_t bits, uint32_t* nonce) {
+    RK_GUARD_BEGIN
+    if (!ctx || !sponge_cells || !nonce) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::pow_grind(ctx, sponge_cells, bits, nonce);
     RK_GUARD_END
 }
 int rk_merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols) {

@@ -5,6 +5,7 @@
 // provers/sp1/driver/src/lib.rs:48-57 -- both crates families are outside the reference tree).
 #pragma once
 #include "../../include/raiko_hip.h"
+#include "taps.hpp"
 #include "poseidon2_any.hpp"
 #include "poseidon2_consts.inc"
 
@@ -15,10 +16,9 @@ struct Sys {
     uint32_t root27m = 0;        // Montgomery form of the 2^27-subgroup generator
     uint32_t shiftm = 0;         // Montgomery form of the coset shift
     uint32_t ext_w = bb::P - 11, root_2_27 = 137, coset_shift = 3;
-    uint32_t queries = 50, blowup_log2 = 2, fri_fold_log2 = 4, fri_min_degree = 256;
+    uint32_t queries = 50, blowup_log2 = 2, fri_fold_log2 = 4, fri_min_degree = 256, pow_bits = 0;
     Sys() : root27m(bb::encode(137)), shiftm(bb::encode(3)) {}
-    // the whole-segment flow is risc0's: blow-up 4, fold 16, final degree 256
-    bool segment_flow_ok() const { return blowup_log2 == 2 && fri_fold_log2 == 4 && fri_min_degree == 256; }
+    Shape shape() const { return Shape{queries, blowup_log2, fri_fold_log2, fri_min_degree, pow_bits}; }
     bool is_default_field() const { return ext_w == bb::P - 11 && root_2_27 == 137 && coset_shift == 3; }
 };
 
@@ -36,6 +36,7 @@ inline void params_preset(rk_params* o, int preset) {
         o->blowup_log2 = 1;
         o->fri_fold_log2 = 1;
         o->fri_min_degree = 1;
+        o->pow_bits = 16;
     } else {
         o->ext_w = bb::P - 11u;
         o->root_2_27 = 137u;
@@ -47,6 +48,7 @@ inline void params_preset(rk_params* o, int preset) {
         o->blowup_log2 = 2;
         o->fri_fold_log2 = 4;
         o->fri_min_degree = 256;
+        o->pow_bits = 0;
     }
 }
 
@@ -60,6 +62,7 @@ inline int resolve_params(const rk_params* in, Sys* sys, p2::Any* p2any) {
     if (in->queries == 0 || in->queries > RK_MAX_QUERIES) return RK_ERR_INVALID;
     if (in->fri_fold_log2 < 1 || in->fri_fold_log2 > 4 || in->blowup_log2 < 1 || in->blowup_log2 > 4) return RK_ERR_INVALID;
     if (in->fri_min_degree == 0 || (in->fri_min_degree & (in->fri_min_degree - 1))) return RK_ERR_INVALID;
+    if (in->pow_bits > 24) return RK_ERR_INVALID;
     // x^4 - W irreducible over Fp (p = 1 mod 4)  <=>  W is not a square
     if (bb::pow(bb::encode(in->ext_w), (bb::P - 1) / 2) != bb::encode(bb::P - 1)) return RK_ERR_INVALID;
     const uint32_t r = bb::encode(in->root_2_27);
@@ -86,6 +89,7 @@ inline int resolve_params(const rk_params* in, Sys* sys, p2::Any* p2any) {
     sys->blowup_log2 = in->blowup_log2;
     sys->fri_fold_log2 = in->fri_fold_log2;
     sys->fri_min_degree = in->fri_min_degree;
+    sys->pow_bits = in->pow_bits;
     return RK_OK;
 }
 

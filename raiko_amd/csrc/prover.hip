@@ -153,16 +153,17 @@ void write_opening(Transcript& iop, const MerkleDev& m, const Openings& o, size_
 // ---------------------------------------------------------------- PolyGroup
 struct PolyGroup {
     DevBuf coeffs;     // count x size, natural order once built
-    DevBuf evaluated;  // count x size*4
+    DevBuf evaluated;  // count x size << blowup_log2
     size_t count = 0, size = 0;
     MerkleDev merkle;
     // coeffs must hold interpolated, zk-shifted, bit-reversed coefficients
     int build(rk_ctx* ctx, size_t cnt, size_t sz) {
         count = cnt;
         size = sz;
-        size_t domain = sz * 4;
+        const unsigned blow = ctx->sys.blowup_log2;
+        size_t domain = sz << blow;
         RK_TRY(evaluated.alloc(ctx, cnt * domain * 4));
-        RK_TRY(rk::ntt_forward(ctx, evaluated.u32(), coeffs.u32(), sz, cnt, 2));
+        RK_TRY(rk::ntt_forward(ctx, evaluated.u32(), coeffs.u32(), sz, cnt, blow));
         // risc0 bit-reverses the coefficients here (PolyGroup::new) because its later users
         // index them in natural order.  The device pipeline instead keeps them bit-reversed:
         // the tap evaluation multiplies by power tables stored in the same order and the
@@ -222,7 +223,8 @@ void poly_interpolate(Ext* out, const Ext* x, const Ext* fx, size_t n, uint32_t 
 int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& seal) {
     const rk_taps& taps = seg->taps;
     RK_TRY(rk::check_taps(taps));
-    if (seg->po2 < 1 || seg->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
+    const rk::Shape shape = ctx->sys.shape();
+    if (!rk::shape_ok(shape) || seg->po2 < 1 || seg->po2 + shape.blowup_log2 > ntt::LAMBDA) return RK_ERR_INVALID;
     const rk_circuit_hooks* hooks = seg->hooks;
     const bool hook_accum = hooks && hooks->accumulate, hook_check = hooks && (hooks->eval_check || hooks->program);
     for (int g = 0; g < 3; g++) {
@@ -232,13 +234,11 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     if ((!seg->check && !hook_check) || (seg->n_globals && !seg->globals)) return RK_ERR_INVALID;
     if (seg->n_accum_mix > (1u << 16)) return RK_ERR_INVALID;
 
-    // the flow is risc0's: blow-up 4, fold 16, final degree 256; field, hash and query count follow rk_params
-    if (!ctx->sys.segment_flow_ok()) {
-        ctx->last_error = "rk_prove_segment needs blowup_log2 = 2, fri_fold_log2 = 4, fri_min_degree = 256";
-        return RK_ERR_INVALID;
-    }
-    const size_t N = (size_t)1 << seg->po2, D = N * 4;
-    const size_t QUERIES = ctx->sys.queries, FRI_FOLD = 16, FRI_MIN_DEGREE = 256, CHECK_SIZE = 16;
+    // the flow is risc0's; its shape (blow-up, fold arity, final degree, queries, proof of work) follows rk_params
+    const unsigned BLOW = shape.blowup_log2;
+    const size_t N = (size_t)1 << seg->po2, D = N << BLOW;
+    const size_t QUERIES = shape.queries, FRI_FOLD = (size_t)1 << shape.fold_log2, FRI_MIN_DEGREE = shape.min_degree;
+    const size_t CHECK_SIZE = (size_t)4 << BLOW;
     const uint32_t wm = ctx->sys.wm;
     const p2::Any& kc = ctx->h_p2;
     Transcript iop(&kc);
@@ -365,9 +365,10 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         RK_TRY(load_trace(check.coeffs, seg->check, 4 * D));  // pre-computed stand-in
     }
     sw.start();
-    // 4 x D evaluations -> 4 x D bit-reversed coefficients = 16 columns of N: quarter c of plane e
-    // holds the coefficients n with n mod 4 = bitrev2(c) of component e, i.e. check(x) =
-    // sum_j x^j g_j(x^4) with g_j in column 4e + bitrev2(j) (the verifier's remap [0,2,1,3]).
+    // 4 x D evaluations -> 4 x D bit-reversed coefficients = 4 * D/N columns of N (16 for blow-up 4):
+    // part c of plane e holds the coefficients n with n mod D/N = bitrev(c) of component e, i.e.
+    // check(x) = sum_j x^j g_j(x^(D/N)) with g_j in column (D/N) e + bitrev(j) (for blow-up 4 the
+    // verifier's remap [0,2,1,3]).
     // No zk_shift here: the hook evaluates at x_i = 3*w^i, so these already are the coefficients
     // of y -> check(3y), the form every PolyGroup is kept in (recalled items).
     RK_TRY(rk::ntt_reverse(ctx, check.coeffs.u32(), D, 4, false));
@@ -382,7 +383,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     Ext z = iop.random_ext();
     uint32_t w27 = ctx->sys.root27m;
     uint32_t back_one = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - seg->po2)));
-    Ext z_pow = bb::pow(z, 4, wm);
+    Ext z_pow = bb::pow(z, (uint64_t)1 << BLOW, wm);
 
     // tap openings: every register at z * back_one^back for each of its backs
     size_t tot_taps = 0;
@@ -392,7 +393,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     for (uint32_t b = 0; b < taps.combo_off[taps.n_combos]; b++)
         if (taps.combo_backs[b] > max_back) max_back = taps.combo_backs[b];
     if (max_back > 64) return RK_ERR_INVALID;
-    // device power tables: slot b = (z*back_one^b)^k, slot max_back+1 = (z^4)^k
+    // device power tables: slot b = (z*back_one^b)^k, slot max_back+1 = (z^(D/N))^k
     size_t n_pts = (size_t)max_back + 2;
     std::vector<Ext> pts(n_pts);
     for (uint32_t b = 0; b <= max_back; b++) pts[b] = bb::scale(z, bb::pow(back_one, b));
@@ -550,12 +551,12 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     const uint32_t* cur_coeffs = final_poly.u32();
     size_t cur_words = N * 4;
     const size_t orig_domain = D;
-    while (cur_words / 4 > FRI_MIN_DEGREE) {
+    while (cur_words / 4 > FRI_MIN_DEGREE && cur_words / 4 >= FRI_FOLD) {
         std::unique_ptr<Round> r(new Round());
-        size_t size = cur_words / 4, domain = size * 4;
+        size_t size = cur_words / 4, domain = size << BLOW;
         r->domain = domain;
         RK_TRY(r->evaluated.alloc(ctx, domain * 16));
-        RK_TRY(rk::ntt_forward(ctx, r->evaluated.u32(), cur_coeffs, size, 4, 2));
+        RK_TRY(rk::ntt_forward(ctx, r->evaluated.u32(), cur_coeffs, size, 4, BLOW));
         RK_TRY(r->merkle.build(ctx, r->evaluated.u32(), domain / FRI_FOLD, FRI_FOLD * 4, QUERIES));
         RK_TRY(r->merkle.commit(ctx, iop));
         Ext fold_mix = iop.random_ext();
@@ -576,6 +577,16 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         iop.write(h.data(), h.size());
         kc.hash_elems(h.data(), h.size(), digest);
         iop.commit(digest);
+    }
+    if (shape.pow_bits) {
+        // proof of work before the query positions exist (Plonky3 `grind`; risc0's parameter set has none):
+        // the nonce goes into the seal and, hashed, into the transcript
+        uint32_t nonce = 0;
+        RK_TRY(rk::pow_grind(ctx, iop.rng.cells, shape.pow_bits, &nonce));
+        iop.write(&nonce, 1);
+        kc.hash_elems(&nonce, 1, digest);
+        iop.commit(digest);
+        if (iop.random_bits(shape.pow_bits) != 0) return RK_ERR_INTERNAL;
     }
     sw.stop(&ctx->timing.fri);
 
@@ -610,7 +621,12 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
 extern "C" {
 
 size_t rk_seal_bound_words(const rk_segment* seg) { return rk::seal_bound_words(seg); }
-size_t rk_seal_bound_words_for(const rk_segment* seg, uint32_t queries) { return rk::seal_bound_words(seg, queries); }
+size_t rk_seal_bound_words_for(const rk_segment* seg, uint32_t queries) { return rk::seal_bound_words(seg, (size_t)queries); }
+size_t rk_seal_bound_words_params(const rk_segment* seg, const rk_params* params) {
+    if (!params || params->struct_size != sizeof(rk_params)) return 0;
+    return rk::seal_bound_words(seg, rk::Shape{params->queries, params->blowup_log2, params->fri_fold_log2, params->fri_min_degree,
+                                               params->pow_bits});
+}
 
 int rk_prove_segment(rk_ctx* ctx, const rk_segment* seg, uint32_t* h_seal, size_t cap, size_t* seal_words) {
     RK_GUARD_BEGIN

@@ -97,7 +97,6 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     if (!pub || !seal) return RK_ERR_INVALID;
     const rk_taps& taps = pub->taps;
     if (rk::check_taps(taps) != RK_OK) return RK_ERR_INVALID;
-    if (pub->po2 < 1 || pub->po2 + 2 > ntt::LAMBDA) return RK_ERR_INVALID;
     if (pub->n_globals && !pub->globals) return RK_ERR_INVALID;
     if (pub->n_accum_mix > (1u << 16)) return RK_ERR_INVALID;
     // parameter set: opts->params (the whole blob), else the three width-24 tables of ABI 1, else the defaults
@@ -117,10 +116,12 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
         if (rk::resolve_params(&pp, &sys, custom.get()) != RK_OK) return RK_ERR_INVALID;
         kp = custom.get();
     }
-    if (!sys.segment_flow_ok()) return RK_ERR_INVALID;
+    const rk::Shape shape = sys.shape();
+    if (!rk::shape_ok(shape) || pub->po2 < 1 || pub->po2 + shape.blowup_log2 > ntt::LAMBDA) return RK_ERR_INVALID;
     const p2::Any& k = *kp;
     const uint32_t wm = sys.wm;
-    const size_t QUERIES = sys.queries, FOLD = 16, MIN_DEGREE = 256, CHECK = 16;
+    const unsigned BLOW = shape.blowup_log2, FOLD_LOG = shape.fold_log2;
+    const size_t QUERIES = shape.queries, FOLD = (size_t)1 << FOLD_LOG, MIN_DEGREE = shape.min_degree, CHECK = (size_t)4 << BLOW;
     Reader r{seal, seal_words};
     Sponge rng(&k);
     uint32_t digest[8], e16[16];
@@ -141,7 +142,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     k.hash_elems(io.data(), io.size(), digest);
     rng.mix(digest);
 
-    const size_t N = (size_t)1 << po2, D = 4 * N;
+    const size_t N = (size_t)1 << po2, D = N << BLOW;
     TreeVerifier tg[3], tcheck;
     tg[1].init(k, r, rng, D, taps.group_size[1], QUERIES);
     tg[2].init(k, r, rng, D, taps.group_size[2], QUERIES);
@@ -187,13 +188,14 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
                                         pub->n_globals, accum_mix.data(), pub->n_accum_mix, result.c) != RK_OK) {
             return 71;
         }
-        static const int remap[4] = {0, 2, 1, 3};
+        // part j of the check polynomial sits in column bitrev(j) of each component ([0,2,1,3] for blow-up 4)
+        const size_t parts = (size_t)1 << BLOW;
         Ext check = bb::ext_zero(), zi = bb::ext_one();
-        for (int i = 0; i < 4; i++) {
+        for (size_t i = 0; i < parts; i++) {
             for (int e = 0; e < 4; e++) {
                 Ext basis = bb::ext_zero();
                 basis.c[e] = bb::ONE;
-                check = bb::add(check, bb::mul(bb::mul(coeff_u[tot_taps + remap[i] + 4 * e], zi, wm), basis, wm));
+                check = bb::add(check, bb::mul(bb::mul(coeff_u[tot_taps + bb::bitrev((uint32_t)i, BLOW) + parts * e], zi, wm), basis, wm));
             }
             zi = bb::mul(zi, z, wm);
         }
@@ -218,7 +220,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
             cur = bb::mul(cur, mix, wm);
         }
     }
-    const Ext z_pow = bb::pow(z, 4, wm);
+    const Ext z_pow = bb::pow(z, (uint64_t)1 << BLOW, wm);
 
     // FRI commitments
     struct Round {
@@ -228,7 +230,7 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     };
     std::vector<Round> rounds;
     size_t degree = N, domain = D;
-    while (degree > MIN_DEGREE) {
+    while (degree > MIN_DEGREE && degree >= FOLD) {
         rounds.emplace_back();
         Round& rd = rounds.back();
         rd.domain = domain;
@@ -242,14 +244,23 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     k.hash_elems(final_coeffs.data(), final_coeffs.size(), digest);
     rng.mix(digest);
     if (r.short_read) return 60;
+    if (shape.pow_bits) {  // proof of work: the nonce, absorbed, must zero the next pow_bits random bits (reason 62)
+        uint32_t nonce = 0;
+        r.read(&nonce, 1);
+        if (r.short_read) return 60;
+        if (nonce >= bb::P) return 62;
+        k.hash_elems(&nonce, 1, digest);
+        rng.mix(digest);
+        if (rng.random_bits(shape.pow_bits) != 0) return 62;
+    }
 
     const uint32_t gen0 = bb::pow(w27, (uint64_t)1 << (27 - log2u(D)));
     const uint32_t gen_final = bb::pow(w27, (uint64_t)1 << (27 - log2u(domain)));
-    const uint32_t w16_inv = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - 4)));
-    const uint32_t inv16 = bb::inv(bb::encode(16));
+    const uint32_t w16_inv = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - FOLD_LOG)));   // inverse of the FOLD-th root
+    const uint32_t inv16 = bb::inv(bb::encode((uint32_t)FOLD));
     std::vector<uint32_t> row[3];
     for (int g = 0; g < 3; g++) row[g].resize(taps.group_size[g] + 1);
-    uint32_t check_row[16];
+    uint32_t check_row[64];
     std::vector<Ext> tot(taps.n_combos + 1);
 
     for (size_t q = 0; q < QUERIES; q++) {
@@ -285,20 +296,20 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
             size_t rows = rd.domain / FOLD;
             size_t quot = pos / rows, group = pos % rows;
             uint32_t data[64];
-            if (!rd.tree.open(k, r, group, data)) return r.short_read ? 60 : 30 + (int)kr;
+            if (!rd.tree.open(k, r, group, data)) return r.short_read ? 60 : 30 + (int)(kr < 9 ? kr : 9);
             Ext de[16];
-            for (int i = 0; i < 16; i++)
-                for (int c = 0; c < 4; c++) de[i].c[c] = data[c * 16 + i];
-            if (!bb::eq(de[quot], goal)) return 40 + (int)kr;
-            // interpolate the 16 coset values and evaluate at mix * w^-group
+            for (size_t i = 0; i < FOLD; i++)
+                for (int c = 0; c < 4; c++) de[i].c[c] = data[c * FOLD + i];
+            if (!bb::eq(de[quot], goal)) return 40 + (int)(kr < 9 ? kr : 9);
+            // interpolate the FOLD coset values and evaluate at mix * w^-group
             Ext co[16];
-            for (int i = 0; i < 16; i++) {
+            for (size_t i = 0; i < FOLD; i++) {
                 Ext acc = bb::ext_zero();
-                for (int j = 0; j < 16; j++) acc = bb::add(acc, bb::scale(de[j], bb::pow(w16_inv, (uint64_t)((i * j) & 15))));
+                for (size_t j = 0; j < FOLD; j++) acc = bb::add(acc, bb::scale(de[j], bb::pow(w16_inv, (uint64_t)((i * j) & (FOLD - 1)))));
                 co[i] = bb::scale(acc, inv16);
             }
             uint32_t inv_wk = bb::pow(bb::inv(bb::pow(w27, (uint64_t)1 << (27 - log2u(rd.domain)))), group);
-            goal = poly_eval(co, 16, bb::scale(rd.mix, inv_wk), wm);
+            goal = poly_eval(co, FOLD, bb::scale(rd.mix, inv_wk), wm);
             pos = group;
         }
         const Ext xf = bb::ext_from(bb::pow(gen_final, pos));

@@ -205,7 +205,8 @@ class HipHal:
         c_seg, keep = make_c_segment(seg, device_inputs)
         if consume_inputs and device_inputs is not None:
             c_seg.on_device = 2
-        cap = int(self._lib.rk_seal_bound_words_for(C.byref(c_seg), self.get_params().queries))
+        prm = self.get_params()
+        cap = int(self._lib.rk_seal_bound_words_params(C.byref(c_seg), C.byref(prm)))
         if cap == 0:  # malformed shape / tap set: nothing is allocated for it
             raise _lib.RkError(_lib.RK_ERR_INVALID, "invalid argument (segment shape or tap set)")
         seal = np.empty(cap, dtype=np.uint32)
@@ -417,7 +418,7 @@ def make_c_segment(seg: Segment, device_inputs=None):
             c.group[g] = a.ctypes.data
         if seg.check is not None:
             chk = np.ascontiguousarray(seg.check, dtype=np.uint32)
-            assert chk.shape == (4, 4 * seg.rows)
+            assert chk.shape[0] == 4 and chk.shape[1] % seg.rows == 0   # 4 x (rows << blowup_log2)
             keep.append(chk)
             c.check = chk.ctypes.data
     gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)

@@ -115,10 +115,11 @@ class Segment:
 
 
 def synthetic_segment(po2: int, widths: Tuple[int, int, int] = (16, 16, 224), seed: int = 20240807,
-                      n_globals: int = 32) -> Segment:
+                      n_globals: int = 32, blowup_log2: int = 2) -> Segment:
     """One synthetic segment of 2^po2 cycles: i.i.d. uniform field elements (already in Montgomery
     form: the uniform distribution is invariant under the encoding), numpy PCG64 seeds
-    seed + group index; check evaluations from seed + 3; globals from seed + 4."""
+    seed + group index; check evaluations from seed + 3; globals from seed + 4.  `blowup_log2`: the
+    check evaluations live on the LDE domain of 2^(po2 + blowup_log2) points (rk_params.blowup_log2)."""
     taps = synthetic_tapset(*widths)
     n = 1 << po2
     groups = []
@@ -126,7 +127,7 @@ def synthetic_segment(po2: int, widths: Tuple[int, int, int] = (16, 16, 224), se
         rng = np.random.Generator(np.random.PCG64(seed + g))
         groups.append(rng.integers(0, P, size=(w, n), dtype=np.uint32))
     rng = np.random.Generator(np.random.PCG64(seed + 3))
-    check = rng.integers(0, P, size=(EXT, INV_RATE * n), dtype=np.uint32)
+    check = rng.integers(0, P, size=(EXT, n << blowup_log2), dtype=np.uint32)
     rng = np.random.Generator(np.random.PCG64(seed + 4))
     globals_ = rng.integers(0, P, size=(n_globals,), dtype=np.uint32)
     return Segment(po2=po2, taps=taps, groups=groups, check=check, globals_=globals_)

@@ -56,12 +56,17 @@ class OrProgram(C.Structure):
     _fields_ = [("steps", C.c_void_p), ("n_steps", C.c_size_t), ("ret", C.c_uint32), ("taps", C.POINTER(OrTaps))]
 
 
+class OrIop(C.Structure):
+    _fields_ = [("proof", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t), ("cells", C.c_uint32 * 24),
+                ("pool_used", C.c_size_t)]
+
+
 class OrParams(C.Structure):
     _fields_ = [("ext_w", C.c_uint32), ("root_2_27", C.c_uint32), ("coset_shift", C.c_uint32),
                 ("p2_width", C.c_uint32), ("p2_m4", C.c_uint32), ("p2_pad_free", C.c_uint32),
                 ("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p),
                 ("queries", C.c_uint32), ("blowup_log2", C.c_uint32), ("fri_fold_log2", C.c_uint32),
-                ("fri_min_degree", C.c_uint32)]
+                ("fri_min_degree", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
 class OrTiming(C.Structure):
@@ -122,6 +127,7 @@ def oracle():
             "or_set_fast": (None, [C.c_int]), "or_get_fast": (C.c_int, []),
             "or_params_preset": (None, [C.POINTER(OrParams), C.c_int]), "or_set_params": (C.c_int, [C.POINTER(OrParams)]),
             "or_prefix_products": (None, [vp, sz]),
+            "or_pow_grind": (u32, [vp, C.c_uint]),
             "or_scatter": (None, [vp, vp, sz, vp, vp]),
             "or_free": (None, [vp]), "or_max_threads": (C.c_int, []), "or_set_threads": (None, [C.c_int]),
             "or_last_timing": (None, [C.POINTER(OrTiming)]),

@@ -175,14 +175,96 @@ def test_segment_seal_under_other_parameters(cfg, kw):
         assert verify_segment(seg, bad, params=blob) != 0
 
 
-def test_protocol_shapes_the_segment_flow_refuses(cfg):
+SHAPES = [
+    dict(blowup_log2=1, fri_fold_log2=1, fri_min_degree=1, queries=100, pow_bits=12),
+    dict(blowup_log2=3, fri_fold_log2=2, fri_min_degree=16, queries=20),
+    dict(blowup_log2=1, fri_fold_log2=3, fri_min_degree=4, queries=33, pow_bits=8),
+    dict(blowup_log2=4, fri_fold_log2=4, fri_min_degree=64, queries=9),
+    dict(blowup_log2=2, fri_fold_log2=1, fri_min_degree=256, queries=50, pow_bits=5),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES + ["sp1"])
+def test_segment_seal_under_other_protocol_shapes(cfg, shape):
+    """blow-up, FRI fold arity, final degree, queries and proof of work are parameters of the segment flow:
+    under each shape -- the last one is SP1 core's whole parameter set (blow-up 2, fold 2 down to a constant,
+    100 queries, 16 proof-of-work bits, Poseidon2 width 16, x^4 - 11) -- the GPU seal is the oracle's word for
+    word and both verifiers accept it under that blob only"""
     h, apply = cfg
-    h.set_params(_lib.RK_PRESET_SP1)                   # blow-up 2, fold 2: served by the operators only
-    with pytest.raises(_lib.RkError) as ei:
-        h.prove_segment(synthetic_segment(6, (2, 2, 3), seed=1))
-    assert ei.value.status == -1
-    for bad in (dict(ext_w=4), dict(root_2_27=3), dict(p2_width=20), dict(queries=0), dict(fri_fold_log2=0)):
+    blob = apply(1) if shape == "sp1" else apply(**shape)
+    blow = 1 if shape == "sp1" else shape["blowup_log2"]
+    for po2, widths in ((5, (2, 2, 3)), (10, (4, 4, 12)), (13, (16, 16, 40))):
+        seg = synthetic_segment(po2, widths, seed=41 + po2, blowup_log2=blow)
+        want = o.oracle_prove(seg)
+        got = h.prove_segment(seg)
+        assert got.size == want.size and np.array_equal(got, want), (po2, shape)
+        assert o.oracle_verify(seg, got) == 0
+        assert verify_segment(seg, got, params=blob) == 0
+        assert verify_segment(seg, got) != 0
+        bad = got.copy()
+        bad[got.size // 3] ^= 1
+        assert verify_segment(seg, bad, params=blob) != 0
+
+
+@pytest.mark.parametrize("bits", [1, 7, 12, 16])
+@pytest.mark.parametrize("kw", [dict(), SP1_HASH])
+def test_pow_grind_matches_the_literal_search(cfg, orc, bits, kw):
+    """rk_pow_grind (one lane per candidate) returns the nonce the oracle finds by trying 0, 1, 2, ..."""
+    import ctypes as C
+    h, apply = cfg
+    apply(**kw)
+    rng = np.random.default_rng(bits)
+    width = 16 if kw else 24
+    iop = o.OrIop()
+    cells = o.rand_elems(rng, (width,))
+    for i in range(width):
+        iop.cells[i] = int(cells[i])
+    want = orc.or_pow_grind(C.byref(iop), bits)
+    nonce = C.c_uint32(0)
+    _lib.check(h._ctx, h._lib.rk_pow_grind(h._ctx, cells.ctypes.data_as(_lib.u32p), bits, C.byref(nonce)))
+    assert nonce.value == want
+
+
+def test_toy_circuit_under_sp1_parameters(cfg):
+    """the toy circuit (constraint degree 3: fits blow-up 2) proven under SP1 core's whole parameter set, with
+    eval_check from its step list (built for x^4 - 11) and the constraint identity checked by both verifiers"""
+    from raiko_amd import circuit_program as cp, toy_circuit
+    toy_circuit.load()
+    h, apply = cfg
+    blob = apply(1)
+    for po2 in (6, 11):
+        seg = toy_circuit.toy_segment(po2, (8, 4, 8), seed=90 + po2)
+        seg.program = cp.Program(*cp.toy_program(seg.taps, seg.n_accum_mix, ext_w=11), seg.taps)
+        want = o.oracle_prove(seg)
+        got = h.prove_segment(seg)
+        assert np.array_equal(got, want)
+        from raiko_amd.hal import make_verify_opts
+        assert verify_segment(seg, got, params=blob, program=seg.program) == 0
+        assert o.oracle_verify(seg, got, toy_identity=True) == 0
+    bad = toy_circuit.toy_segment(7, (8, 4, 8), seed=3, break_row=9)
+    bad.program = cp.Program(*cp.toy_program(bad.taps, bad.n_accum_mix, ext_w=11), bad.taps)
+    seal = h.prove_segment(bad)
+    assert verify_segment(bad, seal, params=blob) == 0
+    assert verify_segment(bad, seal, params=blob, program=bad.program) == 70
+
+
+def test_parameter_sets_the_library_refuses(cfg):
+    h, apply = cfg
+    h.set_params(_lib.RK_PRESET_SP1)
+    for bad in (dict(ext_w=4), dict(root_2_27=3), dict(p2_width=20), dict(queries=0), dict(fri_fold_log2=0), dict(blowup_log2=5),
+                dict(fri_min_degree=48), dict(pow_bits=25)):
         with pytest.raises(_lib.RkError):
             h.set_params(0, **bad)
     # a refused blob leaves the context as it was
     assert h.get_params().p2_width == 16 and h.get_params().ext_w == 11
+    # a segment too large for the blow-up's domain is refused, not truncated
+    import ctypes as C
+    from raiko_amd.hal import make_c_segment
+    blob = h.set_params(0, blowup_log2=4)
+    c_seg, keep = make_c_segment(synthetic_segment(4, (2, 2, 3), seed=1, blowup_log2=4))
+    assert h._lib.rk_seal_bound_words_params(C.byref(c_seg), C.byref(blob)) > 0
+    c_seg.po2 = 21
+    assert h._lib.rk_seal_bound_words_params(C.byref(c_seg), C.byref(blob)) == 0
+    words = C.c_size_t(0)
+    buf = np.zeros(16, dtype=np.uint32)
+    assert h._lib.rk_prove_segment(h._ctx, C.byref(c_seg), buf.ctypes.data_as(_lib.u32p), 16, C.byref(words)) == -1

@@ -240,11 +240,66 @@ def test_segment_flow_under_other_parameters(params, kw):
     o.oracle_set_params()
     assert o.oracle_verify(seg, seal) != 0            # not a proof under risc0's parameters
     assert np.array_equal(o.oracle_prove(seg), base)  # and the defaults are back
-    # SP1's own protocol shape (blow-up 2, fold 2) is served by the operators, not by the segment flow
-    o.oracle_set_params(1)
-    with pytest.raises(RuntimeError):
-        o.oracle_prove(seg)
-    o.oracle_set_params()
+
+
+SHAPES = [
+    dict(blowup_log2=1, fri_fold_log2=1, fri_min_degree=1, queries=100, pow_bits=12),
+    dict(blowup_log2=3, fri_fold_log2=2, fri_min_degree=16, queries=20),
+    dict(blowup_log2=1, fri_fold_log2=3, fri_min_degree=4, queries=33, pow_bits=8),
+    dict(blowup_log2=4, fri_fold_log2=4, fri_min_degree=64, queries=9),
+    dict(blowup_log2=2, fri_fold_log2=1, fri_min_degree=256, queries=50, pow_bits=5),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES + ["sp1"])
+def test_segment_flow_under_other_protocol_shapes(params, shape):
+    """blow-up, FRI fold arity, final degree, query count and proof of work are parameters of the segment
+    flow (SP1 core = blow-up 2, fold 2, 100 queries, 16 proof-of-work bits, Poseidon2 width
+    16, x^4 - 11).  The oracle proves and verifies under each, and the product's verifier -- host code,
+    independent of the oracle -- accepts the oracle's seal from the same parameter blob."""
+    from raiko_amd import hal
+    from raiko_amd.segment import synthetic_segment
+    if shape == "sp1":
+        params(1)
+        blob = hal.make_params(1)
+        blow = 1
+    else:
+        params(**shape)
+        blob = hal.make_params(0, **shape)
+        blow = shape["blowup_log2"]
+    seg = synthetic_segment(8, (4, 4, 12), seed=78, blowup_log2=blow)
+    seal = o.oracle_prove(seg)
+    assert o.oracle_verify(seg, seal) == 0
+    assert hal.verify_segment(seg, seal, params=blob) == 0
+    assert hal.verify_segment(seg, seal) != 0             # not a proof under risc0's parameters
+    bad = seal.copy()
+    bad[seal.size // 2] ^= 1
+    assert o.oracle_verify(seg, bad) != 0 and hal.verify_segment(seg, bad, params=blob) != 0
+    pow_bits = 16 if shape == "sp1" else shape.get("pow_bits", 0)
+    if pow_bits:
+        # the nonce follows the final polynomial; any other value fails the proof-of-work check
+        lib = o.oracle()
+        n_final = None
+        for off in range(seal.size):                       # find it by its defining property instead of by layout
+            t = seal.copy()
+            t[off] = (int(t[off]) + 1) % P
+            if hal.verify_segment(seg, t, params=blob) == 62:
+                n_final = off
+                break
+        assert n_final is not None
+        assert o.oracle_verify(seg, t) == 62
+
+
+def test_pow_grind_is_the_smallest_nonce(params, orc):
+    from raiko_amd.segment import synthetic_segment
+    params(pow_bits=10)
+    seg = synthetic_segment(6, (4, 4, 8), seed=5)
+    seal = o.oracle_prove(seg)
+    assert o.oracle_verify(seg, seal) == 0
+    # expected number of trials 2^10: the smallest valid nonce is far below p
+    params(pow_bits=0)
+    plain = o.oracle_prove(seg)
+    assert seal.size == plain.size + 1
 
 
 def test_product_param_blob_validation():
@@ -260,10 +315,11 @@ def test_product_param_blob_validation():
     assert lib.rk_params_preset(C.byref(p), 7) == -1
     seg = synthetic_segment(5, (2, 2, 3), seed=1)
     seal = np.zeros(50, dtype=np.uint32)
-    for bad in (dict(ext_w=4), dict(root_2_27=3), dict(p2_width=20), dict(queries=0), dict(fri_fold_log2=5)):
+    for bad in (dict(ext_w=4), dict(root_2_27=3), dict(p2_width=20), dict(queries=0), dict(fri_fold_log2=5), dict(blowup_log2=0), dict(blowup_log2=5),
+                dict(fri_min_degree=48), dict(pow_bits=25)):
         assert hal.verify_segment(seg, seal, params=hal.make_params(0, **bad)) == -1
     bad_size = hal.make_params(0)
     bad_size.struct_size = 8
     assert hal.verify_segment(seg, seal, params=bad_size) == -1
-    assert hal.verify_segment(seg, seal, params=hal.make_params(1)) == -1      # SP1's protocol shape: not this flow
+    assert hal.verify_segment(seg, seal, params=hal.make_params(1)) > 0        # SP1's set is a valid one: the all-zero seal is just not a proof
     assert hal.verify_segment(seg, seal, params=hal.make_params(0, queries=100)) > 0   # parsed; the seal is just wrong

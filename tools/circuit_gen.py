@@ -183,7 +183,7 @@ def generate(steps, ret, taps, name, chunk=300, host_inline_limit=2000) -> str:
                     lines.append("    const uint32_t %s = 0x%08xu;" % (nm, mont(v["a"])))
                 elif v["op"] == GET:
                     g, off, back = flat[v["a"]]
-                    idx = "i" if back == 0 else "((i + a.d - %du) & (a.d - 1))" % (4 * back)
+                    idx = "i" if back == 0 else "((i + a.d - ((size_t)%du << a.blow)) & (a.d - 1))" % back
                     lines.append("    const uint32_t %s = a.lde[%d][(size_t)%du * a.d + %s];" % (nm, g, off, idx))
                 else:
                     lines.append("    const uint32_t %s = tab[a.%s_base + %du];" % (nm, "glob" if v["a"] == 0 else "mix", v["b"]))
@@ -320,7 +320,8 @@ struct Args {{
     uint32_t* check;
     size_t d;
     uint32_t glob_base, mix_base, pw_base, wm;
-    uint32_t inv_den[4];
+    uint32_t blow;       // log2 of the blow-up (rk_params.blowup_log2)
+    uint32_t inv_den[16];
 }};
 
 __device__ __forceinline__ Ext load_pw(const_u32 tab, uint32_t base, uint32_t j) {{
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void {name}_kernel(Args a) {{
     uint32_t c[{n_c}];   // values that travel between the functions
     Ext cx[{n_cx}];
 {calls}
-    const Ext tot = bb::scale({result}, a.inv_den[i & 3]);
+    const Ext tot = bb::scale({result}, a.inv_den[i & ((1u << a.blow) - 1)]);
 #pragma unroll
     for (int e = 0; e < 4; e++) a.check[(size_t)e * a.d + i] = tot.c[e];
 }}
@@ -354,8 +355,9 @@ int {name}_eval_check(void*, const rk_circuit_view* v, const uint32_t poly_mix[4
     rk_params prm;
     if (rk_get_params(v->ctx, &prm) != RK_OK) return 2;
     const uint32_t wm = bb::encode(prm.ext_w);
-    const size_t n = (size_t)1 << v->po2, d = 4 * n;
+    const size_t n = (size_t)1 << v->po2, d = n << prm.blowup_log2;
     Args a{{}};
+    a.blow = prm.blowup_log2;
     for (int g = 0; g < 3; g++) a.lde[g] = v->d_lde[g];
     a.check = d_check;
     a.d = d;
@@ -375,8 +377,8 @@ int {name}_eval_check(void*, const rk_circuit_view* v, const uint32_t poly_mix[4
         std::memcpy(&tab[a.pw_base + 4 * j], cur.c, 16);
     }}
     const uint32_t sn = bb::pow(bb::encode(prm.coset_shift), n);
-    const uint32_t w4 = bb::pow(bb::encode(prm.root_2_27), (uint64_t)1 << 25);
-    for (int r = 0; r < 4; r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(w4, r)), bb::ONE));
+    const uint32_t wb = bb::pow(bb::encode(prm.root_2_27), (uint64_t)1 << (27 - prm.blowup_log2));
+    for (uint32_t r = 0; r < (1u << prm.blowup_log2); r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(wb, r)), bb::ONE));
     void* d_tab = nullptr;
     if (rk_alloc(v->ctx, tab.size() * 4, &d_tab) != RK_OK) return 3;
     int rc = rk_h2d(v->ctx, d_tab, tab.data(), tab.size() * 4) == RK_OK ? 0 : 4;   // synchronises: `tab` may go
