@@ -45,13 +45,17 @@ def parse_args():
     ap.add_argument("--total-segments", type=int, default=0,
                     help="strong scaling: this many segments in all, sharded round-robin over the ranks "
                          "(--steps is then ignored); default 0 = every rank proves --steps segments (weak)")
+    ap.add_argument("--preset", choices=["risc0", "sp1"], default="risc0",
+                    help="parameter set of the proofs (rk_session_opts.params): sp1 = SP1 core's RECALLED set -- x^4 - 11, "
+                         "Poseidon2 width 16, blow-up 2, FRI fold 2 down to a constant, 100 queries, 16 proof-of-work bits; "
+                         "the contract line is risc0's")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (value_with_h2d) run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="leave rk_verify_segment out of the timed region")
     return ap.parse_args()
 
 
-def device_segment(torch, seg_mod, po2, widths, seed, device):
+def device_segment(torch, seg_mod, po2, widths, seed, device, blowup_log2=2):
     """A synthetic segment whose O(trace) inputs live in HBM; small metadata on the host."""
     import numpy as np
     P = seg_mod.P
@@ -59,7 +63,7 @@ def device_segment(torch, seg_mod, po2, widths, seed, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     groups = [torch.randint(0, P, (w, n), dtype=torch.int32, device=device, generator=g) for w in widths]
-    check = torch.randint(0, P, (4, 4 * n), dtype=torch.int32, device=device, generator=g)
+    check = torch.randint(0, P, (4, n << blowup_log2), dtype=torch.int32, device=device, generator=g)
     rng = np.random.Generator(np.random.PCG64(seed))
     seg = seg_mod.Segment(po2=po2, taps=seg_mod.synthetic_tapset(*widths), groups=[None, None, None], check=None,
                           globals_=rng.integers(0, P, size=(32,), dtype=np.uint32))
@@ -78,7 +82,9 @@ def main():
     import torch.distributed as dist
     from raiko_amd import segment as seg_mod
     from raiko_amd.dist import gather_seals, shard_indices
-    from raiko_amd.hal import HipHal, prove_session, session_kernel_stats, session_set_kernel_timing, verify_segment
+    from raiko_amd.hal import HipHal, make_params, prove_session, session_kernel_stats, session_set_kernel_timing, verify_segment
+    blob = make_params(1) if args.preset == "sp1" else None
+    blow = blob.blowup_log2 if blob is not None else 2
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -103,7 +109,7 @@ def main():
     inflight = max(1, min(args.inflight, max(my_steps, 1)))
 
     # two distinct resident segments per rank, alternated, so no step sees data it just proved
-    segs = [device_segment(torch, seg_mod, args.po2, widths, 20240807 + 1000 * rank + i, device) for i in range(2)]
+    segs = [device_segment(torch, seg_mod, args.po2, widths, 20240807 + 1000 * rank + i, device, blow) for i in range(2)]
     torch.cuda.synchronize()
 
     def session(n, host=None, verify=not args.no_verify):
@@ -113,9 +119,9 @@ def main():
             return []
         if host is not None:
             return prove_session([host[i % 2] for i in range(n)], device=gpu_index, inflight=inflight,
-                                 upload_ahead=args.upload_ahead, verify=verify)
+                                 upload_ahead=args.upload_ahead, verify=verify, params=blob)
         return prove_session([segs[i % 2][0] for i in range(n)], device=gpu_index, inflight=inflight,
-                             upload_ahead=args.upload_ahead, verify=verify,
+                             upload_ahead=args.upload_ahead, verify=verify, params=blob,
                              device_inputs=[(segs[i % 2][1], segs[i % 2][2]) for i in range(n)])
 
     def barrier():
@@ -133,6 +139,8 @@ def main():
     # the hipEvent brackets are pure kernel time, which picks the dominant kernel class; under
     # concurrency a bracket also contains time spent queued behind the other contexts' kernels.
     hal = HipHal(gpu_index)
+    if blob is not None:
+        hal.set_params(1)
     hal.prove_segment(segs[0][0], device_inputs=(segs[0][1], segs[0][2]))  # cold: first-touch allocations, tables
     hal.set_kernel_timing(True)
     hal.prove_segment(segs[1][0], device_inputs=(segs[1][1], segs[1][2]))
@@ -229,14 +237,18 @@ def main():
         kernels = {k: {"ms_per_step": round(v["ms"] / max(my_steps, 1), 3), "launches_per_step": v["launches"] / max(my_steps, 1),
                        "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
                    for k, v in kstats.items()}
-        algo = seg_mod.algorithmic_bytes(args.po2, widths)
+        sp1 = blob is not None
+        algo = seg_mod.algorithmic_bytes(args.po2, widths, 1, 1, 1) if sp1 else seg_mod.algorithmic_bytes(args.po2, widths)
+        shape_text = ("%d check columns, blow-up 2, Poseidon2 width 16 Merkle, FRI arity 2 to a constant, 100 queries, "
+                      "16 proof-of-work bits, x^4 - 11 (SP1 core's RECALLED parameter set on risc0's flow)" % (4 << blow)) if sp1 else \
+            "16 check columns, blow-up 4, Poseidon2 Merkle, FRI arity 16, 50 queries"
         out = {
             "metric": "proven RISC-V cycles/sec", "value": round(value, 1), "unit": "cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
-            "config": {"workload": "S%d: one 2^%d-cycle segment proof, W=%s (accum/code/data) + 16 check columns, "
-                                   "blow-up 4, Poseidon2 Merkle, FRI arity 16, 50 queries" % (args.po2, args.po2, args.widths),
+            "config": {"workload": "S%d: one 2^%d-cycle segment proof, W=%s (accum/code/data) + %s" % (args.po2, args.po2, args.widths, shape_text),
+                       "params": args.preset,
                        "entry_point": "rk_prove_session (on_device = 1 inputs, verify = %d)" % (0 if args.no_verify else 1),
                        "segments_per_gpu_per_step": 1, "segments_in_flight_per_gpu": inflight,
                        "total_segments": total_segments, "parallelism": "segment-parallel x%d" % world},
@@ -252,20 +264,22 @@ def main():
             out["h2d_seals_identical"] = bool(same)
         if seals:
             # every seal was verified inside the timed region unless --no-verify; check the last one here too
-            out["seal_verified"] = verify_segment(segs[(my_steps - 1) % 2][0], seals[-1]) == 0
+            out["seal_verified"] = verify_segment(segs[(my_steps - 1) % 2][0], seals[-1], params=blob) == 0
             out["seal_words"] = int(seals[-1].size)
         if not args.no_cpu and world == 1:
             # the cpu_baseline leg is the only place bench.py touches oracle/ (test infrastructure):
             # its optimised operator forms (oracle/or_fast.c), the same seal as the plain restatement
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
+            if sp1:
+                oracle_lib.oracle_set_params(1)
             cores = oracle_lib.usable_cores()
             cpu_po2 = args.cpu_po2 if args.cpu_po2 is not None else args.po2
-            cseg = seg_mod.synthetic_segment(cpu_po2, widths, seed=20240807)
+            cseg = seg_mod.synthetic_segment(cpu_po2, widths, seed=20240807, blowup_log2=blow)
             t1 = time.perf_counter()
             oracle_lib.oracle_prove(cseg, threads=cores, fast=True)
             dt = time.perf_counter() - t1
-            cseg1 = seg_mod.synthetic_segment(args.cpu_po2_1t, widths, seed=20240807)
+            cseg1 = seg_mod.synthetic_segment(args.cpu_po2_1t, widths, seed=20240807, blowup_log2=blow)
             t1 = time.perf_counter()
             oracle_lib.oracle_prove(cseg1, threads=1, fast=True)
             dt1 = time.perf_counter() - t1

@@ -339,6 +339,9 @@ typedef struct {
                          * single-process host needs no collective */
     int n_devices;      /* 0: use `device` */
     const rk_verify_opts* verify_opts; /* optional, for verify != 0 */
+    const rk_params* params;    /* optional: the parameter set of this session's proofs (and of their verification,
+                                 * unless verify_opts carries its own); NULL = risc0's.  The device's contexts are
+                                 * re-parameterised only when the set differs from the previous session's */
 } rk_session_opts;
 int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n, uint32_t* const* h_seals,
                      const size_t* seal_capacity_words, size_t* seal_words, size_t* failed_index);

@@ -186,6 +186,7 @@ pub struct rk_session_opts {
     pub devices: *const c_int,
     pub n_devices: c_int,
     pub verify_opts: *const rk_verify_opts,
+    pub params: *const rk_params,
 }
 
 #[repr(C)]

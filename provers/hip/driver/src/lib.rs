@@ -201,6 +201,7 @@ fn prove_locally(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Re
         devices: if devices.len() > 1 { devices.as_ptr() } else { ptr::null() },
         n_devices: if devices.len() > 1 { devices.len() as c_int } else { 0 },
         verify_opts: &vopts,
+        params: ptr::null(), // risc0's parameter set is the library default
     };
     let st = unsafe {
         rk_prove_session(&opts, c_segs.as_ptr(), c_segs.len(), ptrs.as_ptr(), caps.as_ptr(), words.as_mut_ptr(), &mut failed)

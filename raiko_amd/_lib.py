@@ -95,7 +95,8 @@ class RkVerifyOpts(C.Structure):
 
 class RkSessionOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("inflight", C.c_int), ("upload_ahead", C.c_int), ("verify", C.c_int),
-                ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("verify_opts", C.POINTER(RkVerifyOpts))]
+                ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("verify_opts", C.POINTER(RkVerifyOpts)),
+                ("params", C.POINTER(RkParams))]
 
 
 RK_ERR_INVALID = -1

@@ -52,6 +52,7 @@ struct DevicePool {
     std::mutex busy;  // one session at a time per device (`run` may be entered from many threads)
     std::string last_error;
     bool ktime_on = false;  // applied to contexts created later
+    std::vector<std::vector<uint32_t>> prover_key;  // per prover: the parameter set it carries (empty: risc0's defaults)
     void clear() {
         if (uploader) {
             for (Slot* s : ring) {
@@ -64,6 +65,7 @@ struct DevicePool {
         uploader = nullptr;
         for (rk_ctx* c : provers) (void)rk_ctx_destroy(c);
         provers.clear();
+        prover_key.clear();
     }
     ~DevicePool() { clear(); }
 };
@@ -99,6 +101,7 @@ struct Run {
     size_t* words;
     int verify;
     const rk_verify_opts* verify_opts;
+    unsigned blowup_log2 = 2;  // of the session's parameter set: the check evaluations span 4 << blowup_log2 columns of rows
 
     std::unique_ptr<std::atomic<unsigned char>[]> claimed;
     std::vector<int> owner;          // device a device-resident segment lives on (-1: host-resident, any GPU)
@@ -167,7 +170,7 @@ void feeder(Run* run, size_t d) {
             const rk_segment& seg = run->segs[i];
             const size_t rows = (size_t)1 << seg.po2;
             const size_t want[4] = {hook_accum(seg) ? 0 : rows * seg.taps.group_size[0], rows * seg.taps.group_size[1],
-                                    rows * seg.taps.group_size[2], hook_check(seg) ? 0 : rows * 16};
+                                    rows * seg.taps.group_size[2], hook_check(seg) ? 0 : (rows * 4) << run->blowup_log2};
             int st = RK_OK;
             if (want[0] != slot->words[0] || want[1] != slot->words[1] || want[2] != slot->words[2] ||
                 want[3] != slot->words[3]) {
@@ -341,6 +344,39 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
         }
     }
     const size_t workers = std::min<size_t>((size_t)opts->inflight, n);
+    // the session's parameter set: every word that defines it, so that an equal set costs nothing next time
+    rk_params prm;
+    rk::params_preset(&prm, RK_PRESET_RISC0);
+    std::vector<uint32_t> key;
+    if (opts->params) {
+        rk::Sys sys;
+        auto any = std::make_unique<p2::Any>();
+        int st = rk::resolve_params(opts->params, &sys, any.get());
+        if (st != RK_OK) return st;
+        prm = *opts->params;
+        const uint32_t head[] = {prm.ext_w, prm.root_2_27, prm.coset_shift, prm.p2_width, prm.p2_m4, prm.p2_pad_free, prm.queries,
+                                 prm.blowup_log2, prm.fri_fold_log2, prm.fri_min_degree, prm.pow_bits};
+        key.assign(head, head + sizeof head / 4);
+        key.insert(key.end(), any->rc_ext(), any->rc_ext() + 8 * any->cells());
+        key.insert(key.end(), any->rc_int(), any->rc_int() + any->rounds_partial());
+        key.insert(key.end(), any->diag(), any->diag() + any->cells());
+        rk_params dflt;
+        rk::params_preset(&dflt, RK_PRESET_RISC0);
+        rk::Sys dsys;
+        auto dany = std::make_unique<p2::Any>();
+        (void)rk::resolve_params(&dflt, &dsys, dany.get());
+        std::vector<uint32_t> dkey = {dflt.ext_w, dflt.root_2_27, dflt.coset_shift, dflt.p2_width, dflt.p2_m4, dflt.p2_pad_free,
+                                      dflt.queries, dflt.blowup_log2, dflt.fri_fold_log2, dflt.fri_min_degree, dflt.pow_bits};
+        dkey.insert(dkey.end(), dany->rc_ext(), dany->rc_ext() + 8 * dany->cells());
+        dkey.insert(dkey.end(), dany->rc_int(), dany->rc_int() + dany->rounds_partial());
+        dkey.insert(dkey.end(), dany->diag(), dany->diag() + dany->cells());
+        if (key == dkey) key.clear();
+    }
+    rk_verify_opts vopts{};
+    if (opts->verify_opts) vopts = *opts->verify_opts;
+    if (opts->params && !vopts.params) vopts.params = opts->params;
+    run.verify_opts = (opts->verify_opts || opts->params) ? &vopts : nullptr;
+    run.blowup_log2 = prm.blowup_log2;
     run.devs.resize(devices.size());
     for (size_t d = 0; d < devices.size(); d++) {
         DevicePool* pool = pools[d].get();
@@ -350,6 +386,13 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
             if (st != RK_OK) return st;
             if (pool->ktime_on) (void)rk_set_kernel_timing(c, 1);
             pool->provers.push_back(c);
+        }
+        pool->prover_key.resize(pool->provers.size());
+        for (size_t j = 0; j < workers; j++) {
+            if (pool->prover_key[j] == key) continue;
+            int st = rk_set_params(pool->provers[j], &prm);
+            if (st != RK_OK) return st;
+            pool->prover_key[j] = key;
         }
         if (any_host && !pool->uploader) {
             int st = rk_ctx_create(pool->device, nullptr, &pool->uploader);

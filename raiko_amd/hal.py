@@ -235,7 +235,8 @@ class HipHal:
 
 
 def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: int = 2, verify: bool = True,
-                  device_inputs=None, devices: Optional[Sequence[int]] = None, poly_ext=None, poseidon2=None, program=None):
+                  device_inputs=None, devices: Optional[Sequence[int]] = None, poly_ext=None, poseidon2=None, program=None,
+                  params=None):
     """Seals of all `segments`, in order, through rk_prove_session: `inflight` proofs in flight on
     each GPU (`devices`: several GPUs of the node share one work queue of segments), host-resident
     traces staged `upload_ahead` segments ahead on a separate stream, every seal verified on a host
@@ -256,7 +257,8 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
     ptrs = (_lib.u32p * n)()
     seals = []
     for i in range(n):
-        caps[i] = int(lib.rk_seal_bound_words(C.byref(c_segs[i])))
+        caps[i] = int(lib.rk_seal_bound_words_params(C.byref(c_segs[i]), C.byref(params))) if params is not None else \
+            int(lib.rk_seal_bound_words(C.byref(c_segs[i])))
         if caps[i] == 0:
             e = _lib.RkError(_lib.RK_ERR_INVALID, "invalid argument (segment %d: shape or tap set)" % i)
             e.segment = i
@@ -274,6 +276,9 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
         vopts, vkeep = make_verify_opts(poly_ext, poseidon2, program=program)
         opts.verify_opts = C.pointer(vopts)
         keep.append((vopts, vkeep))
+    if params is not None:  # an rk_params blob (make_params): the session's proofs and their verification use it
+        opts.params = C.pointer(params)
+        keep.append(params)
     failed = C.c_size_t(0)
     st = lib.rk_prove_session(C.byref(opts), c_segs, n, ptrs, caps, words, C.byref(failed))
     del keep

@@ -133,28 +133,33 @@ def synthetic_segment(po2: int, widths: Tuple[int, int, int] = (16, 16, 224), se
     return Segment(po2=po2, taps=taps, groups=groups, check=check, globals_=globals_)
 
 
-def algorithmic_bytes(po2: int, widths: Sequence[int]) -> dict:
+def algorithmic_bytes(po2: int, widths: Sequence[int], blowup_log2: int = 2, fold_log2: int = 4,
+                      min_degree: int = FRI_MIN_DEGREE) -> dict:
     """Compulsory HBM traffic of one segment proof with every stage reading its input once and
     writing its output once ('unfused'): per group of W columns
-    13*N*W*4 + 4*D*32; check group as a 16-column group on top of a 4 x D iNTT; DEEP and FRI."""
+    (9 + D/N)*N*W*4 + 4*D*32 (= 13*N*W*4 + ... at blow-up 4); check group as a 4*D/N-column group on top
+    of a 4 x D iNTT; DEEP and FRI.  Defaults: risc0's shape (blow-up 4, fold 16, final degree 256)."""
     n = 1 << po2
-    d = INV_RATE * n
+    blow = 1 << blowup_log2
+    fold = 1 << fold_log2
+    d = blow * n
+    chk = 4 * blow
     out = {}
     trace = 0
     for w in widths:
-        trace += 13 * n * w * 4 + 4 * d * 32
+        trace += (9 + blow) * n * w * 4 + 4 * d * 32
     out["trace_groups"] = trace
-    # check: iNTT over 4 x D (read+write), zk-shift, expand (N->D for 16 cols), hash rows + folds
-    out["check_group"] = 2 * 4 * d * 4 + 2 * n * 16 * 4 + 5 * n * 16 * 4 + (d * 16 * 4 + d * 32) + 3 * d * 32
+    # check: iNTT over 4 x D (read+write), zk-shift, expand (N->D for the columns), hash rows + folds
+    out["check_group"] = 2 * 4 * d * 4 + 2 * n * chk * 4 + (1 + blow) * n * chk * 4 + (d * chk * 4 + d * 32) + 3 * d * 32
     # DEEP: read every coefficient column once more (+ check), write/read combos ~ 4 ext polys
-    out["deep"] = n * (sum(widths) + 16) * 4 + 2 * 4 * n * 16
-    # FRI: rounds of (expand 4 planes x4, hash rows of 64 cols, folds), sizes N, N/16, ...
+    out["deep"] = n * (sum(widths) + chk) * 4 + 2 * 4 * n * 16
+    # FRI: rounds of (expand 4 planes, hash rows of 4*fold cols, folds), sizes N, N/fold, ...
     fri = 0
     size = n
-    while size > FRI_MIN_DEGREE:
-        dom = size * INV_RATE
-        fri += (size + dom) * 4 * 4 + dom * 4 * 4 + (dom // FRI_FOLD) * 32 * 4 + size * 4 * 4
-        size //= FRI_FOLD
+    while size > min_degree and size >= fold:
+        dom = size * blow
+        fri += (size + dom) * 4 * 4 + dom * 4 * 4 + (dom // fold) * 32 * 4 + size * 4 * 4
+        size //= fold
     out["fri"] = fri
     out["total"] = sum(out.values())
     return out

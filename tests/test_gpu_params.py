@@ -268,3 +268,22 @@ def test_parameter_sets_the_library_refuses(cfg):
     words = C.c_size_t(0)
     buf = np.zeros(16, dtype=np.uint32)
     assert h._lib.rk_prove_segment(h._ctx, C.byref(c_seg), buf.ctypes.data_as(_lib.u32p), 16, C.byref(words)) == -1
+
+
+def test_session_under_sp1_parameters_and_back(cfg):
+    """rk_session_opts.params: the drop-in entry point under another parameter set -- the device's prover
+    contexts are re-parameterised for the session, seals equal the oracle's under the same blob and are
+    verified inside the session; the next session without a blob is risc0's again"""
+    from raiko_amd.hal import make_params, prove_session
+    _, apply = cfg
+    blob = make_params(1)
+    o.oracle_set_params(1)
+    segs = [synthetic_segment(9 + (i % 2), (4, 4, 12), seed=70 + i, blowup_log2=1) for i in range(5)]
+    seals = prove_session(segs, inflight=3, verify=True, params=blob)
+    for seg, seal in zip(segs, seals):
+        assert np.array_equal(seal, o.oracle_prove(seg))
+        assert verify_segment(seg, seal, params=blob) == 0
+    o.oracle_set_params()
+    plain = [synthetic_segment(9, (4, 4, 12), seed=80 + i) for i in range(4)]
+    for seg, seal in zip(plain, prove_session(plain, inflight=3, verify=True)):
+        assert np.array_equal(seal, o.oracle_prove(seg))
