@@ -332,7 +332,8 @@ typedef struct {
     int device;        /* the GPU, when n_devices == 0 */
     int inflight;      /* per GPU, 1..16; 3 is where an MI355X saturates at 2^20-cycle segments */
     int upload_ahead;  /* per GPU, 0..16 staged segments waiting for a prover; 2 hides a 20 ms upload */
-    int verify;
+    int verify;        /* 0: no verification; 1: verify every seal (the library picks up to 4 host threads);
+                        * 2..16: that many verifier threads */
     const int* devices; /* optional list of distinct GPUs of this node: every GPU's prover contexts take
                          * segments from ONE shared index (a work queue: a short last segment or a slower
                          * GPU does not stall the others), seals land in the caller's host buffers, so a

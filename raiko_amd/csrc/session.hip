@@ -412,7 +412,14 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
         threads.emplace_back(feeder_thread, &run, d);
         for (size_t w = 0; w < workers; w++) threads.emplace_back(prover_thread, pools[d]->provers[w], &run, d);
     }
-    if (run.verify) threads.emplace_back(verifier, &run);
+    // a seal takes ~7 ms of host time to verify whatever the segment size (50 query paths of Poseidon2):
+    // one thread keeps up with 2^20-cycle segments, smaller ones need more (2^16: 3.5 ms per proof)
+    if (run.verify) {
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nv = run.verify == 1 ? std::min<size_t>(4, std::max<unsigned>(1, hw / 4)) : std::min<size_t>((size_t)run.verify, 16);
+        nv = std::min(nv, n);
+        for (size_t v = 0; v < nv; v++) threads.emplace_back(verifier, &run);
+    }
     for (auto& t : threads) t.join();
     if (run.status != RK_OK) {
         if (failed_index) *failed_index = run.failed;
