@@ -32,13 +32,15 @@ namespace {
 using bb::Ext;
 
 constexpr uint32_t NONE = 0xffffffffu;
-// operand = kind << 29 | index; a tap's index is group << 27 | back << 20 | column, so that the
-// evaluator needs no table to find it
-enum : uint32_t { K_SLOT = 0, K_TAP = 1, K_CONST = 2, K_GLOBAL = 3, K_MIX = 4 };
-constexpr uint32_t TAP_MAX_BACK = 127, TAP_MAX_COLUMN = (1u << 20) - 1;
+// operand = kind << 29 | index.  K_SLOT: a slot kept in LDS; K_SPILL: one in the HBM scratch matrix (which is
+// which is settled when the list is compiled); K_TAP: index into the per-proof tap table {column base, shift}.
+// The evaluator is bound by scalar instructions (profiles/r02_pmc_program.json), so what can be a table
+// lookup (one SMEM instruction) or a compile-time decision is not computed per op
+enum : uint32_t { K_SLOT = 0, K_TAP = 1, K_CONST = 2, K_GLOBAL = 3, K_MIX = 4, K_SPILL = 5 };
 constexpr uint32_t IDX_MASK = (1u << 29) - 1;
 inline uint32_t operand(uint32_t kind, uint32_t idx) { return (kind << 29) | idx; }
-// op.x = opcode | dst << 8
+// op.x = opcode | dst << 8; DST_SPILL in the opcode byte: the result goes to the HBM scratch matrix
+constexpr uint32_t DST_SPILL = 0x80u;
 enum : uint32_t { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_EQZ = 3, OP_COND = 4 };
 constexpr uint32_t MAX_SLOTS = 1u << 24, MAX_MIX_SLOTS = 1u << 12, MAX_POWERS = 1u << 20;
 
@@ -62,6 +64,7 @@ struct rk_program {
     std::vector<uint32_t> consts;   // Montgomery
     std::vector<uint32_t> powers;   // distinct exponents of poly_mix, ascending
     uint32_t n_fp_slots = 0, n_mix_slots = 0;
+    uint32_t lds_fp = 0, lds_mix = 0;  // how many of them live in LDS (the rest in the HBM scratch matrix)
     uint32_t ret_slot = NONE;       // NONE: the result is identically zero
     uint32_t need_globals = 0, need_mix = 0;
     rk_program_info info{};
@@ -243,8 +246,7 @@ int compile(rk_program* pg) {
                     break;
                 case RK_STEP_GET: {
                     const Tap& t = pg->taps[v.a];
-                    if (t.back > TAP_MAX_BACK || t.offset > TAP_MAX_COLUMN) return RK_ERR_CAPACITY;
-                    v.opnd = operand(K_TAP, (t.group << 27) | (t.back << 20) | t.offset);
+                    v.opnd = operand(K_TAP, v.a);
                     pg->group_min[t.group] = std::max(pg->group_min[t.group], t.offset + 1);
                     break;
                 }
@@ -297,6 +299,24 @@ int compile(rk_program* pg) {
     }
     pg->n_fp_slots = fp_pool.next;
     pg->n_mix_slots = mx_pool.next;
+    // which slots live in LDS is a property of the compiled list: the lowest-numbered (busiest) ones
+    pg->lds_mix = std::min(pg->n_mix_slots, LDS_MIX_SLOTS);
+    pg->lds_fp = std::min(pg->n_fp_slots, LDS_WORDS_PER_LANE - 4 * pg->lds_mix);
+    auto place = [&](uint32_t opnd) {
+        if (opnd == NONE || (opnd >> 29) != K_SLOT) return opnd;
+        const uint32_t slot = opnd & IDX_MASK;
+        return slot < pg->lds_fp ? opnd : operand(K_SPILL, slot - pg->lds_fp);
+    };
+    for (uint4& op : pg->code) {
+        const uint32_t oc = op.x & 0xffu, dst = op.x >> 8;
+        if (oc <= OP_MUL) {
+            op.y = place(op.y);
+            op.z = place(op.z);
+            if (dst >= pg->lds_fp) op.x = (oc | DST_SPILL) | ((dst - pg->lds_fp) << 8);
+        } else {
+            op.z = place(op.z);
+        }
+    }
     pg->ret_slot = mx[pg->ret].zero ? NONE : mx[pg->ret].slot;
     pg->info.n_steps = n;
     pg->info.n_ops = n_ops;
@@ -317,6 +337,14 @@ int compile(rk_program* pg) {
 #else
 #define RK_CONST_AS
 #endif
+// the slot array: an explicit LDS pointer.  Through a generic pointer the compiler merges the LDS, HBM-spill
+// and tap cases of an operand fetch into one flat_load (the vector-memory path, hundreds of cycles);
+// with the address space in the type each case keeps its own instruction and slots are ds_read / ds_write
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+#else
+typedef uint32_t lds_u32;
+#endif
 typedef const RK_CONST_AS uint4* const_u4;
 typedef const RK_CONST_AS uint32_t* const_u32;
 typedef const RK_CONST_AS uint64_t* const_u64;
@@ -325,48 +353,43 @@ struct EvalArgs {
     uint64_t code;       // uint4 per op
     uint64_t consts;     // program constants | globals | accum mix
     uint64_t powers;     // 4 words per distinct power of poly_mix
-    const uint32_t* lde[3];
+    uint64_t taps;       // uint4 per tap: column base (64-bit), shift in points, 0
     uint32_t* spill;
     uint32_t* check;
     size_t d;
     uint32_t n_ops, glob_base, mix_base;
     uint32_t lds_fp, lds_mix, n_fp_slots;
     uint32_t ret_slot, wm;
-    uint32_t blow;       // log2 of the blow-up: a tap `back` rows behind is back << blow points behind
+    uint32_t blow;       // log2 of the blow-up
     uint32_t inv_den[16];
 };
 
 struct Lane {
     const EvalArgs& a;
-    uint32_t* lds;
+    lds_u32* lds;
     size_t i;
     const_u32 consts;
+    const_u4 taps;
     __device__ __forceinline__ uint32_t fetch(uint32_t opnd) const {
         const uint32_t kind = opnd >> 29, idx = opnd & IDX_MASK;
-        switch (kind) {
-            case K_SLOT:
-                return idx < a.lds_fp ? lds[idx * WG] : a.spill[(size_t)(idx - a.lds_fp) * a.d + i];
-            case K_TAP: {
-                const uint32_t g = idx >> 27, back = (idx >> 20) & TAP_MAX_BACK, column = idx & TAP_MAX_COLUMN;
-                const uint32_t* base = g == 0 ? a.lde[0] : g == 1 ? a.lde[1] : a.lde[2];
-                return base[(size_t)column * a.d + ((i + a.d - ((size_t)back << a.blow)) & (a.d - 1))];
-            }
-            case K_CONST:
-                return consts[idx];
-            case K_GLOBAL:
-                return consts[a.glob_base + idx];
-            default:
-                return consts[a.mix_base + idx];
+        if (kind == K_SLOT) return lds[idx * WG];
+        if (kind == K_TAP) {
+            const uint4 t = taps[idx];
+            const char* col = reinterpret_cast<const char*>(((uint64_t)t.y << 32) | t.x);
+            const uint32_t off = ((uint32_t)i + (uint32_t)a.d - t.z) & ((uint32_t)a.d - 1);
+            return *reinterpret_cast<const uint32_t*>(col + (off << 2));
         }
+        if (kind == K_SPILL) return a.spill[(size_t)idx * a.d + i];
+        return consts[(kind == K_CONST ? 0u : kind == K_GLOBAL ? a.glob_base : a.mix_base) + idx];
     }
-    __device__ __forceinline__ void store(uint32_t slot, uint32_t v) const {
-        if (slot < a.lds_fp) lds[slot * WG] = v;
-        else a.spill[(size_t)(slot - a.lds_fp) * a.d + i] = v;
+    __device__ __forceinline__ void store(uint32_t slot, bool spilled, uint32_t v) const {
+        if (!spilled) lds[slot * WG] = v;
+        else a.spill[(size_t)slot * a.d + i] = v;
     }
     __device__ __forceinline__ Ext load_mix(uint32_t slot) const {
         Ext r;
         if (slot < a.lds_mix) {
-            const uint32_t* p = lds + (size_t)(a.lds_fp + 4 * slot) * WG;
+            const lds_u32* p = lds + (a.lds_fp + 4 * slot) * WG;
 #pragma unroll
             for (int e = 0; e < 4; e++) r.c[e] = p[e * WG];
         } else {
@@ -378,7 +401,7 @@ struct Lane {
     }
     __device__ __forceinline__ void store_mix(uint32_t slot, const Ext& v) const {
         if (slot < a.lds_mix) {
-            uint32_t* p = lds + (size_t)(a.lds_fp + 4 * slot) * WG;
+            lds_u32* p = lds + (a.lds_fp + 4 * slot) * WG;
 #pragma unroll
             for (int e = 0; e < 4; e++) p[e * WG] = v.c[e];
         } else {
@@ -393,18 +416,18 @@ __global__ __launch_bounds__(WG) void program_kernel(EvalArgs a) {
     extern __shared__ uint32_t lds_all[];
     const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
     if (i >= a.d) return;  // no barrier anywhere below
-    Lane ln{a, lds_all + threadIdx.x, i, (const_u32)a.consts};
+    Lane ln{a, (lds_u32*)lds_all + threadIdx.x, i, (const_u32)a.consts, (const_u4)a.taps};
     const const_u4 code = (const_u4)a.code;
     const const_u32 powers = (const_u32)a.powers;
     uint4 next = code[0];  // the list has a spare entry at the end: the fetch of op pc + 1 runs under op pc
     for (uint32_t pc = 0; pc < a.n_ops; pc++) {
         const uint4 op = next;
         next = code[pc + 1];
-        const uint32_t oc = op.x & 0xffu, dst = op.x >> 8;
+        const uint32_t oc = op.x & 0x7fu, dst = op.x >> 8;
         if (oc <= OP_MUL) {
             const uint32_t x = ln.fetch(op.y), y = ln.fetch(op.z);
             const uint32_t r = oc == OP_ADD ? bb::add(x, y) : oc == OP_SUB ? bb::sub(x, y) : bb::mul(x, y);
-            ln.store(dst, r);
+            ln.store(dst, (op.x & DST_SPILL) != 0, r);
         } else {
             const const_u32 pw = powers + (size_t)(op.w & 0xfffffu) * 4;
             Ext t = bb::scale(Ext{{pw[0], pw[1], pw[2], pw[3]}}, ln.fetch(op.z));
@@ -460,10 +483,10 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     const uint4* d_ops = nullptr;
     RK_TRY(device_code(pg, ctx, &d_ops));
     a.code = (uint64_t)(uintptr_t)d_ops;
-    // per-proof tables in one upload: constants | globals | mix | powers
-    const size_t nc = pg->consts.size(), npw = pg->powers.size();
+    // per-proof tables in one upload: constants | globals | mix | powers | taps
+    const size_t nc = pg->consts.size(), npw = pg->powers.size(), ntap = pg->taps.size();
     const size_t o_glob = nc, o_mix = o_glob + v->n_globals, o_pw = (o_mix + v->n_mix + 3) & ~(size_t)3;
-    const size_t words = o_pw + 4 * npw;
+    const size_t o_tap = o_pw + 4 * npw, words = o_tap + 4 * ntap;
     std::vector<uint32_t> pack(words + 4, 0);
     std::memcpy(pack.data(), pg->consts.data(), nc * 4);
     if (v->n_globals) std::memcpy(&pack[o_glob], v->globals, (size_t)v->n_globals * 4);
@@ -478,7 +501,15 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
             std::memcpy(&pack[o_pw + 4 * j], cur.c, 16);
         }
     }
-    for (int g = 0; g < 3; g++) a.lde[g] = v->d_lde[g];
+    for (size_t t = 0; t < ntap; t++) {  // a tap `back` rows behind is back << blow points behind
+        const Tap& tp = pg->taps[t];
+        uint64_t col = 0;
+        if (tp.group < 3 && v->d_lde[tp.group] && tp.offset < v->group_size[tp.group])
+            col = (uint64_t)(uintptr_t)(v->d_lde[tp.group] + (size_t)tp.offset * d);
+        pack[o_tap + 4 * t] = (uint32_t)col;
+        pack[o_tap + 4 * t + 1] = (uint32_t)(col >> 32);
+        pack[o_tap + 4 * t + 2] = (uint32_t)((((size_t)tp.back) << blow) & (d - 1));
+    }
     void* d_pack = nullptr;
     RK_TRY(scratch(ctx, words * 4 + 16, &d_pack));
     RK_HIP_TRY(ctx, hipMemcpyAsync(d_pack, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -488,11 +519,12 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     a.glob_base = (uint32_t)o_glob;
     a.mix_base = (uint32_t)o_mix;
     a.powers = (uint64_t)(uintptr_t)(dp + o_pw);
+    a.taps = (uint64_t)(uintptr_t)(dp + o_tap);
     a.check = d_check;
     a.d = d;
     a.n_ops = (uint32_t)pg->code.size();
-    a.lds_mix = std::min(pg->n_mix_slots, LDS_MIX_SLOTS);
-    a.lds_fp = std::min(pg->n_fp_slots, LDS_WORDS_PER_LANE - 4 * a.lds_mix);
+    a.lds_mix = pg->lds_mix;
+    a.lds_fp = pg->lds_fp;
     a.n_fp_slots = pg->n_fp_slots;
     a.ret_slot = pg->ret_slot;
     a.wm = wm;

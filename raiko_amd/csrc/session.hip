@@ -416,7 +416,8 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
     // one thread keeps up with 2^20-cycle segments, smaller ones need more (2^16: 3.5 ms per proof)
     if (run.verify) {
         unsigned hw = std::thread::hardware_concurrency();
-        size_t nv = run.verify == 1 ? std::min<size_t>(4, std::max<unsigned>(1, hw / 4)) : std::min<size_t>((size_t)run.verify, 16);
+        size_t nv = run.verify == 1 ? std::min<size_t>(std::min<size_t>(16, 4 * devices.size()), std::max<unsigned>(1, hw / 4))
+                                    : std::min<size_t>((size_t)run.verify, 16);
         nv = std::min(nv, n);
         for (size_t v = 0; v < nv; v++) threads.emplace_back(verifier, &run);
     }

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--sizes", default="1000,10000,40000")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only-local", action="store_true", help="only the expression-tree list (for counter collection)")
     ap.add_argument("--gen", help="directory with <name>.npz (steps, ret) and lib<name>.so built from tools/circuit_gen.py output: "
                                   "the list through the interpreter and through its generated code, outputs compared")
     ap.add_argument("--gen-name", default="big10000")
@@ -70,7 +71,7 @@ def main():
     out = hal.alloc_elem(4 * d)
     v = view_for(hal, po2, bufs, widths, globals_, mix)
     v.stream = ts.cuda_stream
-    for n_ops, local in [(int(x), loc) for x in args.sizes.split(",") for loc in (True, False)]:
+    for n_ops, local in [(int(x), loc) for x in args.sizes.split(",") for loc in ((True,) if args.only_local else (True, False))]:
         steps, ret = random_program(rng, taps, 32, 40, n_fp_ops=n_ops, n_live=0, depth=2, n_constraints=max(8, n_ops // 10),
                                     local=local)
         prog = cp.Program(steps, ret, taps)
@@ -83,6 +84,8 @@ def main():
                           "mix_slots": info["n_mix_slots"], "ms": round(t * 1e3, 3),
                           "G_point_ops_per_s": round(info["n_ops"] * d / t / 1e9, 2)}), flush=True)
         prog.close()
+    if args.only_local:
+        return
     if args.gen:
         z = np.load(os.path.join(args.gen, args.gen_name + ".npz"))
         prog = cp.Program(z["steps"], int(z["ret"]), taps)
