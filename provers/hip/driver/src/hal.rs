@@ -237,3 +237,96 @@ impl Hal for HipHal {
         ck(self.raw(), unsafe { rk_scatter(self.raw(), into.as_ptr(), into.size(), index.as_ptr(), index.len() - 1, offsets.as_ptr(), vals.as_ptr()) }, "rk_scatter");
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// `impl CircuitHal<HipHal>`: the circuit's half of the operator route.  risc0's CUDA / Metal back ends
+// ship a generated `eval_check` kernel per circuit; here the circuit's constraint list
+// (`PolyExtStepDef`) is handed to the library once (`rk_program_create`) and `eval_check` runs it on
+// the buffers the prover already holds on the GPU (`rk_program_eval_check`).  `accumulate` stays
+// risc0's CPU code on host views of the device buffers.
+//
+// RECALLED: `risc0_zkp::hal::CircuitHal` of 1.0.1 -- `eval_check(check, groups, globals, poly_mix, po2,
+// steps)` with groups in REGISTER_GROUP order (accum, code, data) and globals = [mix, out];
+// `accumulate(ctrl, io, data, mix, accum, steps)`.
+pub struct HipCircuitHal {
+    program: *mut rk_program,
+    cpu: risc0_circuit_rv32im::cpu::CpuCircuitHal,
+}
+
+impl HipCircuitHal {
+    /// `steps` / `ret`: the circuit's `PolyExtStepDef` flattened to `rk_poly_step`s (see
+    /// `crate::circuit::program` in lib.rs for the conversion); `taps`: its TapSet as `rk_taps`.
+    pub fn new(steps: &[rk_poly_step], ret: u32, taps: &rk_taps) -> Result<Self, i32> {
+        let mut program = ptr::null_mut();
+        let st = unsafe { rk_program_create(steps.as_ptr(), steps.len(), ret, taps, &mut program) };
+        if st != RK_OK {
+            return Err(st);
+        }
+        Ok(Self { program, cpu: risc0_circuit_rv32im::cpu::CpuCircuitHal::new() })
+    }
+}
+
+impl Drop for HipCircuitHal {
+    fn drop(&mut self) {
+        unsafe { rk_program_destroy(self.program) };
+    }
+}
+
+impl risc0_zkp::hal::CircuitHal<HipHal> for HipCircuitHal {
+    fn eval_check(
+        &self,
+        check: &HipBuffer<BabyBearElem>,
+        groups: &[&HipBuffer<BabyBearElem>],
+        globals: &[&HipBuffer<BabyBearElem>],
+        poly_mix: BabyBearExtElem,
+        po2: usize,
+        steps: usize,
+    ) {
+        let ctx = check.ctx();
+        let domain = steps * 4;
+        // globals = [mix, out]: small, read back once per proof
+        let mut mix = vec![0u32; globals[0].size()];
+        let mut out = vec![0u32; globals[1].size()];
+        globals[0].view(|s| mix.copy_from_slice(bytemuck::cast_slice(s)));
+        globals[1].view(|s| out.copy_from_slice(bytemuck::cast_slice(s)));
+        let view = rk_circuit_view {
+            ctx,
+            stream: ptr::null_mut(), // the library uses the context's own stream
+            po2: po2 as u32,
+            group_size: [
+                (groups[0].size() / domain) as u32,
+                (groups[1].size() / domain) as u32,
+                (groups[2].size() / domain) as u32,
+            ],
+            d_trace: [ptr::null(); 3],
+            d_lde: [groups[0].as_ptr() as *const u32, groups[1].as_ptr() as *const u32, groups[2].as_ptr() as *const u32],
+            globals: out.as_ptr(),
+            n_globals: out.len() as u32,
+            mix: mix.as_ptr(),
+            n_mix: mix.len() as u32,
+        };
+        let pm: [u32; 4] = bytemuck::cast(poly_mix);
+        ck(ctx, unsafe { rk_program_eval_check(self.program, &view, pm.as_ptr(), check.as_ptr()) }, "rk_program_eval_check");
+    }
+
+    fn accumulate(
+        &self,
+        ctrl: &HipBuffer<BabyBearElem>,
+        io: &HipBuffer<BabyBearElem>,
+        data: &HipBuffer<BabyBearElem>,
+        mix: &HipBuffer<BabyBearElem>,
+        accum: &HipBuffer<BabyBearElem>,
+        steps: usize,
+    ) {
+        // risc0's CPU accumulate on host copies (the buffers' view / view_mut round-trip through rk_d2h / rk_h2d)
+        let cpu_hal = risc0_zkp::hal::cpu::CpuHal::new(risc0_zkp::core::hash::poseidon2::Poseidon2HashSuite::new_suite());
+        let host = |b: &HipBuffer<BabyBearElem>, name: &'static str| {
+            let mut v = vec![BabyBearElem::default(); b.size()];
+            b.view(|s| v.copy_from_slice(s));
+            cpu_hal.copy_from_elem(name, &v)
+        };
+        let (c, i, d, m, a) = (host(ctrl, "ctrl"), host(io, "io"), host(data, "data"), host(mix, "mix"), host(accum, "accum"));
+        risc0_zkp::hal::CircuitHal::accumulate(&self.cpu, &c, &i, &d, &m, &a, steps);
+        a.view(|s| accum.view_mut(|dst| dst.copy_from_slice(s)));
+    }
+}
