@@ -130,6 +130,23 @@ __global__ void zk_shift_kernel(uint32_t* io, size_t total, size_t size, unsigne
     }
 }
 
+// zero-extension of bit-reversed coefficients: source word j of a column becomes word j << e of the longer
+// column, the words in between are zero (coefficient n < n_src sits at bitrev_(k+e)(n) = bitrev_k(n) << e).
+// One thread per source word writes its 2^e output words.
+__global__ void zero_interleave_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t total_src,
+                                       unsigned e) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total_src) return;
+    uint32_t* o = out + (j << e);
+    const uint32_t v = in[j];
+    if (e == 1) {
+        *reinterpret_cast<uint2*>(o) = make_uint2(v, 0u);
+    } else {
+        *reinterpret_cast<uint4*>(o) = make_uint4(v, 0u, 0u, 0u);
+        for (unsigned q = 1; q < (1u << (e - 2)); q++) reinterpret_cast<uint4*>(o)[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 __global__ void bit_reverse_kernel(uint32_t* io, size_t total, size_t size, unsigned bits) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -315,6 +332,28 @@ int ntt_forward(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_si
         RK_TRY(launch_nf_fwd_contig(ctx, a, expand_bits));
         a.src = d_out;
         a.n_src = size;
+        return launch_nf_strided<true>(ctx, a);
+    }
+    if (expand_bits != 0 && d_out != d_in && nf::usable(k, 0, aligned16(d_out, d_in)) && count <= 0xffffffffu) {
+        // other expansion factors (blow-up 2, 8, 16): spread the coefficients over the longer column, then the
+        // shape-specialised non-expanding transform in place -- one more pass over the output than the 4x
+        // kernel makes, still well ahead of the general passes
+        const size_t total_src = count * in_size;
+        {
+            rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)count * 4 * (in_size + size));
+            hipLaunchKernelGGL(zero_interleave_kernel, dim3((unsigned)((total_src + 255) / 256)), dim3(256), 0, ctx->stream, d_out,
+                               d_in, total_src, expand_bits);
+            RK_TRY(rk::post_launch(ctx, "zero_interleave_kernel"));
+        }
+        nf::Args a{};
+        a.dst = d_out;
+        a.src = d_out;
+        a.n = size;
+        a.n_src = size;
+        a.k = k;
+        a.count = (unsigned)count;
+        RK_TRY(nf_table(ctx, 0, k, &a.fs));
+        RK_TRY(launch_nf_fwd_contig(ctx, a, 0));
         return launch_nf_strided<true>(ctx, a);
     }
     if (expand_bits == 0 && d_out != d_in) {

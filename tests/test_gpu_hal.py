@@ -58,6 +58,21 @@ def test_zk_shift_and_expand(hal, orc, k, count):
     assert np.array_equal(out.to_host().reshape(count, 4 * n), want_e)
 
 
+@pytest.mark.parametrize("k,e,count", [(17, 1, 3), (18, 1, 2), (20, 1, 1), (15, 3, 2), (18, 3, 1), (14, 4, 3), (16, 4, 1), (19, 2, 1),
+                                         (3, 1, 2), (9, 3, 2), (12, 4, 1)])
+def test_expand_by_other_factors(hal, orc, k, e, count):
+    """blow-up 2, 8, 16 (rk_params.blowup_log2 1, 3, 4): output sizes 2^18..2^22 take the shape-specialised
+    kernels after a zero-interleave, the rest the general passes"""
+    rng = np.random.default_rng(700 + 10 * k + e)
+    n = 1 << k
+    x = o.rand_elems(rng, (count, n))
+    want = np.zeros((count, n << e), dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(want.ctypes.data, x.ctypes.data, n, count, e)
+    out = hal.alloc_elem(count * (n << e))
+    hal.batch_expand_into_evaluate_ntt(out, dev(hal, x), count, e)
+    assert np.array_equal(out.to_host().reshape(count, n << e), want)
+
+
 @pytest.mark.parametrize("k,count", [(0, 1), (1, 2), (2, 2), (7, 3), (16, 2)])
 def test_batch_bit_reverse(hal, orc, k, count):
     rng = np.random.default_rng(400 + k)
