@@ -153,6 +153,31 @@ int rk_pow_grind(rk_ctx* ctx, const uint32_t* sponge_cells, uint32_t bits, uint3
 /* MerkleTreeProver::new (risc0-zkp prove/merkle.rs): hash_rows + every hash_fold level into
  * d_nodes (2*rows digests, heap order, root at index 1). */
 int rk_merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols);
+/* ---- mixed-matrix commitment: Plonky3's MerkleTreeMmcs (p3-merkle-tree `MerkleTree::new`, RECALLED; what
+ * SP1 commits a shard's per-chip traces with -- provers/sp1/driver/src/lib.rs:48-57 reaches it through
+ * sp1-sdk) on this library's Poseidon2 sponge and 2-to-1 compression ----
+ * Matrices of different power-of-two heights, row-major (element (r, c) at r * width + c, Plonky3's
+ * RowMajorMatrix) or column-major, in one tree: the leaves are the hashes of the concatenated rows of
+ * the tallest matrices (given order); going up, a level whose size equals the height of further
+ * matrices takes them in -- node = compress(compress(left, right), hash(concatenated rows of those
+ * matrices)).  d_nodes: 2 * H digests in heap order (H = largest height; leaves at H + i, root at 1). */
+typedef struct {
+    const uint32_t* d_values;      /* device */
+    uint32_t height;               /* power of two */
+    uint32_t width;
+    uint32_t row_major;            /* 1: (r, c) at r * width + c; 0: at c * height + r */
+} rk_matrix;
+int rk_mmcs_commit(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, uint32_t* d_nodes, uint32_t h_root[8]);
+/* Mmcs::open_batch at leaf `index` of the tallest matrices: row (index >> log2(H / height)) of every
+ * matrix, concatenated in the given order into h_rows (sum of widths words), and the log2(H) sibling
+ * digests from the leaf level up into h_path. */
+int rk_mmcs_open(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, const uint32_t* d_nodes, uint32_t index,
+                 uint32_t* h_rows, uint32_t* h_path);
+/* Mmcs::verify_batch on the host (no GPU): heights / widths of the matrices in commit order, the opened rows
+ * and path, against `root`.  params NULL = risc0's Poseidon2 instance.  0 = accepted, 1 = rejected. */
+int rk_mmcs_verify(const rk_params* params, const uint32_t* heights, const uint32_t* widths, uint32_t n_mats,
+                   uint32_t index, const uint32_t* rows, const uint32_t* path, const uint32_t root[8]);
+
 /* synthetic division of one extension polynomial (count coefficients, natural order) by (x - z),
  * in place (core/poly.rs poly_divide); the remainder f(z) goes to h_rem (4 words, may be NULL). */
 int rk_poly_divide(rk_ctx* ctx, uint32_t* d_polys_ext, size_t count, const uint32_t z[4], uint32_t* h_rem);

@@ -196,6 +196,11 @@ typedef struct { const or_step* steps; size_t n_steps; uint32_t ret; const or_ta
 int or_program_eval_check(void* user, const or_circuit_view* v, const fp* poly_mix, fp* check);
 int or_program_poly_ext(void* user, const or_segment* pub, const fp* poly_mix, const fp4* eval_u, size_t n_taps,
                         const fp* mix, uint32_t n_mix, fp* out);
+/* ---- Plonky3 MerkleTreeMmcs restated (oracle/or_mmcs.c): the checker of rk_mmcs_commit / open / verify ---- */
+typedef struct { const fp* values; uint32_t height, width, row_major; } or_matrix;
+void or_mmcs_commit(const or_matrix* mats, uint32_t n, uint32_t* nodes /* 2 * H digests, heap order */);
+int or_mmcs_verify(const uint32_t* heights, const uint32_t* widths, uint32_t n, uint32_t index, const fp* rows, const uint32_t* path,
+                   const uint32_t* root);
 void or_free(void* p);
 int or_max_threads(void);
 void or_set_threads(int n);

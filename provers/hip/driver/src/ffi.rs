@@ -91,6 +91,15 @@ pub struct rk_params {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct rk_matrix {
+    pub d_values: *const u32,
+    pub height: u32,
+    pub width: u32,
+    pub row_major: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct rk_taps {
     pub group_size: [u32; 3],
     pub n_regs: u32,
@@ -279,6 +288,9 @@ extern "C" {
     pub fn rk_scatter(ctx: *mut rk_ctx, d_into: *mut u32, into_words: usize, h_index: *const u32, n_cycles: usize, h_offsets: *const u32, h_values: *const u32) -> c_int;
     pub fn rk_pow_grind(ctx: *mut rk_ctx, sponge_cells: *const u32, bits: u32, nonce: *mut u32) -> c_int;
     pub fn rk_merkle_build(ctx: *mut rk_ctx, d_nodes: *mut u32, d_matrix: *const u32, rows: usize, cols: usize) -> c_int;
+    pub fn rk_mmcs_commit(ctx: *mut rk_ctx, mats: *const rk_matrix, n_mats: u32, d_nodes: *mut u32, h_root: *mut u32) -> c_int;
+    pub fn rk_mmcs_open(ctx: *mut rk_ctx, mats: *const rk_matrix, n_mats: u32, d_nodes: *const u32, index: u32, h_rows: *mut u32, h_path: *mut u32) -> c_int;
+    pub fn rk_mmcs_verify(params: *const rk_params, heights: *const u32, widths: *const u32, n_mats: u32, index: u32, rows: *const u32, path: *const u32, root: *const u32) -> c_int;
     pub fn rk_poly_divide(ctx: *mut rk_ctx, d_polys_ext: *mut u32, count: usize, z: *const u32, h_rem: *mut u32) -> c_int;
     pub fn rk_program_create(steps: *const rk_poly_step, n_steps: usize, ret: u32, taps: *const rk_taps, out: *mut *mut rk_program) -> c_int;
     pub fn rk_program_destroy(prog: *mut rk_program) -> c_int;

@@ -88,6 +88,10 @@ class RkParams(C.Structure):
 RK_PRESET_RISC0, RK_PRESET_SP1 = 0, 1
 
 
+class RkMatrix(C.Structure):
+    _fields_ = [("d_values", C.c_void_p), ("height", C.c_uint32), ("width", C.c_uint32), ("row_major", C.c_uint32)]
+
+
 class RkVerifyOpts(C.Structure):
     _fields_ = [("p2_rc_ext", u32p), ("p2_rc_int", u32p), ("p2_diag", u32p), ("poly_ext", POLY_EXT_FN),
                 ("user", C.c_void_p), ("program", C.c_void_p), ("params", C.POINTER(RkParams))]
@@ -175,6 +179,9 @@ SYMBOLS = {
     "rk_seal_bound_words_for": (_sz, [C.POINTER(RkSegment), _u32]),
     "rk_seal_bound_words_params": (_sz, [C.POINTER(RkSegment), C.POINTER(RkParams)]),
     "rk_pow_grind": (C.c_int, [_vp, u32p, _u32, u32p]),
+    "rk_mmcs_commit": (C.c_int, [_vp, C.POINTER(RkMatrix), _u32, _vp, u32p]),
+    "rk_mmcs_open": (C.c_int, [_vp, C.POINTER(RkMatrix), _u32, _vp, _u32, u32p, u32p]),
+    "rk_mmcs_verify": (C.c_int, [C.POINTER(RkParams), u32p, u32p, _u32, _u32, u32p, u32p, u32p]),
     "rk_params_preset": (C.c_int, [C.POINTER(RkParams), C.c_int]),
     "rk_set_params": (C.c_int, [_vp, C.POINTER(RkParams)]),
     "rk_get_params": (C.c_int, [_vp, C.POINTER(RkParams)]),

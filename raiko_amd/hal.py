@@ -197,6 +197,31 @@ class HipHal:
         self._ck(self._lib.rk_poly_divide(self._ctx, _ptr(poly), count, _u32p(zz), _u32p(rem)))
         return rem
 
+    # ---- mixed-matrix commitment (Plonky3 MerkleTreeMmcs) ----
+    def _c_mats(self, mats):
+        arr = (_lib.RkMatrix * len(mats))()
+        for i, (buf, height, width, row_major) in enumerate(mats):
+            arr[i].d_values = _ptr(buf)
+            arr[i].height, arr[i].width, arr[i].row_major = int(height), int(width), 1 if row_major else 0
+        return arr
+
+    def mmcs_commit(self, mats):
+        """mats: [(device buffer, height, width, row_major)] in commit order -> (nodes buffer, root[8])"""
+        h_max = max(int(m[1]) for m in mats)
+        nodes = self.alloc_elem(2 * h_max * 8)
+        root = np.zeros(8, dtype=np.uint32)
+        self._ck(self._lib.rk_mmcs_commit(self._ctx, self._c_mats(mats), len(mats), _ptr(nodes), _u32p(root)))
+        return nodes, root
+
+    def mmcs_open(self, mats, nodes, index: int):
+        """-> (rows: the opened row of every matrix concatenated, path: log2(H) x 8 sibling digests)"""
+        h_max = max(int(m[1]) for m in mats)
+        rows = np.zeros(sum(int(m[2]) for m in mats), dtype=np.uint32)
+        path = np.zeros((max(h_max.bit_length() - 1, 0), 8), dtype=np.uint32)
+        pp = path if path.size else np.zeros((1, 8), dtype=np.uint32)
+        self._ck(self._lib.rk_mmcs_open(self._ctx, self._c_mats(mats), len(mats), _ptr(nodes), int(index), _u32p(rows), _u32p(pp)))
+        return rows, path
+
     # ---- whole segment ----
     def prove_segment(self, seg: Segment, device_inputs=None, consume_inputs: bool = False) -> np.ndarray:
         """Seal (uint32 transcript) of one segment.  `device_inputs` = (groups[3], check) of device
@@ -327,6 +352,20 @@ def session_kernel_stats(device: int) -> dict:
         _lib.check(None, lib.rk_session_kernel_stats(device, k, C.byref(st)))
         out[lib.rk_kernel_class_name(k).decode()] = {"launches": int(st.launches), "ms": float(st.ms), "bytes": float(st.bytes)}
     return out
+
+
+def mmcs_verify(heights, widths, index: int, rows, path, root, params=None) -> int:
+    """Mmcs::verify_batch on the host: 0 = accepted, 1 = rejected (params: an rk_params blob, None = risc0's)"""
+    lib = _lib.load()
+    h = np.ascontiguousarray(heights, dtype=np.uint32)
+    w = np.ascontiguousarray(widths, dtype=np.uint32)
+    r = np.ascontiguousarray(rows, dtype=np.uint32)
+    p = np.ascontiguousarray(path, dtype=np.uint32).reshape(-1)
+    if p.size == 0:
+        p = np.zeros(8, dtype=np.uint32)
+    rt = np.ascontiguousarray(root, dtype=np.uint32)
+    return int(lib.rk_mmcs_verify(C.byref(params) if params is not None else None, _u32p(h), _u32p(w), h.size, int(index), _u32p(r),
+                                  _u32p(p), _u32p(rt)))
 
 
 def make_verify_opts(poly_ext=None, poseidon2=None, params=None, program=None):

@@ -56,6 +56,10 @@ class OrProgram(C.Structure):
     _fields_ = [("steps", C.c_void_p), ("n_steps", C.c_size_t), ("ret", C.c_uint32), ("taps", C.POINTER(OrTaps))]
 
 
+class OrMatrix(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("height", C.c_uint32), ("width", C.c_uint32), ("row_major", C.c_uint32)]
+
+
 class OrIop(C.Structure):
     _fields_ = [("proof", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t), ("cells", C.c_uint32 * 24),
                 ("pool_used", C.c_size_t)]
@@ -128,6 +132,8 @@ def oracle():
             "or_params_preset": (None, [C.POINTER(OrParams), C.c_int]), "or_set_params": (C.c_int, [C.POINTER(OrParams)]),
             "or_prefix_products": (None, [vp, sz]),
             "or_pow_grind": (u32, [vp, C.c_uint]),
+            "or_mmcs_commit": (None, [vp, u32, vp]),
+            "or_mmcs_verify": (C.c_int, [vp, vp, u32, u32, vp, vp, vp]),
             "or_scatter": (None, [vp, vp, sz, vp, vp]),
             "or_free": (None, [vp]), "or_max_threads": (C.c_int, []), "or_set_threads": (None, [C.c_int]),
             "or_last_timing": (None, [C.POINTER(OrTiming)]),
