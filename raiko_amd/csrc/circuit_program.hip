@@ -364,59 +364,87 @@ struct EvalArgs {
     uint32_t inv_den[16];
 };
 
+// P points per lane: the evaluator is bound by scalar work per op (operand decode, kind branches), which a
+// wave pays once whatever it computes -- with two points per lane that cost is spread over 128 points
+// instead of 64.  A workgroup still covers WG = 256 points (its LDS tile is the same), with WG / P lanes;
+// point p of lane t is tile point t + p * (WG / P), so every access stays coalesced / conflict-free.
+template <int P>
 struct Lane {
+    static constexpr int NL = WG / P;  // lanes per workgroup
     const EvalArgs& a;
-    lds_u32* lds;
-    size_t i;
+    lds_u32* lds;      // + tid
+    size_t i;          // first point of the lane (the others: + NL, ...)
     const_u32 consts;
     const_u4 taps;
-    __device__ __forceinline__ uint32_t fetch(uint32_t opnd) const {
+    __device__ __forceinline__ void fetch(uint32_t opnd, uint32_t (&out)[P]) const {
         const uint32_t kind = opnd >> 29, idx = opnd & IDX_MASK;
-        if (kind == K_SLOT) return lds[idx * WG];
-        if (kind == K_TAP) {
+        if (kind == K_SLOT) {
+#pragma unroll
+            for (int p = 0; p < P; p++) out[p] = lds[idx * WG + p * NL];
+        } else if (kind == K_TAP) {
             const uint4 t = taps[idx];
             const char* col = reinterpret_cast<const char*>(((uint64_t)t.y << 32) | t.x);
-            const uint32_t off = ((uint32_t)i + (uint32_t)a.d - t.z) & ((uint32_t)a.d - 1);
-            return *reinterpret_cast<const uint32_t*>(col + (off << 2));
-        }
-        if (kind == K_SPILL) return a.spill[(size_t)idx * a.d + i];
-        return consts[(kind == K_CONST ? 0u : kind == K_GLOBAL ? a.glob_base : a.mix_base) + idx];
-    }
-    __device__ __forceinline__ void store(uint32_t slot, bool spilled, uint32_t v) const {
-        if (!spilled) lds[slot * WG] = v;
-        else a.spill[(size_t)slot * a.d + i] = v;
-    }
-    __device__ __forceinline__ Ext load_mix(uint32_t slot) const {
-        Ext r;
-        if (slot < a.lds_mix) {
-            const lds_u32* p = lds + (a.lds_fp + 4 * slot) * WG;
 #pragma unroll
-            for (int e = 0; e < 4; e++) r.c[e] = p[e * WG];
+            for (int p = 0; p < P; p++) {
+                const uint32_t off = ((uint32_t)i + p * NL + (uint32_t)a.d - t.z) & ((uint32_t)a.d - 1);
+                out[p] = *reinterpret_cast<const uint32_t*>(col + (off << 2));
+            }
+        } else if (kind == K_SPILL) {
+#pragma unroll
+            for (int p = 0; p < P; p++) out[p] = a.spill[(size_t)idx * a.d + i + p * NL];
         } else {
-            const uint32_t* p = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+            const uint32_t c = consts[(kind == K_CONST ? 0u : kind == K_GLOBAL ? a.glob_base : a.mix_base) + idx];
 #pragma unroll
-            for (int e = 0; e < 4; e++) r.c[e] = p[(size_t)e * a.d];
+            for (int p = 0; p < P; p++) out[p] = c;
         }
-        return r;
     }
-    __device__ __forceinline__ void store_mix(uint32_t slot, const Ext& v) const {
+    __device__ __forceinline__ void store(uint32_t slot, bool spilled, const uint32_t (&v)[P]) const {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            if (!spilled) lds[slot * WG + p * NL] = v[p];
+            else a.spill[(size_t)slot * a.d + i + p * NL] = v[p];
+        }
+    }
+    __device__ __forceinline__ void load_mix(uint32_t slot, Ext (&r)[P]) const {
         if (slot < a.lds_mix) {
-            lds_u32* p = lds + (a.lds_fp + 4 * slot) * WG;
+            const lds_u32* q = lds + (a.lds_fp + 4 * slot) * WG;
 #pragma unroll
-            for (int e = 0; e < 4; e++) p[e * WG] = v.c[e];
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) r[p].c[e] = q[e * WG + p * NL];
         } else {
-            uint32_t* p = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+            const uint32_t* q = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
 #pragma unroll
-            for (int e = 0; e < 4; e++) p[(size_t)e * a.d] = v.c[e];
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) r[p].c[e] = q[(size_t)e * a.d + p * NL];
+        }
+    }
+    __device__ __forceinline__ void store_mix(uint32_t slot, const Ext (&v)[P]) const {
+        if (slot < a.lds_mix) {
+            lds_u32* q = lds + (a.lds_fp + 4 * slot) * WG;
+#pragma unroll
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) q[e * WG + p * NL] = v[p].c[e];
+        } else {
+            uint32_t* q = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+#pragma unroll
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) q[(size_t)e * a.d + p * NL] = v[p].c[e];
         }
     }
 };
 
-__global__ __launch_bounds__(WG) void program_kernel(EvalArgs a) {
+// the domain is a multiple of WG when P > 1 (the host picks P = 1 for smaller ones): every lane's points exist
+template <int P>
+__global__ __launch_bounds__(WG / P) void program_kernel(EvalArgs a) {
     extern __shared__ uint32_t lds_all[];
+    constexpr int NL = WG / P;
     const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (i >= a.d) return;  // no barrier anywhere below
-    Lane ln{a, (lds_u32*)lds_all + threadIdx.x, i, (const_u32)a.consts, (const_u4)a.taps};
+    if (i >= a.d) return;  // P == 1 only; no barrier anywhere below
+    Lane<P> ln{a, (lds_u32*)lds_all + threadIdx.x, i, (const_u32)a.consts, (const_u4)a.taps};
     const const_u4 code = (const_u4)a.code;
     const const_u32 powers = (const_u32)a.powers;
     uint4 next = code[0];  // the list has a spare entry at the end: the fetch of op pc + 1 runs under op pc
@@ -425,20 +453,49 @@ __global__ __launch_bounds__(WG) void program_kernel(EvalArgs a) {
         next = code[pc + 1];
         const uint32_t oc = op.x & 0x7fu, dst = op.x >> 8;
         if (oc <= OP_MUL) {
-            const uint32_t x = ln.fetch(op.y), y = ln.fetch(op.z);
-            const uint32_t r = oc == OP_ADD ? bb::add(x, y) : oc == OP_SUB ? bb::sub(x, y) : bb::mul(x, y);
+            uint32_t x[P], y[P], r[P];
+            ln.fetch(op.y, x);
+            ln.fetch(op.z, y);
+#pragma unroll
+            for (int p = 0; p < P; p++) r[p] = oc == OP_ADD ? bb::add(x[p], y[p]) : oc == OP_SUB ? bb::sub(x[p], y[p]) : bb::mul(x[p], y[p]);
             ln.store(dst, (op.x & DST_SPILL) != 0, r);
         } else {
             const const_u32 pw = powers + (size_t)(op.w & 0xfffffu) * 4;
-            Ext t = bb::scale(Ext{{pw[0], pw[1], pw[2], pw[3]}}, ln.fetch(op.z));
-            if (oc == OP_COND) t = bb::mul(t, ln.load_mix(op.w >> 20), a.wm);
-            if (op.y != NONE) t = bb::add(t, ln.load_mix(op.y));
+            const Ext pwe{{pw[0], pw[1], pw[2], pw[3]}};
+            uint32_t v[P];
+            ln.fetch(op.z, v);
+            Ext t[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) t[p] = bb::scale(pwe, v[p]);
+            if (oc == OP_COND) {
+                Ext in[P];
+                ln.load_mix(op.w >> 20, in);
+#pragma unroll
+                for (int p = 0; p < P; p++) t[p] = bb::mul(t[p], in[p], a.wm);
+            }
+            if (op.y != NONE) {
+                Ext x[P];
+                ln.load_mix(op.y, x);
+#pragma unroll
+                for (int p = 0; p < P; p++) t[p] = bb::add(t[p], x[p]);
+            }
             ln.store_mix(dst, t);
         }
     }
-    Ext tot = a.ret_slot == NONE ? bb::ext_zero() : bb::scale(ln.load_mix(a.ret_slot), a.inv_den[i & ((1u << a.blow) - 1)]);
+    Ext tot[P];
+    if (a.ret_slot == NONE) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) a.check[(size_t)e * a.d + i] = tot.c[e];
+        for (int p = 0; p < P; p++) tot[p] = bb::ext_zero();
+    } else {
+        ln.load_mix(a.ret_slot, tot);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const size_t pt = i + p * NL;
+        const Ext r = bb::scale(tot[p], a.inv_den[pt & ((1u << a.blow) - 1)]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) a.check[(size_t)e * a.d + pt] = r.c[e];
+    }
 }
 
 int device_code(rk_program* pg, rk_ctx* ctx, const uint4** out) {
@@ -537,7 +594,10 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     if (spill_words) RK_TRY(dev_alloc(ctx, spill_words * 4, &d_spill));
     a.spill = (uint32_t*)d_spill;
     const size_t lds_bytes = (size_t)(a.lds_fp + 4 * a.lds_mix) * WG * 4;
-    hipLaunchKernelGGL(program_kernel, dim3((unsigned)((d + WG - 1) / WG)), dim3(WG), lds_bytes, ctx->stream, a);
+    if (d % WG == 0)  // two points per lane: the per-op scalar work is paid once per 128 points
+        hipLaunchKernelGGL(program_kernel<2>, dim3((unsigned)(d / WG)), dim3(WG / 2), lds_bytes, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(program_kernel<1>, dim3((unsigned)((d + WG - 1) / WG)), dim3(WG), lds_bytes, ctx->stream, a);
     int rc = post_launch(ctx, "program_kernel");
     if (d_spill) {
         int fr = dev_free(ctx, d_spill);  // drains the stream first
