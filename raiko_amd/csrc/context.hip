@@ -1,10 +1,49 @@
 // Context, device memory and table management + the plain C entry points for them.
+#include <dlfcn.h>
+
+#include <cstdlib>
+
 #include "internal.hpp"
 
 #include <cstring>
 #include <memory>
 
 namespace rk {
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* on = std::getenv("RK_ROCTX");
+        if (!on || !*on || *on == '0') return;
+        // rocprofv3 listens to the SDK's roctx; the older tools to libroctx64
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+
+bool trace_push(const char* name) {
+    const Roctx& r = roctx();
+    if (!r.push) return false;
+    (void)r.push(name);
+    return true;
+}
+void trace_pop() {
+    const Roctx& r = roctx();
+    if (r.pop) (void)r.pop();
+}
 
 int post_launch(rk_ctx* ctx, const char* what) {
     hipError_t e = hipGetLastError();

@@ -94,6 +94,11 @@ struct KTimer {
     ~KTimer();
 };
 
+// optional roctx ranges around the proof stages (context.hip): libroctx64 is looked up at run time and only
+// when RK_ROCTX is set, so the library has no link-time dependency on it
+bool trace_push(const char* name);
+void trace_pop();
+
 // memory (context.hip)
 int dev_alloc(rk_ctx* ctx, size_t bytes, void** out);
 int dev_free(rk_ctx* ctx, void* p);

@@ -176,7 +176,7 @@ struct PolyGroup {
 struct Stopwatch {
     rk_ctx* ctx;
     hipEvent_t ev[2];
-    bool ok = false;
+    bool ok = false, ranged = false;
     explicit Stopwatch(rk_ctx* c) : ctx(c) {
         ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
     }
@@ -186,11 +186,15 @@ struct Stopwatch {
             (void)hipEventDestroy(ev[1]);
         }
     }
-    void start() {
+    // `stage`: with RK_ROCTX=1 in the environment the stage is also a roctx range (rocprofv3 --marker-trace)
+    void start(const char* stage = nullptr) {
+        ranged = stage && rk::trace_push(stage);
         if (ok) (void)hipEventRecord(ev[0], ctx->stream);
     }
     // accumulates elapsed device time since start() into *acc (synchronises the stream)
     void stop(float* acc) {
+        if (ranged) rk::trace_pop();
+        ranged = false;
         if (!ok) return;
         (void)hipEventRecord(ev[1], ctx->stream);
         (void)hipEventSynchronize(ev[1]);
@@ -245,7 +249,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     uint32_t digest[8];
     ctx->timing = rk_timing{};
     Stopwatch total_sw(ctx), sw(ctx);
-    total_sw.start();
+    total_sw.start("segment");
 
     {
         uint32_t e[16];
@@ -297,11 +301,11 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     // Prover::commit_group; `preloaded`: pg.coeffs already holds the trace (written by a hook)
     auto commit_group = [&](int g, PolyGroup& pg, const uint32_t* trace, size_t count, bool preloaded = false) -> int {
         if (!preloaded) RK_TRY(load_group(g, pg.coeffs, trace, count * N));
-        sw.start();
+        sw.start("ntt");
         RK_TRY(rk::ntt_reverse(ctx, pg.coeffs.u32(), N, count, /*fuse_zk_shift=*/true));
         RK_TRY(pg.build(ctx, count, N));
         sw.stop(&ctx->timing.ntt);
-        sw.start();
+        sw.start("hash");
         RK_TRY(pg.merkle.build(ctx, pg.evaluated.u32(), D, count, QUERIES));
         sw.stop(&ctx->timing.hash);
         return pg.merkle.commit(ctx, iop);
@@ -330,7 +334,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         view.d_trace[2] = d_raw[2];
         view.d_lde[1] = groups[1].evaluated.u32();
         view.d_lde[2] = groups[2].evaluated.u32();
-        sw.start();
+        sw.start("circuit");
         if (hooks->accumulate(hooks->user, &view, groups[0].coeffs.u32()) != 0) {
             ctx->last_error = "circuit hook `accumulate` failed";
             return RK_ERR_CALLBACK;
@@ -350,7 +354,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         // CircuitHal::eval_check over the LDE domain, into the buffer that becomes the check group
         RK_TRY(check.coeffs.alloc(ctx, 4 * D * 4));
         for (int g = 0; g < 3; g++) view.d_lde[g] = groups[g].evaluated.u32();
-        sw.start();
+        sw.start("circuit");
         if (hooks->eval_check) {
             if (hooks->eval_check(hooks->user, &view, poly_mix.c, check.coeffs.u32()) != 0) {
                 ctx->last_error = "circuit hook `eval_check` failed";
@@ -364,7 +368,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     } else {
         RK_TRY(load_trace(check.coeffs, seg->check, 4 * D));  // pre-computed stand-in
     }
-    sw.start();
+    sw.start("ntt");
     // 4 x D evaluations -> 4 x D bit-reversed coefficients = 4 * D/N columns of N (16 for blow-up 4):
     // part c of plane e holds the coefficients n with n mod D/N = bitrev(c) of component e, i.e.
     // check(x) = sum_j x^j g_j(x^(D/N)) with g_j in column (D/N) e + bitrev(j) (for blow-up 4 the
@@ -374,12 +378,12 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     RK_TRY(rk::ntt_reverse(ctx, check.coeffs.u32(), D, 4, false));
     RK_TRY(check.build(ctx, CHECK_SIZE, N));
     sw.stop(&ctx->timing.ntt);
-    sw.start();
+    sw.start("hash");
     RK_TRY(check.merkle.build(ctx, check.evaluated.u32(), D, CHECK_SIZE, QUERIES));
     sw.stop(&ctx->timing.hash);
     RK_TRY(check.merkle.commit(ctx, iop));
 
-    sw.start();
+    sw.start("deep");
     Ext z = iop.random_ext();
     uint32_t w27 = ctx->sys.root27m;
     uint32_t back_one = bb::inv(bb::pow(w27, (uint64_t)1 << (27 - seg->po2)));
@@ -540,7 +544,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     sw.stop(&ctx->timing.deep);
 
     // ---- fri_prove ----
-    sw.start();
+    sw.start("fri");
     struct Round {
         size_t domain;
         DevBuf coeffs, evaluated;
@@ -591,7 +595,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     sw.stop(&ctx->timing.fri);
 
     // ---- queries: positions depend only on the sponge, so all openings are gathered in bulk ----
-    sw.start();
+    sw.start("query");
     std::vector<uint32_t> pos0(QUERIES);
     for (size_t q = 0; q < QUERIES; q++) pos0[q] = iop.random_bits(log2u(orig_domain)) % (uint32_t)orig_domain;
     Openings og[3], ocheck;
