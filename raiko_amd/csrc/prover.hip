@@ -193,13 +193,14 @@ struct Stopwatch {
     }
     // accumulates elapsed device time since start() into *acc (synchronises the stream)
     void stop(float* acc) {
-        if (ranged) rk::trace_pop();
+        if (ok) {
+            (void)hipEventRecord(ev[1], ctx->stream);
+            (void)hipEventSynchronize(ev[1]);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) *acc += ms;
+        }
+        if (ranged) rk::trace_pop();  // after the wait: the range covers the stage's device work
         ranged = false;
-        if (!ok) return;
-        (void)hipEventRecord(ev[1], ctx->stream);
-        (void)hipEventSynchronize(ev[1]);
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) *acc += ms;
     }
 };
 
