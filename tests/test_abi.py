@@ -78,11 +78,11 @@ def test_product_never_imports_the_oracle():
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("(oracle/", "(x/"), f
 
 
-def _build_demo(tmp_path):
+def _build_demo(tmp_path, name="session_demo"):
     import subprocess
-    exe = str(tmp_path / "session_demo")
+    exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "session_demo.c"), "-o", exe,
+                           os.path.join(ROOT, "examples", name + ".c"), "-o", exe,
                            "-L", os.path.join(ROOT, "raiko_amd"), "-lraiko_hip"])
     return exe
 
@@ -99,6 +99,10 @@ def test_plain_c_caller_compiles_against_the_header(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "raiko_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([exe, "2", "8"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no usable GPU" in r.stderr
+    # the constraint-list demo: the program is compiled on the host before any GPU is needed
+    exe2 = _build_demo(tmp_path, "program_demo")
+    r = subprocess.run([exe2, "6"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no usable GPU" in r.stderr and "19 steps, 11 ops" in r.stdout
 
 
 @pytest.mark.gpu
@@ -112,3 +116,16 @@ def test_plain_c_caller_proves_a_session(tmp_path):
     # the same through the device-list form of rk_session_opts (a one-entry list on this box)
     r = subprocess.run([exe, "4", "10", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "4 segments of 2^10 cycles proven and verified" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_proves_from_a_constraint_list(tmp_path):
+    """examples/program_demo.c: a circuit given as data (rk_program) proven and verified from C; a wrong
+    witness cell is caught by the constraint identity only"""
+    import subprocess
+    exe = _build_demo(tmp_path, "program_demo")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "raiko_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for po2 in ("4", "11"):
+        r = subprocess.run([exe, po2], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "verifier says 0" in r.stdout and "with it 70" in r.stdout
