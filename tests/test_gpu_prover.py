@@ -302,3 +302,35 @@ def test_execute_segment_and_prove_an_elf(hal):
     assert [s.exit_code[0] for s in receipt.segments] == ["SystemSplit"] * 3 + ["Halted"]
     uuid, back = rc.deserialize(rc.serialize("", receipt))
     assert back.journal == receipt.journal and len(back.seals) == 4
+
+
+def test_overlapping_run_calls_are_safe():
+    """raiko's host lets up to `concurrency_limit` = 16 proofs overlap (reference host/src/lib.rs:38-41) and the
+    `Prover` trait has no self (lib/src/prover.rs:52-62): concurrent rk_prove_session calls for one GPU are
+    serialised inside the library, a release in between is harmless, and every caller gets its own seals"""
+    import threading
+    from raiko_amd import _lib
+    from raiko_amd.hal import prove_session
+    from raiko_amd.segment import synthetic_segment
+    jobs = [[synthetic_segment(8 + (t % 3), (4, 4, 12), seed=500 + 10 * t + i) for i in range(3)] for t in range(6)]
+    want = [[o.oracle_prove(s) for s in segs] for segs in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def worker(t):
+        try:
+            got[t] = prove_session(jobs[t], inflight=2, verify=True)
+            if t == 2:
+                _lib.load().rk_session_release()
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for t in range(len(jobs)):
+        for a, b in zip(got[t], want[t]):
+            assert np.array_equal(a, b)
