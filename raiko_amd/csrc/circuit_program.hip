@@ -13,11 +13,13 @@
 //     used (L2 / L1 hits) instead of occupying a slot for the rest of the program;
 //   * live ADD / SUB / MUL results and mix tots get slots by a linear scan over last uses, lowest
 //     free number first, so the busiest slots are the low ones.
-// Evaluate (GPU): one LDE point per lane, 256 lanes per workgroup, no synchronisation at all (a
-// lane only touches its own column of the slot array).  Slots below the LDS budget live in LDS as
-// [slot][lane] (consecutive lanes, consecutive banks), the rest in a global scratch matrix
-// [slot][point].  The op list, constants and powers are wave-uniform and come through the scalar
-// cache; every branch on an opcode or operand kind is a scalar branch.
+// Evaluate (GPU): a workgroup covers 256 LDE points with 128 lanes (two points per lane: the scalar
+// decode of an op is paid once per wave whatever it computes), no synchronisation at all (a lane
+// only touches its own columns of the slot array).  Slots below the LDS budget live in LDS as
+// [slot][point] (consecutive lanes, consecutive banks), the rest in a global scratch matrix
+// [slot][point]; which is which is settled at compile time.  The op list, constants, powers and the
+// per-proof tap table are wave-uniform and come through the scalar cache; every branch on an opcode
+// or operand kind is a scalar branch.  Bound by scalar instructions (profiles/r02_pmc_program.json).
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -347,7 +349,6 @@ typedef uint32_t lds_u32;
 #endif
 typedef const RK_CONST_AS uint4* const_u4;
 typedef const RK_CONST_AS uint32_t* const_u32;
-typedef const RK_CONST_AS uint64_t* const_u64;
 
 struct EvalArgs {
     uint64_t code;       // uint4 per op
