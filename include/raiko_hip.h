@@ -278,6 +278,15 @@ int rk_program_get_info(const rk_program* prog, rk_program_info* out);
  * hooks with `program` set; a hook of the caller's may call it too) */
 int rk_program_eval_check(const rk_program* prog, const rk_circuit_view* view, const uint32_t poly_mix[4],
                           uint32_t* d_check);
+/* Optional: turn the list into a gfx950 code object for ctx's GPU now (straight-line HIP generated from the list
+ * -- what tools/circuit_gen.py emits at build time -- compiled with hiprtc; seconds for 10^4 steps).  From then on
+ * rk_program_eval_check on that GPU runs the generated kernel (about 3x the interpreter's speed) instead of the
+ * interpreter; results are identical.  RK_ERR_HIP with the compiler's log in rk_last_error if it cannot be
+ * built -- the interpreter stays in charge. */
+int rk_program_compile(rk_program* prog, rk_ctx* ctx);
+/* the HIP source rk_program_compile hands to the compiler (NUL-terminated; *length without the NUL;
+ * RK_ERR_CAPACITY with *length set when `out` is too small) */
+int rk_program_source(const rk_program* prog, char* out, size_t capacity, size_t* length);
 /* CircuitDef::poly_ext from the program (host): the value rk_poly_ext_fn returns.  ext_w: canonical W
  * of the extension (rk_params.ext_w; 0 = risc0's) */
 int rk_program_poly_ext(const rk_program* prog, uint32_t ext_w, const uint32_t poly_mix[4], const uint32_t* eval_u_ext,

@@ -296,6 +296,8 @@ extern "C" {
     pub fn rk_program_destroy(prog: *mut rk_program) -> c_int;
     pub fn rk_program_get_info(prog: *const rk_program, out: *mut rk_program_info) -> c_int;
     pub fn rk_program_eval_check(prog: *const rk_program, view: *const rk_circuit_view, poly_mix: *const u32, d_check: *mut u32) -> c_int;
+    pub fn rk_program_compile(prog: *mut rk_program, ctx: *mut rk_ctx) -> c_int;
+    pub fn rk_program_source(prog: *const rk_program, out: *mut c_char, capacity: usize, length: *mut usize) -> c_int;
     pub fn rk_program_poly_ext(prog: *const rk_program, ext_w: u32, poly_mix: *const u32, eval_u_ext: *const u32, n_taps: usize, globals: *const u32, n_globals: u32, mix: *const u32, n_mix: u32, out_ext: *mut u32) -> c_int;
     pub fn rk_prove_segment(ctx: *mut rk_ctx, seg: *const rk_segment, h_seal: *mut u32, seal_capacity_words: usize, seal_words: *mut usize) -> c_int;
     pub fn rk_verify_segment(pub_: *const rk_segment, seal: *const u32, seal_words: usize) -> c_int;

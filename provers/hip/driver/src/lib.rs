@@ -383,6 +383,14 @@ mod circuit {
                 let taps = tapset();
                 let mut prog: *mut rk_program = ptr::null_mut();
                 let rc = unsafe { rk_program_create(steps.as_ptr(), steps.len(), def.ret as u32, &taps.as_rk_taps(), &mut prog) };
+                // the generated kernel (hiprtc, once per process) instead of the interpreter, where it builds
+                if rc == RK_OK {
+                    let mut ctx: *mut rk_ctx = ptr::null_mut();
+                    if unsafe { rk_ctx_create(0, ptr::null_mut(), &mut ctx) } == RK_OK {
+                        let _ = unsafe { rk_program_compile(prog, ctx) };
+                        unsafe { rk_ctx_destroy(ctx) };
+                    }
+                }
                 if rc == RK_OK { prog as usize } else { 0 }
             }) as *const rk_program;
         }

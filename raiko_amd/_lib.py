@@ -199,6 +199,8 @@ SYMBOLS = {
     "rk_program_destroy": (C.c_int, [_vp]),
     "rk_program_get_info": (C.c_int, [_vp, _vp]),
     "rk_program_eval_check": (C.c_int, [_vp, C.POINTER(RkCircuitView), u32p, _vp]),
+    "rk_program_compile": (C.c_int, [_vp, _vp]),
+    "rk_program_source": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "rk_program_poly_ext": (C.c_int, [_vp, _u32, u32p, u32p, _sz, u32p, _u32, u32p, _u32, u32p]),
     "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
     "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),

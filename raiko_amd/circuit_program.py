@@ -177,6 +177,20 @@ class Program:
         _lib.check(None, _lib.load().rk_program_get_info(self._h, C.byref(i)))
         return {n: int(getattr(i, n)) for n, _ in i._fields_}
 
+    def compile(self, hal) -> None:
+        """rk_program_compile: generate straight-line HIP from the list and build it for hal's GPU with hiprtc;
+        rk_program_eval_check on that GPU then runs the generated kernel instead of the interpreter"""
+        _lib.check(hal._ctx, _lib.load().rk_program_compile(self._h, hal._ctx))
+
+    def source(self) -> str:
+        """the HIP source rk_program_compile hands to the compiler"""
+        lib = _lib.load()
+        n = C.c_size_t(0)
+        lib.rk_program_source(self._h, None, 0, C.byref(n))
+        buf = C.create_string_buffer(n.value + 1)
+        _lib.check(None, lib.rk_program_source(self._h, buf, n.value + 1, C.byref(n)))
+        return buf.value.decode()
+
     def hooks(self, accumulate_from: Optional[int] = None) -> int:
         """address of an rk_circuit_hooks {user, accumulate of `accumulate_from` (an rk_circuit_hooks
         address, e.g. the toy circuit's), eval_check NULL, program this}"""

@@ -1,0 +1,399 @@
+// Run-time code generation for a constraint list (rk_program_compile): the list is turned into
+// straight-line HIP -- the form risc0's build gives its CUDA / Metal eval_check kernels and
+// tools/circuit_gen.py gives a circuit at build time -- and compiled for gfx950 with hiprtc, so a host
+// that hands the list over at run time (the Rust crate does, provers/hip/driver/src/lib.rs) gets the
+// generated kernel's speed (3x the interpreter's) without a build step.  One code object per device,
+// kept inside the rk_program; rk_program_eval_check uses it when it is there.
+//
+// The generator reads the validated step list itself (its own liveness pass, independent of the
+// interpreter's compiler -- the two are checked against each other and against the oracle):
+//   * dead steps dropped, every mix state's `mul` folded to a power of poly_mix (table per proof);
+//   * constants as Montgomery literals, taps as (group, column, back) immediates, arguments from the table;
+//   * statements cut into __noinline__ functions of CHUNK statements (one basic block of 10^4 statements
+//     costs the compiler tens of minutes), values that cross a cut travel through per-lane carry arrays,
+//     leaves are re-read where they are used.
+#include <hip/hiprtc.h>
+
+#include <algorithm>
+#include <cstring>
+#include <set>
+#include <sstream>
+
+#include "circuit_program.hpp"
+
+namespace {
+
+using bb::Ext;
+constexpr size_t CHUNK = 300;
+constexpr uint32_t NONE = rk::PROGRAM_NONE;
+
+// what the generated kernel receives (same layout as `struct Args` in the source below)
+struct JitArgs {
+    const uint32_t* lde[3];
+    uint64_t tab;        // globals | accum mix | powers (4 words each)
+    uint32_t* check;
+    uint64_t d;
+    uint32_t glob_base, mix_base, pw_base, wm;
+    uint32_t blow, pad;
+    uint32_t inv_den[16];
+};
+
+const char* PRELUDE = R"SRC(
+#define RK_FI __device__ inline __attribute__((always_inline))
+#define RK_NI __device__ __attribute__((noinline))
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef const __attribute__((address_space(4))) u32* const_u32;
+namespace bb {
+constexpr u32 P = 2013265921u;
+constexpr u32 MPRIME = 0x88000001u;
+RK_FI u32 add(u32 a, u32 b) { u32 r = a + b, s = r - P; return s < r ? s : r; }
+RK_FI u32 sub(u32 a, u32 b) { u32 r = a - b, s = r + P; return s < r ? s : r; }
+RK_FI u32 mul(u32 a, u32 b) {
+    u64 t = (u64)a * b;
+    u32 q = (u32)t * (0u - MPRIME);
+    u64 w = t + (u64)q * P;
+    u32 r = (u32)(w >> 32), s = r - P;
+    return s < r ? s : r;
+}
+struct Ext { u32 c[4]; };
+RK_FI Ext ext_zero() { return Ext{{0, 0, 0, 0}}; }
+RK_FI Ext add(const Ext& a, const Ext& b) { return Ext{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}}; }
+RK_FI Ext scale(const Ext& a, u32 s) { return Ext{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}}; }
+RK_FI Ext mul(const Ext& a, const Ext& b, u32 wm) {
+    u32 h0 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
+    u32 h1 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
+    u32 h2 = mul(a.c[3], b.c[3]);
+    Ext r;
+    r.c[0] = add(mul(a.c[0], b.c[0]), mul(wm, h0));
+    r.c[1] = add(add(mul(a.c[0], b.c[1]), mul(a.c[1], b.c[0])), mul(wm, h1));
+    r.c[2] = add(add(add(mul(a.c[0], b.c[2]), mul(a.c[1], b.c[1])), mul(a.c[2], b.c[0])), mul(wm, h2));
+    r.c[3] = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
+    return r;
+}
+}  // namespace bb
+using bb::Ext;
+struct Args {
+    const u32* lde[3];
+    u64 tab;
+    u32* check;
+    u64 d;
+    u32 glob_base, mix_base, pw_base, wm;
+    u32 blow, pad;
+    u32 inv_den[16];
+};
+RK_FI Ext load_pw(const_u32 tab, u32 base, u32 j) {
+    const_u32 p = tab + base + 4 * j;
+    return Ext{{p[0], p[1], p[2], p[3]}};
+}
+)SRC";
+
+struct Fp {
+    uint32_t op, a, b;
+    bool live = false;
+};
+struct Mx {
+    uint32_t op, x, v, inner;
+    uint64_t k = 0;
+    bool zero = false, live = false;
+};
+
+// the source of the kernel; *powers: the exponents its table holds
+std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
+    const auto& steps = pg.steps;
+    std::vector<Fp> fp;
+    std::vector<Mx> mx;
+    std::vector<std::pair<bool, uint32_t>> where;
+    where.reserve(steps.size());
+    for (const rk_poly_step& st : steps) {  // validated by rk_program_create
+        if (st.op <= RK_STEP_MUL) {
+            where.push_back({false, (uint32_t)fp.size()});
+            fp.push_back(Fp{st.op, st.a, st.b});
+        } else {
+            Mx m{st.op, st.a, st.b, st.c};
+            if (st.op == RK_STEP_TRUE) {
+                m.zero = true;
+            } else if (st.op == RK_STEP_AND_COND) {
+                m.k = mx[st.a].k + mx[st.c].k;
+                m.zero = mx[st.a].zero && mx[st.c].zero;
+            } else {
+                m.k = mx[st.a].k + 1;
+            }
+            where.push_back({true, (uint32_t)mx.size()});
+            mx.push_back(m);
+        }
+    }
+    auto is_leaf = [&](uint32_t i) { return fp[i].op == RK_STEP_CONST || fp[i].op == RK_STEP_GET || fp[i].op == RK_STEP_GET_GLOBAL; };
+    mx[pg.ret].live = true;
+    for (size_t s = where.size(); s-- > 0;) {
+        if (where[s].first) {
+            const Mx& m = mx[where[s].second];
+            if (!m.live || m.op == RK_STEP_TRUE) continue;
+            mx[m.x].live = true;
+            if (m.op == RK_STEP_AND_EQZ) {
+                fp[m.v].live = true;
+            } else if (!mx[m.inner].zero) {
+                mx[m.inner].live = true;
+                fp[m.v].live = true;
+            }
+        } else {
+            const Fp& v = fp[where[s].second];
+            if (v.live && !is_leaf(where[s].second)) fp[v.a].live = fp[v.b].live = true;
+        }
+    }
+    std::set<uint64_t> pw_set;
+    for (const Mx& m : mx)
+        if (m.live && m.op != RK_STEP_TRUE && !m.zero) pw_set.insert(mx[m.x].k);
+    std::vector<uint32_t> powers(pw_set.begin(), pw_set.end());
+    auto pw_idx = [&](uint64_t k) { return (uint32_t)(std::lower_bound(powers.begin(), powers.end(), (uint32_t)k) - powers.begin()); };
+    *powers_out = powers;
+
+    // statements in list order; an AND_COND over an identically-zero block is its x under another name
+    std::vector<uint32_t> alias(mx.size(), NONE);
+    auto name_mx = [&](uint32_t i) {
+        while (alias[i] != NONE) i = alias[i];
+        return i;
+    };
+    struct Item {
+        bool is_mix;
+        uint32_t idx;
+    };
+    std::vector<Item> items;
+    for (const auto& w : where) {
+        if (!w.first) {
+            if (fp[w.second].live && !is_leaf(w.second)) items.push_back(Item{false, w.second});
+        } else {
+            const Mx& m = mx[w.second];
+            if (!m.live || m.op == RK_STEP_TRUE || m.zero) continue;
+            if (m.op == RK_STEP_AND_COND && mx[m.inner].zero) {
+                alias[w.second] = m.x;
+                continue;
+            }
+            items.push_back(Item{true, w.second});
+        }
+    }
+    const size_t n_chunks = std::max<size_t>(1, (items.size() + CHUNK - 1) / CHUNK);
+    // chunk of every statement's result; chunks that read it
+    std::vector<uint32_t> fp_chunk(fp.size(), NONE), mx_chunk(mx.size(), NONE), fp_last(fp.size(), 0), mx_last(mx.size(), 0);
+    auto note = [&](bool is_mix, uint32_t j, uint32_t c) {
+        uint32_t& last = is_mix ? mx_last[j] : fp_last[j];
+        last = std::max(last, c);
+    };
+    for (size_t t = 0; t < items.size(); t++) {
+        const uint32_t c = (uint32_t)(t / CHUNK);
+        const Item& it = items[t];
+        if (it.is_mix) {
+            mx_chunk[it.idx] = c;
+            const Mx& m = mx[it.idx];
+            if (!is_leaf(m.v)) note(false, m.v, c);
+            if (!mx[m.x].zero) note(true, name_mx(m.x), c);
+            if (m.op == RK_STEP_AND_COND) note(true, name_mx(m.inner), c);
+        } else {
+            fp_chunk[it.idx] = c;
+            const Fp& v = fp[it.idx];
+            if (!is_leaf(v.a)) note(false, v.a, c);
+            if (!is_leaf(v.b)) note(false, v.b, c);
+        }
+    }
+    const bool ret_zero = mx[pg.ret].zero;
+    const uint32_t ret_name = ret_zero ? NONE : name_mx(pg.ret);
+    if (!ret_zero) note(true, ret_name, (uint32_t)n_chunks);  // read by the kernel after the last function
+
+    std::vector<uint32_t> fp_slot(fp.size(), NONE), mx_slot(mx.size(), NONE);
+    std::vector<uint32_t> free_fp, free_mx;
+    uint32_t next_fp = 0, next_mx = 0;
+    std::vector<std::vector<std::pair<bool, uint32_t>>> release(n_chunks + 1);
+    std::ostringstream src;
+    src << PRELUDE;
+    std::vector<std::string> calls;
+    for (size_t c = 0; c < n_chunks; c++) {
+        std::ostringstream body;
+        std::set<uint32_t> have_fp, have_mx;
+        auto use_fp = [&](uint32_t j) -> std::string {
+            std::string nm = "f" + std::to_string(j);
+            if (have_fp.count(j)) return nm;
+            have_fp.insert(j);
+            const Fp& v = fp[j];
+            if (v.op == RK_STEP_CONST) {
+                body << "    const u32 " << nm << " = " << bb::encode(v.a) << "u;\n";
+            } else if (v.op == RK_STEP_GET) {
+                const rk::Tap& t = pg.taps[v.a];
+                body << "    const u32 " << nm << " = a.lde[" << t.group << "][(u64)" << t.offset << "u * a.d + ";
+                if (t.back == 0) body << "i];\n";
+                else body << "((i + a.d - ((u64)" << t.back << "u << a.blow)) & (a.d - 1))];\n";
+            } else if (v.op == RK_STEP_GET_GLOBAL) {
+                body << "    const u32 " << nm << " = tab[a." << (v.a == 0 ? "glob_base" : "mix_base") << " + " << v.b << "u];\n";
+            } else {
+                body << "    const u32 " << nm << " = c[" << fp_slot[j] << "];\n";
+            }
+            return nm;
+        };
+        auto use_mx = [&](uint32_t j) -> std::string {
+            std::string nm = "x" + std::to_string(j);
+            if (have_mx.count(j)) return nm;
+            have_mx.insert(j);
+            body << "    const Ext " << nm << " = cx[" << mx_slot[j] << "];\n";
+            return nm;
+        };
+        for (size_t t = c * CHUNK; t < std::min(items.size(), (c + 1) * CHUNK); t++) {
+            const Item& it = items[t];
+            if (!it.is_mix) {
+                const Fp& v = fp[it.idx];
+                const char* fn = v.op == RK_STEP_ADD ? "add" : v.op == RK_STEP_SUB ? "sub" : "mul";
+                std::string a_ = use_fp(v.a), b_ = use_fp(v.b);
+                body << "    const u32 f" << it.idx << " = bb::" << fn << "(" << a_ << ", " << b_ << ");\n";
+                have_fp.insert(it.idx);
+                if (fp_last[it.idx] > c) {
+                    uint32_t k;
+                    if (!free_fp.empty()) {
+                        k = free_fp.back();
+                        free_fp.pop_back();
+                    } else {
+                        k = next_fp++;
+                    }
+                    fp_slot[it.idx] = k;
+                    release[fp_last[it.idx]].push_back({false, it.idx});
+                    body << "    c[" << k << "] = f" << it.idx << ";\n";
+                }
+            } else {
+                const Mx& m = mx[it.idx];
+                std::string term = "bb::scale(load_pw(tab, a.pw_base, " + std::to_string(pw_idx(mx[m.x].k)) + "), " + use_fp(m.v) + ")";
+                if (m.op == RK_STEP_AND_COND) term = "bb::mul(" + term + ", " + use_mx(name_mx(m.inner)) + ", a.wm)";
+                if (!mx[m.x].zero) term = "bb::add(" + use_mx(name_mx(m.x)) + ", " + term + ")";
+                body << "    const Ext x" << it.idx << " = " << term << ";\n";
+                have_mx.insert(it.idx);
+                if (mx_last[it.idx] > c) {
+                    uint32_t k;
+                    if (!free_mx.empty()) {
+                        k = free_mx.back();
+                        free_mx.pop_back();
+                    } else {
+                        k = next_mx++;
+                    }
+                    mx_slot[it.idx] = k;
+                    release[mx_last[it.idx]].push_back({true, it.idx});
+                    body << "    cx[" << k << "] = x" << it.idx << ";\n";
+                }
+            }
+        }
+        for (const auto& r : release[c]) (r.first ? free_mx : free_fp).push_back(r.first ? mx_slot[r.second] : fp_slot[r.second]);
+        src << (n_chunks == 1 ? "RK_FI" : "RK_NI") << " void part" << c
+            << "(const Args& a, const_u32 tab, u64 i, u32* c, Ext* cx) {\n"
+            << body.str() << "}\n";
+        calls.push_back("    part" + std::to_string(c) + "(a, tab, i, c, cx);\n");
+    }
+    src << "extern \"C\" __global__ __attribute__((amdgpu_flat_work_group_size(1, 256))) void rk_jit_eval_check(Args a) {\n"
+        << "    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;\n"
+        << "    if (i >= a.d) return;\n"
+        << "    const const_u32 tab = (const_u32)a.tab;\n"
+        << "    u32 c[" << std::max<uint32_t>(1, next_fp) << "];\n"
+        << "    Ext cx[" << std::max<uint32_t>(1, next_mx) << "];\n";
+    for (const std::string& call : calls) src << call;
+    src << "    const Ext tot = bb::scale(" << (ret_zero ? std::string("bb::ext_zero()") : "cx[" + std::to_string(mx_slot[ret_name]) + "]")
+        << ", a.inv_den[i & ((1u << a.blow) - 1)]);\n"
+        << "    for (int e = 0; e < 4; e++) a.check[(u64)e * a.d + i] = tot.c[e];\n"
+        << "}\n";
+    return src.str();
+}
+
+}  // namespace
+
+namespace rk {
+
+// the generated kernel for the context's device, or nullptr when rk_program_compile has not run for it
+const JitEntry* program_jit(rk_program* pg, int device) {
+    std::lock_guard<std::mutex> lk(pg->mu);
+    auto it = pg->jit.find(device);
+    return it == pg->jit.end() ? nullptr : &it->second;
+}
+
+int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const rk_circuit_view* v, const uint32_t* d_tab, uint32_t glob_base,
+                       uint32_t mix_base, uint32_t pw_base, uint32_t* d_check, const uint32_t inv_den[16]) {
+    const unsigned blow = ctx->sys.blowup_log2;
+    JitArgs a{};
+    for (int g = 0; g < 3; g++) a.lde[g] = v->d_lde[g];
+    a.tab = (uint64_t)(uintptr_t)d_tab;
+    a.check = d_check;
+    a.d = (uint64_t)1 << (v->po2 + blow);
+    a.glob_base = glob_base;
+    a.mix_base = mix_base;
+    a.pw_base = pw_base;
+    a.wm = ctx->sys.wm;
+    a.blow = blow;
+    std::memcpy(a.inv_den, inv_den, sizeof a.inv_den);
+    size_t sz = sizeof a;
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    RK_HIP_TRY(ctx, hipModuleLaunchKernel(je.kernel, (unsigned)((a.d + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, nullptr, cfg));
+    return RK_OK;
+}
+
+}  // namespace rk
+
+extern "C" {
+
+int rk_program_compile(rk_program* pg, rk_ctx* ctx) {
+    RK_GUARD_BEGIN
+    if (!pg || !ctx) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> lk(pg->mu);
+        if (pg->jit.count(ctx->device)) return RK_OK;
+    }
+    rk::JitEntry je;
+    const std::string src = generate(*pg, &je.powers);
+    je.n_powers = (uint32_t)je.powers.size();
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "rk_program.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        ctx->last_error = "hiprtcCreateProgram failed";
+        return RK_ERR_HIP;
+    }
+    hipDeviceProp_t props;
+    RK_HIP_TRY(ctx, hipGetDeviceProperties(&props, ctx->device));
+    const std::string arch = std::string("--offload-arch=") + props.gcnArchName;
+    const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+    const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        (void)hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+        ctx->last_error = "hiprtcCompileProgram: " + log.substr(0, 2000);
+        (void)hiprtcDestroyProgram(&prog);
+        return RK_ERR_HIP;
+    }
+    size_t code_size = 0;
+    (void)hiprtcGetCodeSize(prog, &code_size);
+    std::vector<char> code(code_size);
+    (void)hiprtcGetCode(prog, code.data());
+    (void)hiprtcDestroyProgram(&prog);
+    RK_HIP_TRY(ctx, hipModuleLoadData(&je.module, code.data()));
+    hipError_t e = hipModuleGetFunction(&je.kernel, je.module, "rk_jit_eval_check");
+    if (e != hipSuccess) {
+        (void)hipModuleUnload(je.module);
+        ctx->last_error = std::string("hipModuleGetFunction: ") + hipGetErrorString(e);
+        return RK_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(pg->mu);
+    if (pg->jit.count(ctx->device)) {  // another thread got there first
+        (void)hipModuleUnload(je.module);
+        return RK_OK;
+    }
+    pg->jit.emplace(ctx->device, std::move(je));
+    return RK_OK;
+    RK_GUARD_END
+}
+
+// the HIP source rk_program_compile would hand to hiprtc (for inspection and for building it ahead of time)
+int rk_program_source(const rk_program* pg, char* out, size_t capacity, size_t* length) {
+    RK_GUARD_BEGIN
+    if (!pg || !length) return RK_ERR_INVALID;
+    std::vector<uint32_t> powers;
+    const std::string src = generate(*pg, &powers);
+    *length = src.size();
+    if (!out || capacity < src.size() + 1) return RK_ERR_CAPACITY;
+    std::memcpy(out, src.c_str(), src.size() + 1);
+    return RK_OK;
+    RK_GUARD_END
+}
+
+}  // extern "C"

@@ -28,12 +28,14 @@
 #include <queue>
 
 #include "internal.hpp"
+#include "circuit_program.hpp"
 
 namespace {
 
 using bb::Ext;
+using rk::Tap;
 
-constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t NONE = rk::PROGRAM_NONE;
 // operand = kind << 29 | index.  K_SLOT: a slot kept in LDS; K_SPILL: one in the HBM scratch matrix (which is
 // which is settled when the list is compiled); K_TAP: index into the per-proof tap table {column base, shift}.
 // The evaluator is bound by scalar instructions (profiles/r02_pmc_program.json), so what can be a table
@@ -50,30 +52,7 @@ constexpr int WG = 256;
 constexpr uint32_t LDS_WORDS_PER_LANE = 60;  // 60 KB per workgroup at most: two workgroups per CU
 constexpr uint32_t LDS_MIX_SLOTS = 6;
 
-struct Tap {
-    uint32_t group, offset, back;
-};
-
 }  // namespace
-
-struct rk_program {
-    std::vector<rk_poly_step> steps;
-    uint32_t ret = 0;
-    std::vector<Tap> taps;
-    uint32_t group_min[3] = {0, 0, 0};  // columns a view must have per group
-
-    std::vector<uint4> code;
-    std::vector<uint32_t> consts;   // Montgomery
-    std::vector<uint32_t> powers;   // distinct exponents of poly_mix, ascending
-    uint32_t n_fp_slots = 0, n_mix_slots = 0;
-    uint32_t lds_fp = 0, lds_mix = 0;  // how many of them live in LDS (the rest in the HBM scratch matrix)
-    uint32_t ret_slot = NONE;       // NONE: the result is identically zero
-    uint32_t need_globals = 0, need_mix = 0;
-    rk_program_info info{};
-
-    std::mutex mu;
-    std::map<int, void*> d_code;    // per device
-};
 
 namespace {
 
@@ -537,6 +516,29 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     const size_t n = (size_t)1 << v->po2, d = n << blow;
     const uint32_t wm = ctx->sys.wm;
 
+    if (const JitEntry* je = program_jit(pg, ctx->device)) {
+        // the generated kernel (rk_program_compile): table = globals | mix | the powers its code indexes
+        const size_t o_mix = v->n_globals, o_pw = (o_mix + v->n_mix + 3) & ~(size_t)3, words = o_pw + 4 * (size_t)je->n_powers;
+        std::vector<uint32_t> tab(words + 4, 0);
+        if (v->n_globals) std::memcpy(tab.data(), v->globals, (size_t)v->n_globals * 4);
+        if (v->n_mix) std::memcpy(&tab[o_mix], v->mix, (size_t)v->n_mix * 4);
+        Ext pm, cur = bb::ext_one();
+        std::memcpy(pm.c, poly_mix, 16);
+        uint32_t at = 0;
+        for (uint32_t j = 0; j < je->n_powers; j++) {
+            cur = bb::mul(cur, bb::pow(pm, je->powers[j] - at, wm), wm);
+            at = je->powers[j];
+            std::memcpy(&tab[o_pw + 4 * j], cur.c, 16);
+        }
+        uint32_t inv_den[16] = {0};
+        const uint32_t sn = bb::pow(ctx->sys.shiftm, n), wb = bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - blow));
+        for (unsigned r = 0; r < (1u << blow); r++) inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(wb, r)), bb::ONE));
+        void* d_tab = nullptr;
+        RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
+        RK_HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
+        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `tab` is a stack-lifetime host buffer
+        return program_jit_launch(ctx, *je, v, (const uint32_t*)d_tab, 0, (uint32_t)o_mix, (uint32_t)o_pw, d_check, inv_den);
+    }
     EvalArgs a{};
     const uint4* d_ops = nullptr;
     RK_TRY(device_code(pg, ctx, &d_ops));
@@ -696,6 +698,9 @@ int rk_program_destroy(rk_program* pg) {
     if (!pg) return RK_OK;
     for (auto& kv : pg->d_code) {
         if (hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second);
+    }
+    for (auto& kv : pg->jit) {
+        if (hipSetDevice(kv.first) == hipSuccess && kv.second.module) (void)hipModuleUnload(kv.second.module);
     }
     delete pg;
     return RK_OK;

@@ -223,3 +223,33 @@ def test_generated_straight_line_code_equals_the_interpreter(hal, toy, po2):
     bad = by_generated.copy()
     bad[-1] ^= 1
     assert verify_segment(seg, bad, poly_ext=toy.gen_poly_ext_fn()) != 0
+
+
+@pytest.mark.parametrize("seed,po2,n_live", [(10, 4, 0), (11, 8, 30), (12, 10, 120), (13, 9, 0)])
+def test_runtime_compiled_programs_match_the_oracle(hal, seed, po2, n_live):
+    """rk_program_compile: the list as straight-line HIP built with hiprtc at run time; the generated kernel, the
+    interpreter and the oracle's literal interpretation agree word for word"""
+    rng = np.random.default_rng(2000 + seed)
+    taps = synthetic_tapset(int(rng.integers(4, 12)), int(rng.integers(3, 9)), int(rng.integers(4, 40)))
+    n_globals, n_mix = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    steps, ret = random_program(rng, taps, n_globals, n_mix, n_fp_ops=int(rng.integers(50, 900)), n_live=n_live, depth=3,
+                                n_constraints=50, local=seed == 13)
+    interp, jit = cp.Program(steps, ret, taps), cp.Program(steps, ret, taps)
+    jit.compile(hal)
+    jit.compile(hal)                                     # idempotent
+    assert "rk_jit_eval_check" in jit.source()
+    d = 4 << po2
+    lde = [o.rand_elems(rng, (int(w), d)) for w in taps.group_size]
+    globals_, mix, pm = o.rand_elems(rng, (n_globals,)), o.rand_elems(rng, (n_mix,)), o.rand_elems(rng, (4,))
+    want = oracle_eval_check(interp, taps, po2, lde, globals_, mix, pm)
+    assert np.array_equal(run_eval_check(hal, interp, po2, lde, globals_, mix, pm), want)
+    assert np.array_equal(run_eval_check(hal, jit, po2, lde, globals_, mix, pm), want)
+
+
+def test_runtime_compiled_toy_circuit_seal(hal, toy):
+    seg = toy_with_program(toy, 10, (8, 4, 8), seed=77)
+    want = o.oracle_prove(seg)
+    seg.program.compile(hal)
+    got = hal.prove_segment(seg)
+    assert np.array_equal(got, want)
+    assert verify_segment(seg, got, program=seg.program) == 0

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--sizes", default="1000,10000,40000")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--jit", action="store_true", help="also rk_program_compile the expression-tree lists (hiprtc) and time the generated kernel")
     ap.add_argument("--only-local", action="store_true", help="only the expression-tree list (for counter collection)")
     ap.add_argument("--gen", help="directory with <name>.npz (steps, ret) and lib<name>.so built from tools/circuit_gen.py output: "
                                   "the list through the interpreter and through its generated code, outputs compared")
@@ -79,7 +80,13 @@ def main():
         run = lambda: _lib.check(hal._ctx, lib.rk_program_eval_check(prog.handle, C.byref(v), pm.ctypes.data_as(_lib.u32p), out.ptr))
         t = timed(hal, run, args.reps)
         shape = "expression trees (few values alive)" if local else "uniform operands (everything stays alive: spill-bound)"
-        print(json.dumps({"what": "rk_program_eval_check, random list, " + shape, "po2": po2, "points": d, "widths": widths,
+        extra = {}
+        if local and args.jit:
+            t0 = time.perf_counter()
+            prog.compile(hal)
+            extra["hiprtc_compile_s"] = round(time.perf_counter() - t0, 2)
+            extra["ms_runtime_compiled"] = round(timed(hal, run, args.reps) * 1e3, 3)
+        print(json.dumps({**extra, "what": "rk_program_eval_check, random list, " + shape, "po2": po2, "points": d, "widths": widths,
                           "steps": info["n_steps"], "ops": info["n_ops"], "fp_slots": info["n_fp_slots"],
                           "mix_slots": info["n_mix_slots"], "ms": round(t * 1e3, 3),
                           "G_point_ops_per_s": round(info["n_ops"] * d / t / 1e9, 2)}), flush=True)
