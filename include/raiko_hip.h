@@ -401,6 +401,7 @@ typedef struct {
     uint64_t session_limit;        /* total cycles allowed, 0 = no limit (session_limit(None), bonsai.rs:248) */
     const uint32_t* input_words;   /* env.write_slice(&encoded_input), bonsai.rs:250 */
     size_t n_input_words;
+    uint32_t record_trace;         /* keep every executed cycle (28 bytes each) for rk_exec_witness */
 } rk_exec_opts;
 typedef struct {
     uint64_t total_cycles;
@@ -423,6 +424,20 @@ int rk_exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, 
 int rk_exec_summary_get(const rk_exec* ex, rk_exec_summary* out);
 int rk_exec_segment_get(const rk_exec* ex, uint32_t index, rk_exec_segment* out);
 int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* len);
+/* Witness generation for the STAND-IN trace circuit (not rv32im's: that layout is in a crate outside the
+ * reference tree).  Columns of executed segment `index`, column-major 2^po2 rows, Montgomery form, every 32-bit
+ * machine word as two 16-bit field elements; needs rk_exec_opts.record_trace:
+ *   code (RK_TRACE_CODE_COLS = 2):   0 first-row selector, 1 last-row selector
+ *   data (RK_TRACE_DATA_COLS = 16):  0/1 pc lo/hi, 2/3 next pc lo/hi, 4/5 instruction lo/hi, 6 seq (next = pc + 4),
+ *                                    7 carry of pc_lo + 4, 8/9 rs1 value, 10/11 rs2 value, 12/13 value written to rd,
+ *                                    14 rd written, 15 active (0 on the padding rows after the last cycle)
+ * The constraints a proof over them checks (raiko_amd/circuit_program.py trace_program): flags are bits, a seq row
+ * advances pc by 4 with the stated carry, every row starts where the previous one went, padding is final, the
+ * segment's first and last pc are the public ones.  Limb ranges, instruction decoding, registers and memory are
+ * NOT constrained: this is the witness path exercised end to end, not a zkVM. */
+#define RK_TRACE_CODE_COLS 2
+#define RK_TRACE_DATA_COLS 16
+int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t* data);
 const char* rk_exec_error(const rk_exec* ex);
 int rk_exec_free(rk_exec* ex);
 

@@ -212,22 +212,54 @@ def step(m, inputs, in_pos):
     return False, in_pos
 
 
-def run(elf, inputs=(), segment_limit_po2=20, max_cycles=10 ** 7):
-    """-> dict(segments=[(cycles, po2, start_pc, end_pc, exit)], journal, exit_code, total_cycles, machine)"""
+WRITES_RD = (0x37, 0x17, 0x6F, 0x67, 0x03, 0x13, 0x33)
+
+
+def run(elf, inputs=(), segment_limit_po2=20, max_cycles=10 ** 7, trace=False):
+    """-> dict(segments=[(cycles, po2, start_pc, end_pc, exit)], journal, exit_code, total_cycles, machine);
+    trace: also `traces` = per segment the executed cycles as (pc, ins, rs1 value, rs2 value, value written to rd,
+    next pc, rd written) -- what raiko_amd/csrc/executor.cpp records for rk_exec_witness"""
     m = Machine()
     load_elf(m, elf)
-    limit, total, in_pos, halted, segs = 1 << segment_limit_po2, 0, 0, False, []
+    limit, total, in_pos, halted, segs, traces = 1 << segment_limit_po2, 0, 0, False, [], []
     while not halted:
-        start, cycles = m.pc, 0
+        start, cycles, rows = m.pc, 0, []
         while cycles < limit and not halted:
             if total >= max_cycles:
                 raise Trap("cycle budget of the oracle exhausted")
+            if trace:
+                pc, ins = m.pc, m.lw(m.pc)
+                rd, a, b = (ins >> 7) & 31, m.x[(ins >> 15) & 31], m.x[(ins >> 20) & 31]
             halted, in_pos = step(m, inputs, in_pos)
+            if trace:
+                wr = 1 if ((ins & 0x7F) in WRITES_RD and rd != 0) else 0
+                rows.append((pc, ins, a, b, m.x[rd] if wr else 0, m.pc, wr))
             cycles += 1
             total += 1
+        traces.append(rows)
         po2 = MIN_PO2
         while (1 << po2) < cycles:
             po2 += 1
         segs.append((cycles, po2, start, m.pc, 0 if halted else 2))
     return dict(segments=segs, journal=bytes(m.journal), exit_code=m.exit_code, total_cycles=total, machine=m,
-                input_words_read=in_pos)
+                input_words_read=in_pos, traces=traces if trace else None)
+
+
+def witness(rows, po2, end_pc):
+    """The stand-in trace circuit's columns (include/raiko_hip.h rk_exec_witness) as canonical integers:
+    -> (code [2][2^po2], data [16][2^po2])"""
+    n = 1 << po2
+    code = [[0] * n for _ in range(2)]
+    data = [[0] * n for _ in range(16)]
+    code[0][0] = 1
+    code[1][n - 1] = 1
+    for i in range(n):
+        active = i < len(rows)
+        pc, ins, a, b, res, nxt, wr = rows[i] if active else (end_pc, 0, 0, 0, 0, end_pc, 0)
+        seq = 1 if active and nxt == (pc + 4) & M32 and pc + 4 <= M32 else 0
+        carry = 1 if seq and (pc & 0xFFFF) + 4 > 0xFFFF else 0
+        vals = [pc & 0xFFFF, pc >> 16, nxt & 0xFFFF, nxt >> 16, ins & 0xFFFF, ins >> 16, seq, carry, a & 0xFFFF, a >> 16,
+                b & 0xFFFF, b >> 16, res & 0xFFFF, res >> 16, wr, 1 if active else 0]
+        for c, v in enumerate(vals):
+            data[c][i] = v
+    return code, data

@@ -51,6 +51,8 @@ pub const RK_KCLASS_POLY: rk_kclass = 4;
 pub const RK_KCLASS_COUNT: rk_kclass = 5;
 
 pub const RK_MAX_QUERIES: u32 = 256;
+pub const RK_TRACE_CODE_COLS: u32 = 2;
+pub const RK_TRACE_DATA_COLS: u32 = 16;
 
 #[repr(C)]
 pub struct rk_ctx {
@@ -206,6 +208,7 @@ pub struct rk_exec_opts {
     pub session_limit: u64,
     pub input_words: *const u32,
     pub n_input_words: usize,
+    pub record_trace: u32,
 }
 
 #[repr(C)]
@@ -312,6 +315,7 @@ extern "C" {
     pub fn rk_exec_summary_get(ex: *const rk_exec, out: *mut rk_exec_summary) -> c_int;
     pub fn rk_exec_segment_get(ex: *const rk_exec, index: u32, out: *mut rk_exec_segment) -> c_int;
     pub fn rk_exec_journal(ex: *const rk_exec, out: *mut u8, capacity: usize, len: *mut usize) -> c_int;
+    pub fn rk_exec_witness(ex: *const rk_exec, index: u32, code: *mut u32, data: *mut u32) -> c_int;
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
     pub fn rk_last_timing(ctx: *mut rk_ctx, out: *mut rk_timing) -> c_int;

@@ -121,7 +121,7 @@ class RkTiming(C.Structure):
 
 class RkExecOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("segment_limit_po2", C.c_uint32), ("session_limit", C.c_uint64),
-                ("input_words", u32p), ("n_input_words", C.c_size_t)]
+                ("input_words", u32p), ("n_input_words", C.c_size_t), ("record_trace", C.c_uint32)]
 
 
 class RkExecSummary(C.Structure):
@@ -193,6 +193,7 @@ SYMBOLS = {
     "rk_exec_summary_get": (C.c_int, [C.c_void_p, C.POINTER(RkExecSummary)]),
     "rk_exec_segment_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RkExecSegment)]),
     "rk_exec_journal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rk_exec_witness": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     "rk_exec_error": (C.c_char_p, [C.c_void_p]),
     "rk_exec_free": (C.c_int, [C.c_void_p]),
     "rk_program_create": (C.c_int, [_vp, _sz, _u32, C.POINTER(RkTaps), C.POINTER(_vp)]),

@@ -263,3 +263,38 @@ def toy_program(taps: TapSet, n_mix: int, ext_w: int = P - 11) -> Tuple[np.ndarr
     junk = b.mul(b.get(D_, 1), b.get(D_, 2))
     b.and_eqz(b.true(), junk)
     return b.array(), x
+
+
+def trace_program(taps: TapSet) -> Tuple[np.ndarray, int]:
+    """The stand-in trace circuit over rk_exec_witness's columns (include/raiko_hip.h): flags are bits, a `seq` row
+    advances pc by 4 with the stated carry, every row starts where the previous one went, padding is final and
+    not sequential, the first / last pc are the public ones (globals 0..3 = start lo/hi, end lo/hi)."""
+    b = ProgramBuilder(taps)
+    C_, D_ = 1, 2
+    one, four, k16 = b.const(1), b.const(4), b.const(65536)
+    first, last = b.get(C_, 0), b.get(C_, 1)
+    pc_lo, pc_hi, nx_lo, nx_hi = (b.get(D_, c) for c in range(4))
+    seq, carry, wr, active = b.get(D_, 6), b.get(D_, 7), b.get(D_, 14), b.get(D_, 15)
+    pnx_lo, pnx_hi, pactive = b.get(D_, 2, 1), b.get(D_, 3, 1), b.get(D_, 15, 1)
+    bit = lambda v: b.mul(v, b.sub(v, one))
+    x = b.true()
+    for v in (seq, carry, wr, active):
+        x = b.and_eqz(x, bit(v))
+    # a sequential row: next = pc + 4 on 16-bit limbs
+    inner = b.and_eqz(b.true(), b.add(b.sub(b.sub(nx_lo, pc_lo), four), b.mul(carry, k16)))
+    inner = b.and_eqz(inner, b.sub(b.sub(nx_hi, pc_hi), carry))
+    x = b.and_cond(x, seq, inner)
+    # continuity: every row but the first starts where the previous one went
+    not_first = b.sub(one, first)
+    cont = b.and_eqz(b.and_eqz(b.true(), b.sub(pc_lo, pnx_lo)), b.sub(pc_hi, pnx_hi))
+    cont = b.and_eqz(cont, b.mul(b.sub(one, pactive), active))          # once padding, always padding
+    x = b.and_cond(x, not_first, cont)
+    # padding rows do nothing
+    x = b.and_eqz(x, b.mul(b.sub(one, active), seq))
+    x = b.and_eqz(x, b.mul(b.sub(one, active), wr))
+    # public boundary: start pc on the first row, end pc after the last
+    start = b.and_eqz(b.and_eqz(b.true(), b.sub(pc_lo, b.get_global(0, 0))), b.sub(pc_hi, b.get_global(0, 1)))
+    x = b.and_cond(x, first, start)
+    end = b.and_eqz(b.and_eqz(b.true(), b.sub(nx_lo, b.get_global(0, 2))), b.sub(nx_hi, b.get_global(0, 3)))
+    x = b.and_cond(x, last, end)
+    return b.array(), x

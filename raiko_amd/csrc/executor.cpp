@@ -72,8 +72,14 @@ void state_digest(const p2::Any& k, const Machine& m, uint32_t* out8) {
 
 }  // namespace
 
+// one executed cycle as the witness generator needs it
+struct TraceRow {
+    uint32_t pc, ins, a, b, res, next, wr;
+};
+
 struct rk_exec {
     std::vector<rk_exec_segment> segments;
+    std::vector<std::vector<TraceRow>> traces;   // per segment, when rk_exec_opts.record_trace is set
     std::vector<uint8_t> journal;
     rk_exec_summary summary{};
     std::string error;
@@ -107,7 +113,7 @@ int load_elf(Machine& m, const uint8_t* elf, size_t n, std::string& err) {
 inline int32_t sext(uint32_t v, unsigned bits) { return (int32_t)(v << (32 - bits)) >> (32 - bits); }
 
 // one instruction; returns 0 to go on, 1 halted, negative rk_status on a trap
-int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::string& err) {
+int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::string& err, TraceRow* row) {
     const uint32_t pc = m.pc, ins = m.load_word(pc);
     const uint32_t opc = ins & 0x7f, rd = (ins >> 7) & 31, f3 = (ins >> 12) & 7, rs1 = (ins >> 15) & 31, rs2 = (ins >> 20) & 31,
                    f7 = ins >> 25;
@@ -244,6 +250,7 @@ int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::st
             switch (m.x[5]) {
                 case RK_ECALL_HALT:
                     ex.summary.exit_code = m.x[10];
+                    if (row) *row = TraceRow{pc, ins, a, b, 0u, next, 0u};
                     m.pc = next;
                     return 1;
                 case RK_ECALL_READ: {  // a0 = destination (word aligned), a1 = capacity in words -> a0 = words read
@@ -270,6 +277,7 @@ int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::st
     }
     if (wr && rd != 0) m.x[rd] = res;
     if (next & 3) return trap("misaligned jump target");
+    if (row) *row = TraceRow{pc, ins, a, b, (wr && rd != 0) ? res : 0u, next, (wr && rd != 0) ? 1u : 0u};
     m.pc = next;
     return 0;
 }
@@ -299,14 +307,17 @@ int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exe
         seg.start_pc = m.pc;
         state_digest(*k, m, seg.pre_state);
         uint64_t cycles = 0;
+        std::vector<TraceRow> trace;
         while (cycles < limit) {
             if (o->session_limit && total >= o->session_limit) {
                 ex->error = "session limit reached";
                 st = RK_ERR_CAPACITY;
                 break;
             }
-            int r = step(m, *ex, *o, in_pos, ex->error);
+            TraceRow row{};
+            int r = step(m, *ex, *o, in_pos, ex->error, o->record_trace ? &row : nullptr);
             if (r < 0) { st = r; break; }
+            if (o->record_trace) trace.push_back(row);
             cycles++;
             total++;
             if (r == 1) { halted = true; break; }
@@ -320,6 +331,7 @@ int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exe
         seg.exit = halted ? RK_EXIT_HALTED : RK_EXIT_SYSTEM_SPLIT;
         state_digest(*k, m, seg.post_state);
         ex->segments.push_back(seg);
+        if (o->record_trace) ex->traces.push_back(std::move(trace));
         if (ex->segments.size() > (1u << 20)) { ex->error = "more than 2^20 segments"; st = RK_ERR_CAPACITY; }
     }
     ex->summary.total_cycles = total;
@@ -356,6 +368,45 @@ int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* le
     if (ex->journal.size() > capacity || (!out && !ex->journal.empty())) return RK_ERR_CAPACITY;
     if (!ex->journal.empty()) std::memcpy(out, ex->journal.data(), ex->journal.size());
     return RK_OK;
+}
+// Witness of one executed segment for the stand-in trace circuit (include/raiko_hip.h): every 32-bit word as two
+// 16-bit field elements; rows beyond the executed cycles repeat the final pc with active = seq = 0.
+int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t* data) {
+    RK_GUARD_BEGIN
+    if (!ex || !code || !data || index >= ex->segments.size() || index >= ex->traces.size()) return RK_ERR_INVALID;
+    const rk_exec_segment& seg = ex->segments[index];
+    const std::vector<TraceRow>& tr = ex->traces[index];
+    const size_t n = (size_t)1 << seg.po2;
+    if (tr.size() != seg.cycles || tr.size() > n) return RK_ERR_INTERNAL;
+    auto put = [&](uint32_t* base, unsigned col, size_t i, uint32_t canon) { base[(size_t)col * n + i] = bb::encode(canon); };
+    for (size_t i = 0; i < n; i++) {
+        put(code, 0, i, i == 0 ? 1u : 0u);         // first row
+        put(code, 1, i, i + 1 == n ? 1u : 0u);     // last row
+        const bool active = i < tr.size();
+        TraceRow r{};
+        if (active) r = tr[i];
+        else r.pc = r.next = seg.end_pc;           // padding: stay where the segment ended
+        const uint32_t lo = r.pc & 0xffffu, carry = (active && lo + 4 > 0xffffu) ? 1u : 0u;
+        const uint32_t seq = (active && r.next == r.pc + 4 && r.pc <= 0xfffffffbu) ? 1u : 0u;  // no wrap of the 32-bit pc
+        put(data, 0, i, lo);
+        put(data, 1, i, r.pc >> 16);
+        put(data, 2, i, r.next & 0xffffu);
+        put(data, 3, i, r.next >> 16);
+        put(data, 4, i, r.ins & 0xffffu);
+        put(data, 5, i, r.ins >> 16);
+        put(data, 6, i, seq);
+        put(data, 7, i, seq ? carry : 0u);
+        put(data, 8, i, r.a & 0xffffu);
+        put(data, 9, i, r.a >> 16);
+        put(data, 10, i, r.b & 0xffffu);
+        put(data, 11, i, r.b >> 16);
+        put(data, 12, i, r.res & 0xffffu);
+        put(data, 13, i, r.res >> 16);
+        put(data, 14, i, r.wr);
+        put(data, 15, i, active ? 1u : 0u);
+    }
+    return RK_OK;
+    RK_GUARD_END
 }
 const char* rk_exec_error(const rk_exec* ex) { return ex ? ex->error.c_str() : ""; }
 int rk_exec_free(rk_exec* ex) {

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .segment import Segment, synthetic_segment
+from .segment import P, Segment, synthetic_segment
 
 
 RkExecOpts, RkExecSummary, RkExecSegment = _lib.RkExecOpts, _lib.RkExecSummary, _lib.RkExecSegment
@@ -41,19 +41,26 @@ class Execution:
     exit_code: int
     total_cycles: int
     input_words_read: int
+    # with record_trace: per segment (code (2, 2^po2), data (16, 2^po2)) witness columns of the stand-in trace circuit
+    witness: Optional[list] = None
 
 
 class ExecutorError(RuntimeError):
     pass
 
 
-def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20, session_limit: int = 0) -> Execution:
+TRACE_CODE_COLS, TRACE_DATA_COLS, TRACE_ACCUM_COLS = 2, 16, 4
+
+
+def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20, session_limit: int = 0,
+            record_trace: bool = False) -> Execution:
     """`ExecutorImpl::from_elf(env, elf).run()` (bonsai.rs:246-269).  Raises ExecutorError on a trap
     (illegal instruction, misaligned access, unknown ecall, session limit)."""
     lib = _lib.load()
     words = np.ascontiguousarray(input_words, dtype=np.uint32)
     opts = RkExecOpts(struct_size=C.sizeof(RkExecOpts), segment_limit_po2=segment_limit_po2, session_limit=session_limit,
-                      input_words=words.ctypes.data_as(_lib.u32p), n_input_words=words.size)
+                      input_words=words.ctypes.data_as(_lib.u32p), n_input_words=words.size,
+                      record_trace=1 if record_trace else 0)
     handle = C.c_void_p()
     st = lib.rk_exec_elf(bytes(elf), len(elf), C.byref(opts), C.byref(handle))
     try:
@@ -71,7 +78,16 @@ def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int 
         buf = C.create_string_buffer(max(int(summ.journal_bytes), 1))
         n = C.c_size_t(0)
         lib.rk_exec_journal(handle, buf, summ.journal_bytes, C.byref(n))
-        return Execution(segs, buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read))
+        witness = None
+        if record_trace:   # rk_exec_witness: the native witness generator of the stand-in trace circuit
+            witness = []
+            for sg in segs:
+                rows = 1 << sg.po2
+                code = np.zeros((TRACE_CODE_COLS, rows), dtype=np.uint32)
+                data = np.zeros((TRACE_DATA_COLS, rows), dtype=np.uint32)
+                _lib.check(None, lib.rk_exec_witness(handle, sg.index, code.ctypes.data_as(_lib.u32p), data.ctypes.data_as(_lib.u32p)))
+                witness.append((code, data))
+        return Execution(segs, buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read), witness)
     finally:
         if handle:
             lib.rk_exec_free(handle)
@@ -90,16 +106,48 @@ def segments_for_proving(ex: Execution, widths: Tuple[int, int, int] = (16, 16, 
     return out
 
 
+def trace_segments(ex: Execution) -> List[Segment]:
+    """One prover segment per executed segment with its EXECUTION TRACE as witness (rk_exec_witness) and the
+    stand-in trace circuit's constraint list (circuit_program.trace_program) behind eval_check: the seal then says
+    that the pc chain of the committed trace is consistent and starts / ends at the public pcs.  Not rv32im."""
+    from .circuit_program import Program, trace_program
+    from .segment import make_tapset
+    if ex.witness is None:
+        raise ValueError("execute(..., record_trace=True) first")
+    taps = make_tapset([[(0,)] * TRACE_ACCUM_COLS, [(0,)] * TRACE_CODE_COLS,
+                        [((0, 1) if c in (2, 3, 15) else (0,)) for c in range(TRACE_DATA_COLS)]])
+    program = Program(*trace_program(taps), taps)
+    out = []
+    for s, (code, data) in zip(ex.segments, ex.witness):
+        mont = lambda v: (int(v) << 32) % P
+        pcs = [s.start_pc & 0xFFFF, s.start_pc >> 16, s.end_pc & 0xFFFF, s.end_pc >> 16]
+        globals_ = np.array([mont(v) for v in pcs] + list(s.pre_state) + list(s.post_state), dtype=np.uint32)
+        accum = np.ascontiguousarray(data[:TRACE_ACCUM_COLS])      # unconstrained in this circuit; no accumulate hook
+        seg = Segment(po2=s.po2, taps=taps, groups=[accum, code, data], check=None, globals_=globals_, n_accum_mix=4,
+                      circuit_info=b"RV32_TRACE:v1___")
+        seg.program = program
+        out.append(seg)
+    return out
+
+
 def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20,
-                      widths: Tuple[int, int, int] = (16, 16, 224), device: int = 0, inflight: int = 3):
+                      widths: Tuple[int, int, int] = (16, 16, 224), device: int = 0, inflight: int = 3,
+                      circuit: str = "synthetic"):
     """`prove_locally` end to end (bonsai.rs:230-272): execute, segment, prove every segment through
     rk_prove_session, assemble the receipt around the journal the guest committed.
-    Returns (Execution, Receipt)."""
+    circuit = "synthetic": stand-in columns of the executed size (the shape of the S20 workload);
+    circuit = "trace": the execution trace as witness under the stand-in trace circuit, every seal's
+    constraint identity verified inside the session.  Returns (Execution, Receipt)."""
     from .hal import prove_session
     from .receipt import Receipt, SegmentReceipt
-    ex = execute(elf, input_words, segment_limit_po2=segment_limit_po2)
-    segs = segments_for_proving(ex, widths)
-    seals = prove_session(segs, device=device, inflight=inflight)
+    if circuit == "trace":
+        ex = execute(elf, input_words, segment_limit_po2=segment_limit_po2, record_trace=True)
+        segs = trace_segments(ex)
+        seals = prove_session(segs, device=device, inflight=inflight, program=segs[0].program if segs else None)
+    else:
+        ex = execute(elf, input_words, segment_limit_po2=segment_limit_po2)
+        segs = segments_for_proving(ex, widths)
+        seals = prove_session(segs, device=device, inflight=inflight)
     n = len(seals)
     receipts = [SegmentReceipt(seal=s, index=i, po2=segs[i].po2,
                                exit_code=("Halted", ex.exit_code) if i + 1 == n else ("SystemSplit", None))

@@ -231,9 +231,10 @@ def make_or_segment(seg):
         c.hooks = oracle().or_toy_hooks()
     if getattr(seg, "program", None) is not None:  # eval_check from the step list (oracle/or_program.c)
         prog, hooks = or_program_of(seg.program, c.taps, keep)
-        toy = C.cast(C.c_void_p(oracle().or_toy_hooks()), C.POINTER(OrCircuitHooks)).contents
         hooks.user = C.addressof(prog)
-        hooks.accumulate = toy.accumulate
+        if getattr(seg, "hooks", None) is not None:   # the toy circuit's accumulate; otherwise accum is given as input
+            toy = C.cast(C.c_void_p(oracle().or_toy_hooks()), C.POINTER(OrCircuitHooks)).contents
+            hooks.accumulate = toy.accumulate
         hooks.eval_check = C.cast(oracle().or_program_eval_check, C.c_void_p).value
         c.hooks = C.addressof(hooks)
     gl = np.ascontiguousarray(seg.globals_, dtype=np.uint32)

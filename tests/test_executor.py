@@ -161,3 +161,54 @@ def test_segments_for_proving_follow_the_execution():
     other = X.execute(A.elf(A.assemble(A.li("a2", 3001) + prog[len(A.li("a2", 3000)):])[0]), segment_limit_po2=13)
     assert X.segments_for_proving(other, widths=(4, 4, 8))[0].globals_.tolist() != segs[0].globals_.tolist() or \
         X.segments_for_proving(other, widths=(4, 4, 8))[-1].globals_.tolist() != segs[-1].globals_.tolist()
+
+
+LOOP = A.li("a2", 3000) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("slli", "a5", "a4", 1),
+                           ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + commit_reg("a4") + HALT
+
+
+def test_witness_columns_match_the_python_restatement():
+    """rk_exec_witness (the native witness generator of the stand-in trace circuit) against oracle/or_rv32.py,
+    column by column, over a run of several segments with a short last one"""
+    image = A.elf(A.assemble(LOOP)[0])
+    got = X.execute(image, segment_limit_po2=13, record_trace=True)
+    want = or_rv32.run(image, segment_limit_po2=13, trace=True)
+    assert len(got.witness) == len(want["segments"]) >= 2
+    mont = lambda cols: (np.array(cols, dtype=np.uint64) * ((1 << 32) % 2013265921) % 2013265921).astype(np.uint32)
+    for (code, data), rows, seg in zip(got.witness, want["traces"], want["segments"]):
+        w_code, w_data = or_rv32.witness(rows, seg[1], seg[3])
+        assert np.array_equal(code, mont(w_code)) and np.array_equal(data, mont(w_data))
+    short = got.witness[-1][1]
+    assert short[15].tolist().count(0) == (1 << got.segments[-1].po2) - got.segments[-1].cycles   # padding rows
+
+
+def test_trace_circuit_proof_on_the_cpu_oracle():
+    """execute -> witness -> the trace circuit's constraint list -> oracle proof -> both verifiers check the
+    constraint identity; a forged cell of the trace (a jump the pc chain does not make) is caught by it"""
+    import oracle_lib as o
+    from raiko_amd import hal
+    prog = A.li("a2", 40) + ["loop:", ("addi", "a3", "a3", 3), ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + HALT
+    ex = X.execute(A.elf(A.assemble(prog)[0]), segment_limit_po2=13, record_trace=True)
+    segs = X.trace_segments(ex)
+    assert len(segs) == 1 and segs[0].taps.group_size == (4, 2, 16)
+    # the 2^13-row oracle proof is the slow part: shrink the segment to 2^8 rows (the run has ~130 cycles)
+    seg = segs[0]
+    cut = 8
+    for g in range(3):
+        seg.groups[g] = np.ascontiguousarray(seg.groups[g][:, : 1 << cut])
+    seg.groups[1][1, :] = 0
+    seg.groups[1][1, (1 << cut) - 1] = seg.groups[1][0, 0]                       # `last` selector moves with the cut
+    seg.po2 = cut
+    seal = o.oracle_prove(seg)
+    assert o.oracle_verify(seg, seal, toy_identity=True) == 0
+    assert hal.verify_segment(seg, seal, program=seg.program) == 0
+    forged = X.trace_segments(ex)[0]
+    for g in range(3):
+        forged.groups[g] = np.ascontiguousarray(forged.groups[g][:, : 1 << cut])
+    forged.groups[1][1, :] = 0
+    forged.groups[1][1, (1 << cut) - 1] = forged.groups[1][0, 0]
+    forged.po2 = cut
+    forged.groups[2][2, 50] = forged.groups[2][2, 51]                              # row 50 claims another next-pc
+    bad = o.oracle_prove(forged)
+    assert hal.verify_segment(forged, bad) == 0                                    # commitments are consistent
+    assert hal.verify_segment(forged, bad, program=forged.program) == 70           # the pc chain is not

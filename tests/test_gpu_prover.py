@@ -334,3 +334,34 @@ def test_overlapping_run_calls_are_safe():
     for t in range(len(jobs)):
         for a, b in zip(got[t], want[t]):
             assert np.array_equal(a, b)
+
+
+def test_execute_witness_prove_under_the_trace_circuit():
+    """ELF -> executor -> native witness generator (rk_exec_witness) -> the trace circuit's constraint list
+    evaluated on the GPU inside every segment proof -> seals equal the oracle's and their constraint identity
+    is verified inside the session (the stand-in circuit of include/raiko_hip.h: the pc chain, not rv32im)"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import rv32_asm as A
+    from raiko_amd import executor as X
+    from raiko_amd.hal import prove_session, verify_segment
+    prog = A.li("a2", 4000) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("slli", "a5", "a4", 1),
+                               ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    ex = X.execute(image, segment_limit_po2=13, record_trace=True)
+    segs = X.trace_segments(ex)
+    assert len(segs) == 3
+    seals = prove_session(segs, inflight=3, verify=True, program=segs[0].program)
+    for seg, seal in zip(segs, seals):
+        assert np.array_equal(seal, o.oracle_prove(seg))
+        assert verify_segment(seg, seal, program=seg.program) == 0
+    # the whole route in one call, and a forged trace cell refused by the session's verifier
+    ex2, receipt = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace")
+    assert len(receipt.segments) == 3 and ex2.total_cycles == ex.total_cycles
+    assert all(np.array_equal(a.seal, b) for a, b in zip(receipt.segments, seals))
+    segs[1].groups[2][2, 100] = segs[1].groups[2][2, 101]
+    from raiko_amd import _lib
+    with pytest.raises(_lib.RkError) as ei:
+        prove_session(segs, inflight=3, verify=True, program=segs[0].program)
+    assert ei.value.status == _lib.RK_ERR_VERIFY and ei.value.segment == 1
