@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <memory>
 #include <new>
 #include <string>
@@ -31,15 +32,41 @@ struct Machine {
     uint32_t pc = 0;
     uint32_t x[32] = {0};
     std::map<uint32_t, std::vector<uint32_t>> pages;  // page index -> 1024 words (ordered: digests walk it)
+    // the last page touched by an instruction fetch and by a data access: the map is searched only when an
+    // access leaves them (map nodes and the vectors inside them never move once created)
+    uint32_t fetch_idx = 0xffffffffu, data_idx = 0xffffffffu;
+    uint32_t* fetch_page = nullptr;
+    uint32_t* data_page = nullptr;
 
-    uint32_t* word_ptr(uint32_t addr) {
-        auto& pg = pages[addr >> 12];
-        if (pg.empty()) pg.assign(PAGE_WORDS, 0);
-        return &pg[(addr >> 2) & (PAGE_WORDS - 1)];
+    uint32_t* page_for_write(uint32_t idx) {
+        if (idx == data_idx && data_page) return data_page;
+        auto& pg = pages[idx];
+        if (pg.empty()) {
+            pg.assign(PAGE_WORDS, 0);
+            if (idx == fetch_idx) fetch_page = pg.data();  // a page first seen absent by the fetch path now exists
+        }
+        data_idx = idx;
+        data_page = pg.data();
+        return data_page;
     }
+    uint32_t* word_ptr(uint32_t addr) { return page_for_write(addr >> 12) + ((addr >> 2) & (PAGE_WORDS - 1)); }
     uint32_t load_word(uint32_t addr) {
-        auto it = pages.find(addr >> 12);
-        return it == pages.end() ? 0u : it->second[(addr >> 2) & (PAGE_WORDS - 1)];
+        const uint32_t idx = addr >> 12;
+        if (idx == data_idx && data_page) return data_page[(addr >> 2) & (PAGE_WORDS - 1)];
+        auto it = pages.find(idx);
+        if (it == pages.end()) return 0u;
+        data_idx = idx;
+        data_page = it->second.data();
+        return data_page[(addr >> 2) & (PAGE_WORDS - 1)];
+    }
+    uint32_t fetch(uint32_t addr) {
+        const uint32_t idx = addr >> 12;
+        if (idx != fetch_idx) {
+            auto it = pages.find(idx);
+            fetch_idx = idx;
+            fetch_page = it == pages.end() ? nullptr : it->second.data();
+        }
+        return fetch_page ? fetch_page[(addr >> 2) & (PAGE_WORDS - 1)] : 0u;
     }
     uint8_t load_byte(uint32_t addr) { return (uint8_t)(load_word(addr & ~3u) >> (8 * (addr & 3))); }
     void store_byte(uint32_t addr, uint8_t v) {
@@ -114,7 +141,7 @@ inline int32_t sext(uint32_t v, unsigned bits) { return (int32_t)(v << (32 - bit
 
 // one instruction; returns 0 to go on, 1 halted, negative rk_status on a trap
 int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::string& err, TraceRow* row) {
-    const uint32_t pc = m.pc, ins = m.load_word(pc);
+    const uint32_t pc = m.pc, ins = m.fetch(pc);
     const uint32_t opc = ins & 0x7f, rd = (ins >> 7) & 31, f3 = (ins >> 12) & 7, rs1 = (ins >> 15) & 31, rs2 = (ins >> 20) & 31,
                    f7 = ins >> 25;
     const uint32_t a = m.x[rs1], b = m.x[rs2];
@@ -378,33 +405,41 @@ int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t*
     const std::vector<TraceRow>& tr = ex->traces[index];
     const size_t n = (size_t)1 << seg.po2;
     if (tr.size() != seg.cycles || tr.size() > n) return RK_ERR_INTERNAL;
-    auto put = [&](uint32_t* base, unsigned col, size_t i, uint32_t canon) { base[(size_t)col * n + i] = bb::encode(canon); };
-    for (size_t i = 0; i < n; i++) {
-        put(code, 0, i, i == 0 ? 1u : 0u);         // first row
-        put(code, 1, i, i + 1 == n ? 1u : 0u);     // last row
-        const bool active = i < tr.size();
-        TraceRow r{};
-        if (active) r = tr[i];
-        else r.pc = r.next = seg.end_pc;           // padding: stay where the segment ended
-        const uint32_t lo = r.pc & 0xffffu, carry = (active && lo + 4 > 0xffffu) ? 1u : 0u;
-        const uint32_t seq = (active && r.next == r.pc + 4 && r.pc <= 0xfffffffbu) ? 1u : 0u;  // no wrap of the 32-bit pc
-        put(data, 0, i, lo);
-        put(data, 1, i, r.pc >> 16);
-        put(data, 2, i, r.next & 0xffffu);
-        put(data, 3, i, r.next >> 16);
-        put(data, 4, i, r.ins & 0xffffu);
-        put(data, 5, i, r.ins >> 16);
-        put(data, 6, i, seq);
-        put(data, 7, i, seq ? carry : 0u);
-        put(data, 8, i, r.a & 0xffffu);
-        put(data, 9, i, r.a >> 16);
-        put(data, 10, i, r.b & 0xffffu);
-        put(data, 11, i, r.b >> 16);
-        put(data, 12, i, r.res & 0xffffu);
-        put(data, 13, i, r.res >> 16);
-        put(data, 14, i, r.wr);
-        put(data, 15, i, active ? 1u : 0u);
-    }
+    // every cell is below 2^16 (or a bit): one Montgomery product each; rows are independent, four threads split them
+    auto put = [&](uint32_t* base, unsigned col, size_t i, uint32_t canon) { base[(size_t)col * n + i] = bb::mul(canon, bb::R2); };
+    auto fill = [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            put(code, 0, i, i == 0 ? 1u : 0u);         // first row
+            put(code, 1, i, i + 1 == n ? 1u : 0u);     // last row
+            const bool active = i < tr.size();
+            TraceRow r{};
+            if (active) r = tr[i];
+            else r.pc = r.next = seg.end_pc;           // padding: stay where the segment ended
+            const uint32_t lo = r.pc & 0xffffu, carry = (active && lo + 4 > 0xffffu) ? 1u : 0u;
+            const uint32_t seq = (active && r.next == r.pc + 4 && r.pc <= 0xfffffffbu) ? 1u : 0u;  // no wrap of the 32-bit pc
+            put(data, 0, i, lo);
+            put(data, 1, i, r.pc >> 16);
+            put(data, 2, i, r.next & 0xffffu);
+            put(data, 3, i, r.next >> 16);
+            put(data, 4, i, r.ins & 0xffffu);
+            put(data, 5, i, r.ins >> 16);
+            put(data, 6, i, seq);
+            put(data, 7, i, seq ? carry : 0u);
+            put(data, 8, i, r.a & 0xffffu);
+            put(data, 9, i, r.a >> 16);
+            put(data, 10, i, r.b & 0xffffu);
+            put(data, 11, i, r.b >> 16);
+            put(data, 12, i, r.res & 0xffffu);
+            put(data, 13, i, r.res >> 16);
+            put(data, 14, i, r.wr);
+            put(data, 15, i, active ? 1u : 0u);
+        }
+    };
+    const size_t n_threads = n >= (1u << 16) ? 4 : 1;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; t++) pool.emplace_back(fill, n * t / n_threads, n * (t + 1) / n_threads);
+    fill(0, n / n_threads);
+    for (auto& th : pool) th.join();
     return RK_OK;
     RK_GUARD_END
 }

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""ELF -> receipt on one MI355X through the stand-in trace circuit: a hand-assembled loop of ~4 M cycles executed and
+cut into 2^20-cycle segments (rk_exec_elf with record_trace), witness columns (rk_exec_witness), every segment
+proven with the constraint list behind eval_check and verified inside rk_prove_session.  One JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rv32_asm as A  # noqa: E402
+from raiko_amd import executor as X  # noqa: E402
+from raiko_amd.hal import HipHal, prove_session  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 800000
+    prog = A.li("a2", iters) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("slli", "a5", "a4", 1),
+                                ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    t0 = time.perf_counter()
+    ex = X.execute(image, segment_limit_po2=20, record_trace=True)
+    t1 = time.perf_counter()
+    segs = X.trace_segments(ex)
+    t2 = time.perf_counter()
+    hal = HipHal(0)
+    segs[0].program.compile(hal)                      # hiprtc: the generated eval_check kernel
+    t3 = time.perf_counter()
+    prove_session(segs[:1], inflight=1, verify=False, program=segs[0].program)   # warm-up: contexts, tables
+    t4 = time.perf_counter()
+    seals = prove_session(segs, inflight=3, verify=True, program=segs[0].program)
+    t5 = time.perf_counter()
+    print(json.dumps({"what": "ELF -> receipt through the stand-in trace circuit (4 + 2 + 16 columns)", "cycles": ex.total_cycles,
+                      "segments": len(segs), "execute_and_witness_s": round(t1 - t0, 3), "segments_and_program_s": round(t2 - t1, 3),
+                      "hiprtc_compile_s": round(t3 - t2, 3), "prove_and_verify_s": round(t5 - t4, 3),
+                      "proven_cycles_per_s_prove_only": round(ex.total_cycles / (t5 - t4), 1),
+                      "cycles_per_s_execute_to_receipt": round(ex.total_cycles / ((t1 - t0) + (t5 - t4)), 1),
+                      "seal_words": [int(s.size) for s in seals]}))
+
+
+if __name__ == "__main__":
+    main()
