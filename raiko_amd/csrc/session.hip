@@ -347,29 +347,26 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
     // the session's parameter set: every word that defines it, so that an equal set costs nothing next time
     rk_params prm;
     rk::params_preset(&prm, RK_PRESET_RISC0);
-    std::vector<uint32_t> key;
-    if (opts->params) {
+    // every word that defines a parameter set; empty for risc0's defaults
+    auto key_of = [](const rk_params& p, std::vector<uint32_t>* out) -> int {
         rk::Sys sys;
         auto any = std::make_unique<p2::Any>();
-        int st = rk::resolve_params(opts->params, &sys, any.get());
+        int st = rk::resolve_params(&p, &sys, any.get());
         if (st != RK_OK) return st;
+        *out = {p.ext_w, p.root_2_27, p.coset_shift, p.p2_width, p.p2_m4, p.p2_pad_free, p.queries, p.blowup_log2, p.fri_fold_log2,
+                p.fri_min_degree, p.pow_bits};
+        out->insert(out->end(), any->rc_ext(), any->rc_ext() + 8 * any->cells());
+        out->insert(out->end(), any->rc_int(), any->rc_int() + any->rounds_partial());
+        out->insert(out->end(), any->diag(), any->diag() + any->cells());
+        return RK_OK;
+    };
+    std::vector<uint32_t> key;
+    if (opts->params) {
+        std::vector<uint32_t> dkey;
+        int st = key_of(*opts->params, &key);
+        if (st != RK_OK) return st;
+        (void)key_of(prm, &dkey);
         prm = *opts->params;
-        const uint32_t head[] = {prm.ext_w, prm.root_2_27, prm.coset_shift, prm.p2_width, prm.p2_m4, prm.p2_pad_free, prm.queries,
-                                 prm.blowup_log2, prm.fri_fold_log2, prm.fri_min_degree, prm.pow_bits};
-        key.assign(head, head + sizeof head / 4);
-        key.insert(key.end(), any->rc_ext(), any->rc_ext() + 8 * any->cells());
-        key.insert(key.end(), any->rc_int(), any->rc_int() + any->rounds_partial());
-        key.insert(key.end(), any->diag(), any->diag() + any->cells());
-        rk_params dflt;
-        rk::params_preset(&dflt, RK_PRESET_RISC0);
-        rk::Sys dsys;
-        auto dany = std::make_unique<p2::Any>();
-        (void)rk::resolve_params(&dflt, &dsys, dany.get());
-        std::vector<uint32_t> dkey = {dflt.ext_w, dflt.root_2_27, dflt.coset_shift, dflt.p2_width, dflt.p2_m4, dflt.p2_pad_free,
-                                      dflt.queries, dflt.blowup_log2, dflt.fri_fold_log2, dflt.fri_min_degree, dflt.pow_bits};
-        dkey.insert(dkey.end(), dany->rc_ext(), dany->rc_ext() + 8 * dany->cells());
-        dkey.insert(dkey.end(), dany->rc_int(), dany->rc_int() + dany->rounds_partial());
-        dkey.insert(dkey.end(), dany->diag(), dany->diag() + dany->cells());
         if (key == dkey) key.clear();
     }
     rk_verify_opts vopts{};
