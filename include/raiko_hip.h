@@ -380,6 +380,17 @@ typedef struct {
 } rk_session_opts;
 int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n, uint32_t* const* h_seals,
                      const size_t* seal_capacity_words, size_t* seal_words, size_t* failed_index);
+/* The same for a session whose segments arrive while it runs (risc0's executor can yield segments one by one:
+ * `run_with_callback`): segment k is proven while the executor is still producing segment k + 1.  A worker thread
+ * proves whatever has been submitted since its last look as one rk_prove_session batch.  The rk_segment is copied at
+ * submit; what it points at, the seal buffer and *seal_words must stay valid until rk_stream_close returns -- which
+ * waits for everything submitted, frees the stream, and returns RK_OK or the first failure with the index (in
+ * submission order) in *failed_index.  opts as for rk_prove_session (devices / params / verify_opts are copied;
+ * tables a params blob points at stay the caller's). */
+typedef struct rk_stream rk_stream;
+int rk_stream_open(const rk_session_opts* opts, rk_stream** out);
+int rk_stream_submit(rk_stream* stream, const rk_segment* seg, uint32_t* h_seal, size_t seal_capacity_words, size_t* seal_words);
+int rk_stream_close(rk_stream* stream, size_t* failed_index);
 const char* rk_session_last_error(int device);
 int rk_session_release(void);
 
@@ -421,6 +432,11 @@ typedef struct {
 } rk_exec_segment;
 /* *out is set also when the run traps (status < 0): read rk_exec_error, then rk_exec_free */
 int rk_exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out);
+/* the same one segment at a time (risc0's `run_with_callback` shape): a host can hand segment k to the prover
+ * while segment k + 1 executes.  rk_exec_open loads the ELF (input words are copied), every
+ * rk_exec_next_segment runs up to the next boundary; *more = 0 once the guest has halted. */
+int rk_exec_open(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out);
+int rk_exec_next_segment(rk_exec* ex, int* more);
 int rk_exec_summary_get(const rk_exec* ex, rk_exec_summary* out);
 int rk_exec_segment_get(const rk_exec* ex, uint32_t index, rk_exec_segment* out);
 int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* len);

@@ -69,6 +69,11 @@ pub struct rk_program {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+pub struct rk_stream {
+    _private: [u8; 0],
+}
+
 pub type rk_poly_ext_fn = unsafe extern "C" fn(user: *mut c_void, pub_: *const rk_segment, poly_mix: *const u32, eval_u_ext: *const u32, n_taps: usize, mix: *const u32, n_mix: u32, out_ext: *mut u32) -> c_int;
 
 #[repr(C)]
@@ -309,9 +314,14 @@ extern "C" {
     pub fn rk_seal_bound_words_for(seg: *const rk_segment, queries: u32) -> usize;
     pub fn rk_seal_bound_words_params(seg: *const rk_segment, params: *const rk_params) -> usize;
     pub fn rk_prove_session(opts: *const rk_session_opts, segs: *const rk_segment, n: usize, h_seals: *const *mut u32, seal_capacity_words: *const usize, seal_words: *mut usize, failed_index: *mut usize) -> c_int;
+    pub fn rk_stream_open(opts: *const rk_session_opts, out: *mut *mut rk_stream) -> c_int;
+    pub fn rk_stream_submit(stream: *mut rk_stream, seg: *const rk_segment, h_seal: *mut u32, seal_capacity_words: usize, seal_words: *mut usize) -> c_int;
+    pub fn rk_stream_close(stream: *mut rk_stream, failed_index: *mut usize) -> c_int;
     pub fn rk_session_last_error(device: c_int) -> *const c_char;
     pub fn rk_session_release() -> c_int;
     pub fn rk_exec_elf(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
+    pub fn rk_exec_open(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
+    pub fn rk_exec_next_segment(ex: *mut rk_exec, more: *mut c_int) -> c_int;
     pub fn rk_exec_summary_get(ex: *const rk_exec, out: *mut rk_exec_summary) -> c_int;
     pub fn rk_exec_segment_get(ex: *const rk_exec, index: u32, out: *mut rk_exec_segment) -> c_int;
     pub fn rk_exec_journal(ex: *const rk_exec, out: *mut u8, capacity: usize, len: *mut usize) -> c_int;

@@ -140,6 +140,9 @@ SYMBOLS = {
     "rk_prove_session": (C.c_int, [C.POINTER(RkSessionOpts), C.POINTER(RkSegment), _sz, C.POINTER(u32p), C.POINTER(_sz),
                                    C.POINTER(_sz), C.POINTER(_sz)]),
     "rk_session_last_error": (C.c_char_p, [C.c_int]),
+    "rk_stream_open": (C.c_int, [C.POINTER(RkSessionOpts), C.POINTER(C.c_void_p)]),
+    "rk_stream_submit": (C.c_int, [C.c_void_p, C.POINTER(RkSegment), u32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rk_stream_close": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rk_session_release": (C.c_int, []),
     "rk_abi_version": (C.c_int, []),
     "rk_strerror": (C.c_char_p, [C.c_int]),
@@ -190,6 +193,8 @@ SYMBOLS = {
     "rk_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(RkKernelStat)]),
     "rk_kernel_class_name": (C.c_char_p, [C.c_int]),
     "rk_exec_elf": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(RkExecOpts), C.POINTER(C.c_void_p)]),
+    "rk_exec_open": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(RkExecOpts), C.POINTER(C.c_void_p)]),
+    "rk_exec_next_segment": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rk_exec_summary_get": (C.c_int, [C.c_void_p, C.POINTER(RkExecSummary)]),
     "rk_exec_segment_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RkExecSegment)]),
     "rk_exec_journal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -107,6 +107,15 @@ struct TraceRow {
 struct rk_exec {
     std::vector<rk_exec_segment> segments;
     std::vector<std::vector<TraceRow>> traces;   // per segment, when rk_exec_opts.record_trace is set
+    // the machine between segments (rk_exec_open / rk_exec_next_segment run it one segment at a time)
+    Machine m;
+    std::unique_ptr<p2::Any> k;                  // the default Poseidon2 instance: state digests at the boundaries
+    rk_exec_opts o{};
+    std::vector<uint32_t> input;                 // copy of the caller's input words
+    size_t in_pos = 0;
+    uint64_t total = 0;
+    bool halted = false;
+    int st = RK_OK;
     std::vector<uint8_t> journal;
     rk_exec_summary summary{};
     std::string error;
@@ -309,64 +318,85 @@ int step(Machine& m, rk_exec& ex, const rk_exec_opts& o, size_t& in_pos, std::st
     return 0;
 }
 
-int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exec** out) {
+void refresh_summary(rk_exec* ex) {
+    ex->summary.total_cycles = ex->total;
+    ex->summary.n_segments = (uint32_t)ex->segments.size();
+    ex->summary.journal_bytes = ex->journal.size();
+    ex->summary.input_words_read = ex->in_pos;
+    ex->summary.status = ex->st;
+}
+
+int exec_open(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exec** out) {
     if (!out) return RK_ERR_INVALID;
     *out = nullptr;
     if (!elf || !o || o->struct_size != sizeof(rk_exec_opts)) return RK_ERR_INVALID;
     if (o->segment_limit_po2 < MIN_PO2 || o->segment_limit_po2 > 24) return RK_ERR_INVALID;
     if (o->n_input_words && !o->input_words) return RK_ERR_INVALID;
     auto ex = std::make_unique<rk_exec>();
-    Machine m;
-    int st = load_elf(m, elf, elf_bytes, ex->error);
-    // the default Poseidon2 instance commits to the machine state at every segment boundary
+    ex->o = *o;
+    if (o->n_input_words) ex->input.assign(o->input_words, o->input_words + o->n_input_words);
+    ex->o.input_words = ex->input.data();
+    ex->st = load_elf(ex->m, elf, elf_bytes, ex->error);
     rk::Sys sys;
-    auto k = std::make_unique<p2::Any>();
+    ex->k = std::make_unique<p2::Any>();
     rk_params def;
     rk::params_preset(&def, RK_PRESET_RISC0);
-    if (st == RK_OK) st = rk::resolve_params(&def, &sys, k.get());
-    const uint64_t limit = (uint64_t)1 << o->segment_limit_po2;
-    uint64_t total = 0;
-    size_t in_pos = 0;
-    bool halted = false;
-    while (st == RK_OK && !halted) {
-        rk_exec_segment seg{};
-        seg.index = (uint32_t)ex->segments.size();
-        seg.start_pc = m.pc;
-        state_digest(*k, m, seg.pre_state);
-        uint64_t cycles = 0;
-        std::vector<TraceRow> trace;
-        while (cycles < limit) {
-            if (o->session_limit && total >= o->session_limit) {
-                ex->error = "session limit reached";
-                st = RK_ERR_CAPACITY;
-                break;
-            }
-            TraceRow row{};
-            int r = step(m, *ex, *o, in_pos, ex->error, o->record_trace ? &row : nullptr);
-            if (r < 0) { st = r; break; }
-            if (o->record_trace) trace.push_back(row);
-            cycles++;
-            total++;
-            if (r == 1) { halted = true; break; }
+    if (ex->st == RK_OK) ex->st = rk::resolve_params(&def, &sys, ex->k.get());
+    refresh_summary(ex.get());
+    const int st = ex->st;
+    *out = ex.release();  // also on failure: the caller reads the error text, then frees
+    return st;
+}
+
+// one more segment; *more = 0 once the guest has halted (or the run has failed)
+int exec_next(rk_exec* ex, int* more) {
+    if (more) *more = 0;
+    if (ex->st != RK_OK || ex->halted) return ex->st;
+    Machine& m = ex->m;
+    const rk_exec_opts& o = ex->o;
+    const uint64_t limit = (uint64_t)1 << o.segment_limit_po2;
+    rk_exec_segment seg{};
+    seg.index = (uint32_t)ex->segments.size();
+    seg.start_pc = m.pc;
+    state_digest(*ex->k, m, seg.pre_state);
+    uint64_t cycles = 0;
+    std::vector<TraceRow> trace;
+    while (cycles < limit) {
+        if (o.session_limit && ex->total >= o.session_limit) {
+            ex->error = "session limit reached";
+            ex->st = RK_ERR_CAPACITY;
+            break;
         }
-        if (st != RK_OK) break;
+        TraceRow row{};
+        int r = step(m, *ex, o, ex->in_pos, ex->error, o.record_trace ? &row : nullptr);
+        if (r < 0) { ex->st = r; break; }
+        if (o.record_trace) trace.push_back(row);
+        cycles++;
+        ex->total++;
+        if (r == 1) { ex->halted = true; break; }
+    }
+    if (ex->st == RK_OK) {
         seg.cycles = cycles;
         uint32_t po2 = MIN_PO2;
         while (((uint64_t)1 << po2) < cycles) po2++;
         seg.po2 = po2;
         seg.end_pc = m.pc;
-        seg.exit = halted ? RK_EXIT_HALTED : RK_EXIT_SYSTEM_SPLIT;
-        state_digest(*k, m, seg.post_state);
+        seg.exit = ex->halted ? RK_EXIT_HALTED : RK_EXIT_SYSTEM_SPLIT;
+        state_digest(*ex->k, m, seg.post_state);
         ex->segments.push_back(seg);
-        if (o->record_trace) ex->traces.push_back(std::move(trace));
-        if (ex->segments.size() > (1u << 20)) { ex->error = "more than 2^20 segments"; st = RK_ERR_CAPACITY; }
+        if (o.record_trace) ex->traces.push_back(std::move(trace));
+        if (ex->segments.size() > (1u << 20)) { ex->error = "more than 2^20 segments"; ex->st = RK_ERR_CAPACITY; }
     }
-    ex->summary.total_cycles = total;
-    ex->summary.n_segments = (uint32_t)ex->segments.size();
-    ex->summary.journal_bytes = ex->journal.size();
-    ex->summary.input_words_read = in_pos;
-    ex->summary.status = st;
-    *out = ex.release();  // also on failure: the caller reads the error text, then frees
+    refresh_summary(ex);
+    if (more) *more = (ex->st == RK_OK && !ex->halted) ? 1 : 0;
+    return ex->st;
+}
+
+int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exec** out) {
+    int st = exec_open(elf, elf_bytes, o, out);
+    if (st != RK_OK) return st;
+    int more = 1;
+    while (more) st = exec_next(*out, &more);
     return st;
 }
 
@@ -377,6 +407,17 @@ extern "C" {
 int rk_exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out) {
     RK_GUARD_BEGIN
     return exec_elf(elf, elf_bytes, opts, out);
+    RK_GUARD_END
+}
+int rk_exec_open(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out) {
+    RK_GUARD_BEGIN
+    return exec_open(elf, elf_bytes, opts, out);
+    RK_GUARD_END
+}
+int rk_exec_next_segment(rk_exec* ex, int* more) {
+    RK_GUARD_BEGIN
+    if (!ex) return RK_ERR_INVALID;
+    return exec_next(ex, more);
     RK_GUARD_END
 }
 int rk_exec_summary_get(const rk_exec* ex, rk_exec_summary* out) {

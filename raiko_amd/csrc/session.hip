@@ -438,6 +438,130 @@ int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t
     RK_GUARD_END
 }
 
+}  // extern "C"
+
+// ---- sessions that grow while they run -------------------------------------------------------------
+// A worker thread takes whatever has been submitted since its last look and proves it as one
+// rk_prove_session batch (the device's contexts persist, so a batch costs nothing to start): the host can
+// hand over segment k while its executor is still producing segment k + 1.
+struct rk_stream {
+    rk_session_opts opts{};
+    std::vector<int> devices;
+    rk_params params{};
+    rk_verify_opts vopts{};
+    struct Item {
+        rk_segment seg;
+        uint32_t* seal;
+        size_t cap;
+        size_t* words;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Item> items;
+    size_t next = 0;
+    bool closed = false;
+    int status = RK_OK;
+    size_t failed = (size_t)-1;
+    std::thread worker;
+
+    void run() {
+        for (;;) {
+            size_t b0, b1;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return closed || next < items.size(); });
+                if (next >= items.size()) return;  // closed and drained
+                b0 = next;
+                b1 = items.size();
+                next = b1;
+                if (status != RK_OK) continue;     // after a failure the rest is only drained
+            }
+            const size_t n = b1 - b0;
+            std::vector<rk_segment> segs(n);
+            std::vector<uint32_t*> seals(n);
+            std::vector<size_t> caps(n), words(n, 0);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                for (size_t i = 0; i < n; i++) {
+                    segs[i] = items[b0 + i].seg;
+                    seals[i] = items[b0 + i].seal;
+                    caps[i] = items[b0 + i].cap;
+                }
+            }
+            size_t bad = (size_t)-1;
+            int st = RK_ERR_INTERNAL;
+            try {
+                st = prove_session(&opts, segs.data(), n, seals.data(), caps.data(), words.data(), &bad);
+            } catch (...) {
+            }
+            std::lock_guard<std::mutex> l(mu);
+            for (size_t i = 0; i < n; i++)
+                if (items[b0 + i].words) *items[b0 + i].words = words[i];
+            if (st != RK_OK && status == RK_OK) {
+                status = st;
+                failed = bad == (size_t)-1 ? bad : b0 + bad;
+            }
+        }
+    }
+};
+
+extern "C" {
+
+int rk_stream_open(const rk_session_opts* opts, rk_stream** out) {
+    RK_GUARD_BEGIN
+    if (!opts || !out) return RK_ERR_INVALID;
+    *out = nullptr;
+    if (opts->inflight < 1 || opts->inflight > 16 || opts->upload_ahead < 0 || opts->upload_ahead > 16) return RK_ERR_INVALID;
+    if (opts->n_devices < 0 || opts->n_devices > 64 || (opts->n_devices > 0 && !opts->devices)) return RK_ERR_INVALID;
+    std::unique_ptr<rk_stream> s(new rk_stream);
+    s->opts = *opts;
+    if (opts->n_devices > 0) {
+        s->devices.assign(opts->devices, opts->devices + opts->n_devices);
+        s->opts.devices = s->devices.data();
+    }
+    if (opts->params) {  // the blob is copied; tables it points at stay the caller's
+        s->params = *opts->params;
+        s->opts.params = &s->params;
+    }
+    if (opts->verify_opts) {
+        s->vopts = *opts->verify_opts;
+        s->opts.verify_opts = &s->vopts;
+    }
+    rk_stream* raw = s.get();
+    s->worker = std::thread([raw] { raw->run(); });
+    *out = s.release();
+    return RK_OK;
+    RK_GUARD_END
+}
+
+int rk_stream_submit(rk_stream* s, const rk_segment* seg, uint32_t* h_seal, size_t seal_capacity_words, size_t* seal_words) {
+    RK_GUARD_BEGIN
+    if (!s || !seg || !h_seal) return RK_ERR_INVALID;
+    std::lock_guard<std::mutex> l(s->mu);
+    if (s->closed) return RK_ERR_INVALID;
+    s->items.push_back(rk_stream::Item{*seg, h_seal, seal_capacity_words, seal_words});
+    s->cv.notify_all();
+    return RK_OK;
+    RK_GUARD_END
+}
+
+int rk_stream_close(rk_stream* s, size_t* failed_index) {
+    RK_GUARD_BEGIN
+    if (failed_index) *failed_index = (size_t)-1;
+    if (!s) return RK_ERR_INVALID;
+    {
+        std::lock_guard<std::mutex> l(s->mu);
+        s->closed = true;
+        s->cv.notify_all();
+    }
+    if (s->worker.joinable()) s->worker.join();
+    const int st = s->status;
+    if (failed_index) *failed_index = s->failed;
+    delete s;
+    return st;
+    RK_GUARD_END
+}
+
 // the text is copied into storage of the calling thread: a later session cannot change it under the caller
 const char* rk_session_last_error(int device) {
     thread_local std::string text;

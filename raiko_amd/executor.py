@@ -106,7 +106,60 @@ def segments_for_proving(ex: Execution, widths: Tuple[int, int, int] = (16, 16, 
     return out
 
 
-def trace_segments(ex: Execution) -> List[Segment]:
+class Stepper:
+    """rk_exec_open / rk_exec_next_segment: the executor one segment at a time (risc0's `run_with_callback`
+    shape), with the trace circuit's witness of every segment as it completes"""
+
+    def __init__(self, elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20):
+        self._lib = _lib.load()
+        words = np.ascontiguousarray(input_words, dtype=np.uint32)
+        opts = RkExecOpts(struct_size=C.sizeof(RkExecOpts), segment_limit_po2=segment_limit_po2, session_limit=0,
+                          input_words=words.ctypes.data_as(_lib.u32p), n_input_words=words.size, record_trace=1)
+        self._h = C.c_void_p()
+        st = self._lib.rk_exec_open(bytes(elf), len(elf), C.byref(opts), C.byref(self._h))
+        if st != 0:
+            detail = self._lib.rk_exec_error(self._h).decode() if self._h else ""
+            self.close()
+            raise ExecutorError("%s%s" % (self._lib.rk_strerror(st).decode(), ": " + detail if detail else ""))
+        self.more = True
+        self.n = 0
+
+    def next(self):
+        """-> (ExecSegment, code, data) of the next executed segment, or None after the last"""
+        if not self.more:
+            return None
+        more = C.c_int(0)
+        st = self._lib.rk_exec_next_segment(self._h, C.byref(more))
+        if st != 0:
+            raise ExecutorError("%s: %s" % (self._lib.rk_strerror(st).decode(), self._lib.rk_exec_error(self._h).decode()))
+        self.more = bool(more.value)
+        s = RkExecSegment()
+        self._lib.rk_exec_segment_get(self._h, self.n, C.byref(s))
+        seg = ExecSegment(s.index, s.po2, int(s.cycles), s.start_pc, s.end_pc, s.exit, tuple(s.pre_state), tuple(s.post_state))
+        rows = 1 << seg.po2
+        code = np.zeros((TRACE_CODE_COLS, rows), dtype=np.uint32)
+        data = np.zeros((TRACE_DATA_COLS, rows), dtype=np.uint32)
+        _lib.check(None, self._lib.rk_exec_witness(self._h, self.n, code.ctypes.data_as(_lib.u32p), data.ctypes.data_as(_lib.u32p)))
+        self.n += 1
+        return seg, code, data
+
+    def finish(self) -> Execution:
+        summ = RkExecSummary()
+        self._lib.rk_exec_summary_get(self._h, C.byref(summ))
+        buf = C.create_string_buffer(max(int(summ.journal_bytes), 1))
+        n = C.c_size_t(0)
+        self._lib.rk_exec_journal(self._h, buf, summ.journal_bytes, C.byref(n))
+        ex = Execution([], buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read))
+        self.close()
+        return ex
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rk_exec_free(self._h)
+            self._h = None
+
+
+def trace_segments(ex: Execution, program=None) -> List[Segment]:
     """One prover segment per executed segment with its EXECUTION TRACE as witness (rk_exec_witness) and the
     stand-in trace circuit's constraint list (circuit_program.trace_program) behind eval_check: the seal then says
     that the pc chain of the committed trace is consistent and starts / ends at the public pcs.  Not rv32im."""
@@ -116,7 +169,8 @@ def trace_segments(ex: Execution) -> List[Segment]:
         raise ValueError("execute(..., record_trace=True) first")
     taps = make_tapset([[(0,)] * TRACE_ACCUM_COLS, [(0,)] * TRACE_CODE_COLS,
                         [((0, 1) if c in (2, 3, 15) else (0,)) for c in range(TRACE_DATA_COLS)]])
-    program = Program(*trace_program(taps), taps)
+    if program is None:
+        program = Program(*trace_program(taps), taps)
     out = []
     for s, (code, data) in zip(ex.segments, ex.witness):
         mont = lambda v: (int(v) << 32) % P
@@ -132,7 +186,7 @@ def trace_segments(ex: Execution) -> List[Segment]:
 
 def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20,
                       widths: Tuple[int, int, int] = (16, 16, 224), device: int = 0, inflight: int = 3,
-                      circuit: str = "synthetic"):
+                      circuit: str = "synthetic", pipeline: bool = False):
     """`prove_locally` end to end (bonsai.rs:230-272): execute, segment, prove every segment through
     rk_prove_session, assemble the receipt around the journal the guest committed.
     circuit = "synthetic": stand-in columns of the executed size (the shape of the S20 workload);
@@ -140,7 +194,30 @@ def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit
     constraint identity verified inside the session.  Returns (Execution, Receipt)."""
     from .hal import prove_session
     from .receipt import Receipt, SegmentReceipt
-    if circuit == "trace":
+    if circuit == "trace" and pipeline:
+        # segment k is proven (rk_stream_*) while the executor runs segment k + 1
+        from .hal import SessionStream
+        stepper = Stepper(elf, input_words, segment_limit_po2)
+        stream, segs, metas = None, [], []
+        try:
+            while True:
+                item = stepper.next()
+                if item is None:
+                    break
+                meta, code, data = item
+                one = Execution([meta], b"", 0, 0, 0, [(code, data)])
+                seg = trace_segments(one, program=segs[0].program if segs else None)[0]
+                if stream is None:
+                    stream = SessionStream(device=device, inflight=inflight, program=seg.program)
+                stream.submit(seg)
+                segs.append(seg)
+                metas.append(meta)
+            ex = stepper.finish()
+            ex.segments = metas
+            seals = stream.close() if stream is not None else []
+        finally:
+            stepper.close()
+    elif circuit == "trace":
         ex = execute(elf, input_words, segment_limit_po2=segment_limit_po2, record_trace=True)
         segs = trace_segments(ex)
         seals = prove_session(segs, device=device, inflight=inflight, program=segs[0].program if segs else None)

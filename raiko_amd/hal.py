@@ -317,6 +317,56 @@ def prove_session(segments, device: int = 0, inflight: int = 3, upload_ahead: in
     return [seals[i][: words[i]].copy() for i in range(n)]
 
 
+class SessionStream:
+    """rk_stream_*: a session whose segments arrive while it runs.  submit() hands one segment over (its arrays
+    are kept alive here), close() waits for everything and returns the seals in submission order."""
+
+    def __init__(self, device: int = 0, inflight: int = 3, upload_ahead: int = 2, verify: bool = True, program=None,
+                 poly_ext=None, params=None):
+        self._lib = _lib.load()
+        self._keep = []
+        self._bufs = []
+        self._words = []
+        self._device = device
+        opts = _lib.RkSessionOpts(device=device, inflight=inflight, upload_ahead=upload_ahead, verify=1 if verify else 0)
+        if poly_ext is not None or program is not None:
+            vopts, vkeep = make_verify_opts(poly_ext, program=program)
+            opts.verify_opts = C.pointer(vopts)
+            self._keep.append((vopts, vkeep))
+        self._params = params
+        if params is not None:
+            opts.params = C.pointer(params)
+        h = C.c_void_p()
+        _lib.check(None, self._lib.rk_stream_open(C.byref(opts), C.byref(h)))
+        self._h = h
+
+    def submit(self, seg: Segment):
+        c, k = make_c_segment(seg)
+        cap = int(self._lib.rk_seal_bound_words_params(C.byref(c), C.byref(self._params))) if self._params is not None else \
+            int(self._lib.rk_seal_bound_words(C.byref(c)))
+        if cap == 0:
+            raise _lib.RkError(_lib.RK_ERR_INVALID, "invalid argument (segment shape or tap set)")
+        buf = np.empty(cap, dtype=np.uint32)
+        words = C.c_size_t(0)
+        self._keep.append((c, k, seg))
+        self._bufs.append(buf)
+        self._words.append(words)
+        _lib.check(None, self._lib.rk_stream_submit(self._h, C.byref(c), _u32p(buf), cap, C.byref(words)))
+
+    def close(self):
+        failed = C.c_size_t(0)
+        st = self._lib.rk_stream_close(self._h, C.byref(failed))
+        self._h = None
+        if st != 0:
+            which = int(failed.value) if failed.value != C.c_size_t(-1).value else -1
+            detail = self._lib.rk_session_last_error(self._device).decode()
+            e = _lib.RkError(st, "%s%s%s" % (self._lib.rk_strerror(st).decode(), ": " + detail if detail else "",
+                                             " (segment %d)" % which if which >= 0 else ""))
+            e.segment = which
+            raise e
+        return [b[: w.value].copy() for b, w in zip(self._bufs, self._words)]
+
+
 _params_keep = []
 
 

@@ -212,3 +212,23 @@ def test_trace_circuit_proof_on_the_cpu_oracle():
     bad = o.oracle_prove(forged)
     assert hal.verify_segment(forged, bad) == 0                                    # commitments are consistent
     assert hal.verify_segment(forged, bad, program=forged.program) == 70           # the pc chain is not
+
+
+def test_stepping_the_executor_gives_the_same_run():
+    """rk_exec_open / rk_exec_next_segment (one segment per call, risc0's run_with_callback shape) against the
+    whole-run entry point: same segments, digests, journal and witness columns"""
+    image = A.elf(A.assemble(LOOP)[0])
+    whole = X.execute(image, segment_limit_po2=13, record_trace=True)
+    st = X.Stepper(image, segment_limit_po2=13)
+    got = []
+    while True:
+        item = st.next()
+        if item is None:
+            break
+        got.append(item)
+    ex = st.finish()
+    assert len(got) == len(whole.segments) and ex.total_cycles == whole.total_cycles and ex.journal == whole.journal
+    for (meta, code, data), ref, (rc, rd) in zip(got, whole.segments, whole.witness):
+        assert meta == ref and np.array_equal(code, rc) and np.array_equal(data, rd)
+    with pytest.raises(X.ExecutorError):
+        X.Stepper(b"not an elf")

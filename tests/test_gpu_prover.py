@@ -365,3 +365,31 @@ def test_execute_witness_prove_under_the_trace_circuit():
     with pytest.raises(_lib.RkError) as ei:
         prove_session(segs, inflight=3, verify=True, program=segs[0].program)
     assert ei.value.status == _lib.RK_ERR_VERIFY and ei.value.segment == 1
+
+
+def test_pipelined_execute_and_prove_matches_the_batch_route():
+    """rk_stream_*: segments submitted while the executor still runs (one at a time) give the seals of the
+    all-at-once session; a forged segment in the stream is reported with its submission index"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import rv32_asm as A
+    from raiko_amd import _lib, executor as X
+    from raiko_amd.hal import SessionStream
+    prog = A.li("a2", 4000) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("slli", "a5", "a4", 1),
+                               ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    ex_a, rc_a = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace")
+    ex_b, rc_b = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace", pipeline=True)
+    assert ex_a.total_cycles == ex_b.total_cycles and ex_a.journal == ex_b.journal and len(rc_b.segments) == 3
+    assert [s.cycles for s in ex_a.segments] == [s.cycles for s in ex_b.segments]
+    for a, b in zip(rc_a.segments, rc_b.segments):
+        assert np.array_equal(a.seal, b.seal)
+    segs = X.trace_segments(X.execute(image, segment_limit_po2=13, record_trace=True))
+    segs[2].groups[2][2, 7] = segs[2].groups[2][2, 8]
+    stream = SessionStream(inflight=2, program=segs[0].program)
+    for s in segs:
+        stream.submit(s)
+    with pytest.raises(_lib.RkError) as ei:
+        stream.close()
+    assert ei.value.status == _lib.RK_ERR_VERIFY and ei.value.segment == 2
