@@ -117,7 +117,11 @@ impl Prover for HipProver {
                 // the reference blocks the async worker for the whole proof (bonsai.rs:230 is a sync fn
                 // called from async code); the SGX backend shows the remedy (provers/sgx/prover/src/lib.rs:276)
                 let po2 = param.execution_po2;
-                let receipt = tokio::task::spawn_blocking(move || prove_locally(po2, encoded_input, &hip))
+                #[cfg(feature = "pipelined")]
+                let prove = prove_locally_pipelined;
+                #[cfg(not(feature = "pipelined"))]
+                let prove = prove_locally;
+                let receipt = tokio::task::spawn_blocking(move || prove(po2, encoded_input, &hip))
                     .await
                     .map_err(|e| ProverError::GuestError(e.to_string()))??;
                 save_receipt(&label, &(String::new(), receipt.clone()))?;
@@ -217,6 +221,96 @@ fn prove_locally(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Re
             seal
         })
         .collect();
+    circuit::assemble_receipt(&session, seals)
+}
+
+/// The same with executor and prover overlapped (cargo feature `pipelined`): risc0's executor hands every
+/// segment to a callback as it completes (RECALLED: `ExecutorImpl::run_with_callback`), the callback builds
+/// the witness and submits it to an `rk_stream`, so segment k is proven while segment k + 1 executes and the
+/// block's wall-clock is the executor's, not the sum.
+#[cfg(feature = "pipelined")]
+fn prove_locally_pipelined(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Receipt, String> {
+    let dir = tempfile::tempdir().map_err(|e| e.to_string())?;
+    let env = ExecutorEnv::builder()
+        .session_limit(None)
+        .segment_limit_po2(po2)
+        .write_slice(&encoded_input)
+        .segment_path(dir.path())
+        .build()
+        .map_err(|e| e.to_string())?;
+    let vopts = rk_verify_opts {
+        p2_rc_ext: ptr::null(),
+        p2_rc_int: ptr::null(),
+        p2_diag: ptr::null(),
+        poly_ext: Some(circuit::poly_ext_trampoline),
+        user: ptr::null_mut(),
+        program: ptr::null(),
+        params: ptr::null(),
+    };
+    let devices: Vec<c_int> = hip.devices.iter().map(|&d| d as c_int).collect();
+    let opts = rk_session_opts {
+        device: devices.first().copied().unwrap_or(0),
+        inflight: hip.inflight,
+        upload_ahead: hip.upload_ahead,
+        verify: 1,
+        devices: if devices.len() > 1 { devices.as_ptr() } else { ptr::null() },
+        n_devices: if devices.len() > 1 { devices.len() as c_int } else { 0 },
+        verify_opts: &vopts,
+        params: ptr::null(),
+    };
+    let mut stream: *mut rk_stream = ptr::null_mut();
+    let st = unsafe { rk_stream_open(&opts, &mut stream) };
+    if st != RK_OK {
+        return Err(describe(st, opts.device, usize::MAX));
+    }
+    let taps = circuit::tapset();
+    // everything a submitted rk_segment points at lives until rk_stream_close: boxed, never moved
+    let mut witnesses: Vec<Box<Witness>> = Vec::new();
+    let mut seals: Vec<Box<(Vec<u32>, usize)>> = Vec::new();
+    let mut exec = ExecutorImpl::from_elf(env, RISC0_GUEST_ELF).map_err(|e| e.to_string())?;
+    let mut submit_err: Option<String> = None;
+    let session = exec
+        .run_with_callback(|segment| {
+            match circuit::witness(&segment) {
+                Ok(w) => {
+                    let w = Box::new(w);
+                    let c_seg = w.as_rk_segment(&taps);
+                    let cap = unsafe { rk_seal_bound_words(&c_seg) };
+                    let mut out = Box::new((vec![0u32; cap], 0usize));
+                    let st = unsafe { rk_stream_submit(stream, &c_seg, out.0.as_mut_ptr(), cap, &mut out.1) };
+                    if st != RK_OK && submit_err.is_none() {
+                        submit_err = Some(format!("rk_stream_submit: status {st}"));
+                    }
+                    witnesses.push(w);
+                    seals.push(out);
+                }
+                Err(e) => {
+                    if submit_err.is_none() {
+                        submit_err = Some(e);
+                    }
+                }
+            }
+            Ok(Box::new(risc0_zkvm::SimpleSegmentRef::new(segment)))
+        })
+        .map_err(|e| e.to_string());
+    let mut failed = usize::MAX;
+    let st = unsafe { rk_stream_close(stream, &mut failed) }; // waits for every submitted segment
+    let session = session?;
+    if let Some(e) = submit_err {
+        return Err(e);
+    }
+    if st != RK_OK {
+        return Err(describe(st, opts.device, failed));
+    }
+    let seals: Vec<Vec<u32>> = seals
+        .into_iter()
+        .map(|b| {
+            let (mut seal, w) = *b;
+            seal.truncate(w);
+            seal
+        })
+        .collect();
+    drop(witnesses);
     circuit::assemble_receipt(&session, seals)
 }
 
