@@ -113,7 +113,8 @@ def oracle_eval_check(prog, taps, po2, lde, globals_, mix, poly_mix):
     return out
 
 
-@pytest.mark.parametrize("seed,po2,n_live", [(0, 3, 0), (1, 6, 10), (2, 8, 70), (3, 10, 150), (4, 7, 300), (5, 11, 40)])
+@pytest.mark.parametrize("seed,po2,n_live", [(0, 3, 0), (1, 6, 10), (2, 8, 70), (3, 10, 150), (4, 7, 300), (5, 11, 40),
+                                              (6, 5, 0), (7, 9, 64), (8, 12, 5), (9, 4, 200), (10, 8, 61), (11, 1, 3)])
 def test_random_programs_match_the_literal_interpreter(hal, seed, po2, n_live):
     rng = np.random.default_rng(1000 + seed)
     taps = synthetic_tapset(int(rng.integers(4, 12)), int(rng.integers(3, 9)), int(rng.integers(4, 40)))

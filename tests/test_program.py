@@ -94,7 +94,7 @@ def test_malformed_programs_are_rejected(bad):
     assert e.value.status == _lib.RK_ERR_INVALID
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(30))
 def test_host_evaluator_matches_the_literal_interpreter(seed):
     rng = np.random.default_rng(seed)
     taps = synthetic_tapset(int(rng.integers(4, 12)), int(rng.integers(3, 9)), int(rng.integers(4, 40)))
