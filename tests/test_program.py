@@ -161,3 +161,45 @@ def test_generated_poly_ext_equals_the_program(cpu_toy):
         assert fn(None, C.pointer(seg), p(pm), p(eval_u), taps.tot_taps, p(mix), mix.size, p(out)) == 0
         assert np.array_equal(out, prog.poly_ext(pm, eval_u, [], mix))
         assert np.array_equal(out, or_poly_ext(prog, taps, pm, eval_u, [], mix))
+
+
+def test_random_garbage_lists_never_crash_the_compiler():
+    """rk_program_create on arbitrary step arrays: accepted or RK_ERR_INVALID, never a crash; what is accepted
+    evaluates on the host to what the oracle's literal interpreter gives"""
+    rng = np.random.default_rng(99)
+    taps = synthetic_tapset(4, 3, 6)
+    accepted = 0
+    for trial in range(400):
+        n = int(rng.integers(1, 40))
+        steps = np.zeros((n, 4), dtype=np.uint32)
+        nf = nm = 0
+        for i in range(n):
+            op = int(rng.integers(0, 10)) if rng.random() < 0.1 else int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 7, 8]))
+            pick = lambda cnt: int(rng.integers(0, max(cnt, 1))) if rng.random() < 0.93 else int(rng.integers(0, 2 ** 32))
+            if op == 1:
+                a, b, c = pick(taps.tot_taps), 0, 0
+            elif op == 2:
+                a, b, c = pick(2), pick(12), 0
+            elif op in (3, 4, 5):
+                a, b, c = pick(nf), pick(nf), 0
+            elif op in (7, 8):
+                a, b, c = pick(nm), pick(nf), pick(nm)
+            else:
+                a, b, c = pick(100), pick(5), pick(5)
+            steps[i] = (op, a, b, c)
+            if op <= 5:
+                nf += 1
+            elif op <= 8:
+                nm += 1
+        ret = int(rng.integers(0, max(nm, 1))) if rng.random() < 0.9 else int(rng.integers(0, 2 ** 32))
+        try:
+            prog = cp.Program(steps, ret, taps)
+        except _lib.RkError as e:
+            assert e.status == _lib.RK_ERR_INVALID
+            continue
+        accepted += 1
+        eval_u = o.rand_elems(rng, (taps.tot_taps, 4))
+        gl, mix, pm = o.rand_elems(rng, (12,)), o.rand_elems(rng, (12,)), o.rand_elems(rng, (4,))
+        assert np.array_equal(prog.poly_ext(pm, eval_u, gl, mix), or_poly_ext(prog, taps, pm, eval_u, gl, mix))
+        assert len(prog.source()) > 0                                    # the code generator copes with it too
+    assert accepted > 40, accepted
