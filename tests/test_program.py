@@ -174,8 +174,8 @@ def test_random_garbage_lists_never_crash_the_compiler():
         steps = np.zeros((n, 4), dtype=np.uint32)
         nf = nm = 0
         for i in range(n):
-            op = int(rng.integers(0, 10)) if rng.random() < 0.1 else int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 7, 8]))
-            pick = lambda cnt: int(rng.integers(0, max(cnt, 1))) if rng.random() < 0.93 else int(rng.integers(0, 2 ** 32))
+            op = int(rng.integers(0, 10)) if rng.random() < 0.02 else int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 7, 8]))
+            pick = lambda cnt: int(rng.integers(0, max(cnt, 1))) if rng.random() < 0.985 else int(rng.integers(0, 2 ** 32))
             if op == 1:
                 a, b, c = pick(taps.tot_taps), 0, 0
             elif op == 2:
