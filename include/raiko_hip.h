@@ -129,6 +129,12 @@ int rk_eltwise_zeroize_elem(rk_ctx* ctx, uint32_t* d_io, size_t n);
 /* Hal::fri_fold: fold of 4 coefficient planes by 2^fri_fold_log2 of the context's parameters
  * (16 by default; bit-reversed order in and out). */
 int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const uint32_t mix[4]);
+/* Plonky3's FRI fold (p3-fri `fold_even_odd`, RECALLED; SP1's arity-2 fold works on evaluations, risc0's
+ * rk_fri_fold on coefficients): d_in_ext = 2 * n_out extension elements (4 consecutive words each), the
+ * evaluations of p over the subgroup of order 2 * n_out in bit-reversed order; d_out_ext = the n_out evaluations
+ * of p_even + beta * p_odd over the squared subgroup, bit-reversed:
+ *   out[i] = (p(x) + p(-x)) / 2 + beta * (p(x) - p(-x)) / (2 x),   x = g^bitrev(i). */
+int rk_fri_fold_evals(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_in_ext, size_t n_out, const uint32_t beta[4]);
 /* Hal::gather_sample: dst[g] = src[g*stride + idx], g < size. */
 int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
 

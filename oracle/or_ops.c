@@ -331,6 +331,21 @@ void or_fri_fold(fp* out, const fp* in, size_t count, const uint32_t* mix) {
         for (int k = 0; k < 4; k++) out[(size_t)k * count + idx] = tot.c[k];
     }
 }
+/* Plonky3 p3-fri fold_even_odd (RECALLED): evaluations of p over the subgroup of order 2 * n_out, bit-reversed,
+ * interleaved extension elements -> evaluations of p_even + beta p_odd over the squared subgroup, bit-reversed */
+void or_fri_fold_evals(fp4* out, const fp4* in, size_t n_out, const uint32_t* beta) {
+    fp4 b; memcpy(&b, beta, 16);
+    unsigned k = log2_exact(2 * n_out);
+    fp half = fp_inv(fp_from_u32(2)), ginv = or_rou_rev(k);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n_out; i++) {
+        size_t j = k > 1 ? (bitrev32((uint32_t)i) >> (32 - (k - 1))) : 0;
+        fp xinv = fp_pow(ginv, j);
+        fp4 even = fp4_scale(fp4_add(in[2 * i], in[2 * i + 1]), half);
+        fp4 odd = fp4_scale(fp4_sub(in[2 * i], in[2 * i + 1]), fp_mul(half, xinv));
+        out[i] = fp4_add(even, fp4_mul(b, odd));
+    }
+}
 void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t stride) {
     for (size_t g = 0; g < size; g++) dst[g] = src[g * stride + idx];
 }

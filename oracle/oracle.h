@@ -95,6 +95,7 @@ void or_eltwise_sum_extelem(fp* out, const fp4* in, size_t count, size_t to_add)
 void or_eltwise_copy_elem(fp* out, const fp* in, size_t n);
 void or_eltwise_zeroize_elem(fp* io, size_t n);
 void or_fri_fold(fp* out, const fp* in, size_t out_count, const uint32_t* mix); /* by 2^g_or.fri_fold_log2 */
+void or_fri_fold_evals(fp4* out, const fp4* in, size_t n_out, const uint32_t* beta); /* Plonky3's, on evaluations */
 void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t stride);
 void or_prefix_products(fp4* io, size_t count);              /* io[i] *= io[i-1], sequential */
 void or_scatter(fp* into, const uint32_t* index, size_t n_cycles, const uint32_t* offsets, const fp* values);

@@ -291,6 +291,7 @@ extern "C" {
     pub fn rk_eltwise_copy_elem(ctx: *mut rk_ctx, d_out: *mut u32, d_in: *const u32, n: usize) -> c_int;
     pub fn rk_eltwise_zeroize_elem(ctx: *mut rk_ctx, d_io: *mut u32, n: usize) -> c_int;
     pub fn rk_fri_fold(ctx: *mut rk_ctx, d_out: *mut u32, d_in: *const u32, out_count: usize, mix: *const u32) -> c_int;
+    pub fn rk_fri_fold_evals(ctx: *mut rk_ctx, d_out_ext: *mut u32, d_in_ext: *const u32, n_out: usize, beta: *const u32) -> c_int;
     pub fn rk_gather_sample(ctx: *mut rk_ctx, d_dst: *mut u32, d_src: *const u32, idx: usize, size: usize, stride: usize) -> c_int;
     pub fn rk_prefix_products(ctx: *mut rk_ctx, d_io_ext: *mut u32, count: usize) -> c_int;
     pub fn rk_scatter(ctx: *mut rk_ctx, d_into: *mut u32, into_words: usize, h_index: *const u32, n_cycles: usize, h_offsets: *const u32, h_values: *const u32) -> c_int;

@@ -170,6 +170,7 @@ SYMBOLS = {
     "rk_eltwise_copy_elem": (C.c_int, [_vp, _vp, _vp, _sz]),
     "rk_eltwise_zeroize_elem": (C.c_int, [_vp, _vp, _sz]),
     "rk_fri_fold": (C.c_int, [_vp, _vp, _vp, _sz, u32p]),
+    "rk_fri_fold_evals": (C.c_int, [_vp, _vp, _vp, _sz, u32p]),
     "rk_gather_sample": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz]),
     "rk_merkle_build": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
     "rk_poly_divide": (C.c_int, [_vp, _vp, _sz, u32p, u32p]),

@@ -124,6 +124,7 @@ int eltwise_add(rk_ctx* ctx, uint32_t* d_out, const uint32_t* a, const uint32_t*
 int eltwise_sum_ext(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add);
 int eltwise_zeroize(rk_ctx* ctx, uint32_t* d_io, size_t n);
 int fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_count, const bb::Ext& mix);
+int fri_fold_evals(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_in_ext, size_t n_out, const bb::Ext& beta);
 int gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
 // rows: d_dst[q*cols + c] = d_matrix[c*rows + h_idx[q]]
 int gather_rows(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_matrix, size_t rows, size_t cols,

@@ -67,6 +67,18 @@ __global__ void fri_fold_kernel(uint32_t* out, const uint32_t* in, size_t count,
     }
 }
 
+__global__ void fri_fold_evals_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t n_out, unsigned k, Ext beta,
+                                      uint32_t half, uint32_t wm, ntt::Tables tb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const Ext a = load_ext(in + 8 * i), b = load_ext(in + 8 * i + 4);       // p(x), p(-x)
+    const uint32_t j = bb::bitrev((uint32_t)i, k - 1);                      // x = g^j, g of order 2^k
+    const uint32_t xinv_half = bb::mul(half, ntt::root_pow(tb, 1, j << (ntt::LAMBDA - k)));
+    const Ext even = bb::scale(bb::add(a, b), half);
+    const Ext odd = bb::scale(bb::sub(a, b), xinv_half);
+    store_ext(out + 4 * i, bb::add(even, bb::mul(beta, odd, wm)));
+}
+
 __global__ void gather_sample_kernel(uint32_t* dst, const uint32_t* src, size_t idx, size_t size, size_t stride) {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     for (; g < size; g += st) dst[g] = src[g * stride + idx];
@@ -343,6 +355,19 @@ int fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_coun
     }
     return post_launch(ctx, "fri_fold_kernel");
 }
+// Plonky3's FRI fold (p3-fri fold_even_odd, RECALLED): on evaluations, arity 2.  `in` = 2 * n_out extension
+// elements (4 consecutive words each), the evaluations of p over the subgroup of order 2 * n_out in
+// bit-reversed order, so p(x) and p(-x) are neighbours; out[i] = (p(x) + p(-x)) / 2 + beta (p(x) - p(-x)) / (2 x)
+// with x = g^bitrev(i): the evaluations of p_even + beta p_odd over the squared subgroup, bit-reversed.
+int fri_fold_evals(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_in_ext, size_t n_out, const bb::Ext& beta) {
+    if (!is_pow2(n_out) || 2 * n_out > ((size_t)1 << ntt::LAMBDA)) return RK_ERR_INVALID;
+    const unsigned k = log2u(2 * n_out);
+    const uint32_t half = bb::inv(bb::encode(2));
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)n_out * 48);
+    hipLaunchKernelGGL(fri_fold_evals_kernel, dim3(grid_for(n_out)), dim3(TPB), 0, ctx->stream, d_out_ext, d_in_ext, n_out, k, beta,
+                       half, ctx->sys.wm, ctx->tb);
+    return post_launch(ctx, "fri_fold_evals_kernel");
+}
 int gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {
     if (size == 0) return RK_OK;
     hipLaunchKernelGGL(gather_sample_kernel, dim3(grid_for(size)), dim3(TPB), 0, ctx->stream, d_dst, d_src, idx, size,
@@ -564,6 +589,14 @@ int rk_fri_fold(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t out_c
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     bb::Ext m{{mix[0], mix[1], mix[2], mix[3]}};
     return rk::fri_fold(ctx, d_out, d_in, out_count, m);
+    RK_GUARD_END
+}
+int rk_fri_fold_evals(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_in_ext, size_t n_out, const uint32_t beta[4]) {
+    RK_GUARD_BEGIN
+    if (!ctx || !d_out_ext || !d_in_ext || !beta || n_out == 0) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bb::Ext b{{beta[0], beta[1], beta[2], beta[3]}};
+    return rk::fri_fold_evals(ctx, d_out_ext, d_in_ext, n_out, b);
     RK_GUARD_END
 }
 int rk_gather_sample(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {

@@ -188,6 +188,11 @@ class HipHal:
         mx = np.ascontiguousarray(mix, dtype=np.uint32)
         self._ck(self._lib.rk_fri_fold(self._ctx, _ptr(out), _ptr(inp), out_count, _u32p(mx)))
 
+    def fri_fold_evals(self, out, inp, n_out: int, beta):
+        """Plonky3's arity-2 fold on bit-reversed evaluations (interleaved extension elements)"""
+        b = np.ascontiguousarray(beta, dtype=np.uint32)
+        self._ck(self._lib.rk_fri_fold_evals(self._ctx, _ptr(out), _ptr(inp), n_out, _u32p(b)))
+
     def gather_sample(self, dst, src, idx: int, size: int, stride: int):
         self._ck(self._lib.rk_gather_sample(self._ctx, _ptr(dst), _ptr(src), idx, size, stride))
 

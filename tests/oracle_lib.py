@@ -119,7 +119,7 @@ def oracle():
             "or_mix_poly_coeffs": (None, [vp, vp, vp, vp, vp, sz, sz]),
             "or_eltwise_add_elem": (None, [vp, vp, vp, sz]), "or_eltwise_sum_extelem": (None, [vp, vp, sz, sz]),
             "or_eltwise_copy_elem": (None, [vp, vp, sz]), "or_eltwise_zeroize_elem": (None, [vp, sz]),
-            "or_fri_fold": (None, [vp, vp, sz, vp]), "or_gather_sample": (None, [vp, vp, sz, sz, sz]),
+            "or_fri_fold": (None, [vp, vp, sz, vp]), "or_fri_fold_evals": (None, [vp, vp, sz, vp]), "or_gather_sample": (None, [vp, vp, sz, sz, sz]),
             "or_poly_interpolate": (None, [vp, vp, vp, sz]), "or_poly_divide": (None, [vp, sz, vp, vp]),
             "or_poly_eval": (None, [vp, sz, vp, vp]),
             "or_prove_segment": (C.c_int, [C.POINTER(OrSegment), C.POINTER(u32p), C.POINTER(sz), C.c_int]),

@@ -287,3 +287,19 @@ def test_session_under_sp1_parameters_and_back(cfg):
     plain = [synthetic_segment(9, (4, 4, 12), seed=80 + i) for i in range(4)]
     for seg, seal in zip(plain, prove_session(plain, inflight=3, verify=True)):
         assert np.array_equal(seal, o.oracle_prove(seg))
+
+
+@pytest.mark.parametrize("k", [1, 2, 8, 16, 21])
+def test_fri_fold_on_evaluations(cfg, orc, k):
+    """Plonky3's arity-2 fold on bit-reversed evaluations (rk_fri_fold_evals) against the oracle, under SP1's field"""
+    h, apply = cfg
+    apply(**SP1_FIELD)
+    rng = np.random.default_rng(k)
+    n_out = 1 << (k - 1)
+    inp = o.rand_elems(rng, (2 * n_out, 4))
+    beta = o.rand_elems(rng, (4,))
+    want = np.zeros((n_out, 4), dtype=np.uint32)
+    orc.or_fri_fold_evals(o.ptr(want), o.ptr(inp), n_out, o.ptr(beta))
+    out = h.alloc_elem(4 * n_out)
+    h.fri_fold_evals(out, h.copy_from_elem(inp), n_out, beta)
+    assert np.array_equal(out.to_host().reshape(n_out, 4), want)

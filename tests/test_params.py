@@ -323,3 +323,35 @@ def test_product_param_blob_validation():
     assert hal.verify_segment(seg, seal, params=bad_size) == -1
     assert hal.verify_segment(seg, seal, params=hal.make_params(1)) > 0        # SP1's set is a valid one: the all-zero seal is just not a proof
     assert hal.verify_segment(seg, seal, params=hal.make_params(0, queries=100)) > 0   # parsed; the seal is just wrong
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 9])
+@pytest.mark.parametrize("w", [P - 11, 11])
+def test_fold_on_evaluations_equals_fold_on_coefficients(params, orc, k, w):
+    """Plonky3's arity-2 FRI fold works on evaluations (or_fri_fold_evals), risc0's on coefficients: for the
+    same polynomial and challenge they describe the same folded polynomial -- evaluate(q) with
+    q_j = p_2j + beta p_2j+1 (exact Python arithmetic) equals fold_evals(evaluate(p))"""
+    params(ext_w=w)
+    rng = np.random.default_rng(10 * k + (w == 11))
+    n = 1 << k
+    coeffs = o.rand_elems(rng, (4, n))                       # 4 planes: the extension polynomial p
+    beta = o.rand_elems(rng, (4,))
+
+    def evaluate_bitrev(planes):                              # natural coefficients -> bit-reversed evaluations, (size, 4)
+        m = planes.shape[1]
+        ev = planes.copy()
+        if m > 1:
+            orc.or_batch_bit_reverse(o.ptr(ev), m, 4)         # the oracle's NTT takes bit-reversed coefficients
+            orc.or_batch_evaluate_ntt(o.ptr(ev), m, 4, 0)     # -> natural-order evaluations
+            orc.or_batch_bit_reverse(o.ptr(ev), m, 4)
+        return np.ascontiguousarray(ev.T)
+    got = np.zeros((n // 2, 4), dtype=np.uint32)
+    orc.or_fri_fold_evals(o.ptr(got), o.ptr(evaluate_bitrev(coeffs)), n // 2, o.ptr(beta))
+    pc, bc = o.from_mont(coeffs).astype(object), canon(beta)
+    q = np.zeros((4, n // 2), dtype=np.uint64)
+    for j in range(n // 2):
+        odd = ext_mul_py(bc, [int(pc[c, 2 * j + 1]) for c in range(4)], w)
+        for c in range(4):
+            q[c, j] = (int(pc[c, 2 * j]) + odd[c]) % P
+    want = evaluate_bitrev(o.to_mont(q))
+    assert np.array_equal(got, want)
