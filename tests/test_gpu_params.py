@@ -303,3 +303,29 @@ def test_fri_fold_on_evaluations(cfg, orc, k):
     out = h.alloc_elem(4 * n_out)
     h.fri_fold_evals(out, h.copy_from_elem(inp), n_out, beta)
     assert np.array_equal(out.to_host().reshape(n_out, 4), want)
+
+
+def test_gpu_seals_against_the_committed_round2_digests():
+    """the product against tests/golden/seal_digests_round2.json alone (no oracle in the loop): SP1's parameter set,
+    other protocol shapes, proof of work, and the toy circuit's constraint list under both fields"""
+    import json
+    from test_oracle_prover import ROUND2_CASES, ROUND2_GOLDEN, digest, round2_case
+    from raiko_amd import toy_circuit
+    from raiko_amd.hal import make_params
+    toy_circuit.load()
+    golden = json.load(open(ROUND2_GOLDEN))
+    h = HipHal(0)
+    try:
+        for name in ROUND2_CASES:
+            kw, seg = round2_case(name)
+            kw = dict(kw)
+            preset = kw.pop("preset")
+            h.set_params(preset, **kw)
+            if getattr(seg, "program", None) is not None:
+                seg.hooks = toy_circuit.hooks_ptr           # the real accumulate hook (the oracle marker was 1)
+            seal = h.prove_segment(seg)
+            assert golden[name] == {"words": int(seal.size), "sha256": digest(seal)}, name
+            blob = make_params(preset, **kw)
+            assert verify_segment(seg, seal, params=blob, program=getattr(seg, "program", None)) == 0
+    finally:
+        h.close()
