@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Soak run on one MI355X: for `seconds`, four host threads keep issuing work against one GPU -- sessions under risc0's
+and SP1's parameter sets (the device's contexts are re-parameterised back and forth), streams, the toy circuit
+behind hand-written hooks, its constraint list interpreted and run-time compiled -- every seal verified inside
+the library (constraint identity where there is a circuit) and a sample of them compared with a second proof
+of the same segment.  Prints one JSON line; exit code 1 on any failure."""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raiko_amd import circuit_program as cp, toy_circuit  # noqa: E402
+from raiko_amd.hal import HipHal, SessionStream, make_params, prove_session  # noqa: E402
+from raiko_amd.segment import synthetic_segment  # noqa: E402
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    toy_circuit.load()
+    sp1 = make_params(1)
+    hal = HipHal(0)
+    toy = toy_circuit.toy_segment(9, (8, 4, 8), seed=5)
+    prog_i = cp.Program(*cp.toy_program(toy.taps, toy.n_accum_mix), toy.taps)
+    prog_j = cp.Program(*cp.toy_program(toy.taps, toy.n_accum_mix), toy.taps)
+    prog_j.compile(hal)
+    stop = time.time() + seconds
+    counts = {"risc0": 0, "sp1": 0, "stream": 0, "toy_hooks": 0, "toy_interpreted": 0, "toy_compiled": 0}
+    errors = []
+    lock = threading.Lock()
+
+    def bump(k, n):
+        with lock:
+            counts[k] += n
+
+    def worker(tid):
+        rng = np.random.default_rng(tid)
+        try:
+            while time.time() < stop:
+                kind = int(rng.integers(0, 6))
+                po2 = int(rng.integers(6, 13))
+                n = int(rng.integers(1, 6))
+                if kind == 0:
+                    segs = [synthetic_segment(po2, (4, 4, 12), seed=int(rng.integers(1 << 30))) for _ in range(n)]
+                    a = prove_session(segs, inflight=3, verify=True)
+                    if rng.random() < 0.2:
+                        b = prove_session(segs[:1], inflight=1, verify=False)
+                        assert np.array_equal(a[0], b[0])
+                    bump("risc0", n)
+                elif kind == 1:
+                    segs = [synthetic_segment(po2, (4, 4, 12), seed=int(rng.integers(1 << 30)), blowup_log2=1) for _ in range(n)]
+                    prove_session(segs, inflight=3, verify=True, params=sp1)
+                    bump("sp1", n)
+                elif kind == 2:
+                    st = SessionStream(inflight=2)
+                    for _ in range(n):
+                        st.submit(synthetic_segment(po2, (3, 2, 7), seed=int(rng.integers(1 << 30))))
+                    assert len(st.close()) == n
+                    bump("stream", n)
+                else:
+                    segs = [toy_circuit.toy_segment(min(po2, 11), (8, 4, 8), seed=int(rng.integers(1 << 30))) for _ in range(n)]
+                    if kind == 3:
+                        prove_session(segs, inflight=3, verify=True, poly_ext=toy_circuit.poly_ext_fn())
+                        bump("toy_hooks", n)
+                    else:
+                        prog = prog_i if kind == 4 else prog_j
+                        for s in segs:
+                            s.program = prog
+                        prove_session(segs, inflight=3, verify=True, program=prog)
+                        bump("toy_interpreted" if kind == 4 else "toy_compiled", n)
+        except Exception as e:  # noqa: BLE001
+            with lock:
+                errors.append("thread %d: %r" % (tid, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    t0 = time.time()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    print(json.dumps({"what": "soak: four host threads against one GPU, every seal verified inside the library", "seconds": round(time.time() - t0, 1),
+                      "segments_proven": counts, "total": sum(counts.values()), "errors": errors}))
+    sys.exit(1 if errors else 0)
+
+
+if __name__ == "__main__":
+    main()
