@@ -245,6 +245,7 @@ int rk_ctx_destroy(rk_ctx* ctx) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
+    for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_p2) (void)hipFree(ctx->d_p2);

@@ -42,6 +42,7 @@ struct rk_ctx {
     size_t scratch_bytes = 0;
 
     rk_timing timing{};
+    std::vector<hipEvent_t> stage_events;            // pool behind the per-stage brackets of prove_segment
 
     // optional per-kernel-class timing (hipEvent pairs on the ctx stream, resolved lazily)
     bool ktime_on = false;

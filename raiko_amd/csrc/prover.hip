@@ -173,34 +173,57 @@ struct PolyGroup {
     }
 };
 
-struct Stopwatch {
+// Per-stage device time without stalling the proof: every stage is bracketed by two events taken from a pool
+// the context keeps, and the brackets are read once the proof has finished (a stop that waited for its event
+// made the host notice every stage boundary before it could queue the next stage: ~11 bubbles per proof, which
+// is what small segments are made of).  With RK_ROCTX=1 a stage is also a roctx range and does wait, so that
+// the range covers the device work.
+struct StageClock {
     rk_ctx* ctx;
-    hipEvent_t ev[2];
-    bool ok = false, ranged = false;
-    explicit Stopwatch(rk_ctx* c) : ctx(c) {
-        ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
-    }
-    ~Stopwatch() {
-        if (ok) {
-            (void)hipEventDestroy(ev[0]);
-            (void)hipEventDestroy(ev[1]);
-        }
-    }
-    // `stage`: with RK_ROCTX=1 in the environment the stage is also a roctx range (rocprofv3 --marker-trace)
+    struct Bracket {
+        hipEvent_t a, b;
+        float* acc;
+    };
+    std::vector<Bracket> used;
+    size_t open = (size_t)-1;
+    bool ranged = false;
+    explicit StageClock(rk_ctx* c) : ctx(c) {}
     void start(const char* stage = nullptr) {
         ranged = stage && rk::trace_push(stage);
-        if (ok) (void)hipEventRecord(ev[0], ctx->stream);
-    }
-    // accumulates elapsed device time since start() into *acc (synchronises the stream)
-    void stop(float* acc) {
-        if (ok) {
-            (void)hipEventRecord(ev[1], ctx->stream);
-            (void)hipEventSynchronize(ev[1]);
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) *acc += ms;
+        if (ctx->stage_events.size() < 2 * (used.size() + 1)) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                open = (size_t)-1;
+                return;
+            }
+            ctx->stage_events.push_back(e0);
+            ctx->stage_events.push_back(e1);
         }
-        if (ranged) rk::trace_pop();  // after the wait: the range covers the stage's device work
+        Bracket br{ctx->stage_events[2 * used.size()], ctx->stage_events[2 * used.size() + 1], nullptr};
+        (void)hipEventRecord(br.a, ctx->stream);
+        used.push_back(br);
+        open = used.size() - 1;
+    }
+    void stop(float* acc) {
+        if (open != (size_t)-1) {
+            used[open].acc = acc;
+            (void)hipEventRecord(used[open].b, ctx->stream);
+            if (ranged) (void)hipEventSynchronize(used[open].b);  // profiling mode: the range ends with the device work
+        }
+        if (ranged) rk::trace_pop();
         ranged = false;
+        open = (size_t)-1;
+    }
+    // after the proof's last synchronisation: add every bracket to its accumulator
+    void resolve() {
+        for (const Bracket& br : used) {
+            if (!br.acc) continue;
+            (void)hipEventSynchronize(br.b);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, br.a, br.b) == hipSuccess) *br.acc += ms;
+        }
+        used.clear();
     }
 };
 
@@ -249,8 +272,18 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     Transcript iop(&kc);
     uint32_t digest[8];
     ctx->timing = rk_timing{};
-    Stopwatch total_sw(ctx), sw(ctx);
-    total_sw.start("segment");
+    StageClock sw(ctx);
+    sw.start("segment");
+    const size_t total_bracket = sw.used.size() - 1;
+    struct Finish {  // also on the error returns
+        StageClock& c;
+        bool ranged;
+        ~Finish() {
+            c.resolve();
+            if (ranged) rk::trace_pop();
+        }
+    } finish_on_exit{sw, sw.ranged};
+    sw.ranged = false;
 
     {
         uint32_t e[16];
@@ -616,7 +649,10 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         for (size_t k = 0; k < rounds.size(); k++) write_opening(iop, rounds[k]->merkle, oround[k], q);
     }
     sw.stop(&ctx->timing.query);
-    total_sw.stop(&ctx->timing.total);
+    if (total_bracket < sw.used.size()) {  // the outermost bracket was opened first and closes last
+        sw.used[total_bracket].acc = &ctx->timing.total;
+        (void)hipEventRecord(sw.used[total_bracket].b, ctx->stream);
+    }
     seal.swap(iop.proof);
     return RK_OK;
 }
