@@ -10,6 +10,9 @@
 namespace {
 
 constexpr int HASH_BLOCK = 256;
+// levels with at most this many parents go cell-parallel (hash_fold_top): a cell-parallel permutation costs ~6x the
+// lane-cycles of a lane-per-parent one, so it only pays where the level is latency-bound anyway
+constexpr size_t CELLS_MAX_OUT = 4096;
 
 // C = the configured p2::Core (width 24 or 16, external 4x4 block): one kernel instance per Core.
 // pad_free: the last partial block leaves the remaining rate cells as they are (Plonky3
@@ -102,6 +105,131 @@ __global__ __launch_bounds__(TAIL_MAX) void hash_fold_tail_kernel(uint32_t* __re
     }
 }
 
+// ---- cell-parallel permutation: one 32-lane half-wave per permutation, one lane per cell --------------
+// The levels near the root have too few parents to fill the chip, so a lane-per-permutation launch costs the
+// latency of one permutation (~6.7 k dependent instructions, ~15 us) per level whatever its size.  Here the
+// 24 (16) cells of one state sit in consecutive lanes, values canonical Montgomery residues:
+//   * S-boxes run in all lanes at once (full rounds) or are kept by cell 0 only (partial rounds);
+//   * external layer circ(2 M4, M4, ...): out = M4 (x_quad + X), X_j = sum over quads of cell j -- the quad
+//     sums are two row rotations (DPP row_ror:4/8) and one exchange of the two 16-lane rows
+//     (v_permlane16_swap, gfx950), the 4x4 product takes its operands by DPP quad broadcasts and
+//     accumulates exactly in 64 bits (< 16 p), one REDC and one product by 2^64 bring it back;
+//   * internal layer: the cell sum is a 5-step DPP reduction, then x_i = d_i x_i + S.
+// ~40 dependent instructions per round instead of ~230, nothing goes through LDS.  Lanes beyond the width
+// hold zero between layers so that they do not disturb the sums.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+constexpr int DPP_ROR1 = 0x121, DPP_ROR2 = 0x122, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
+constexpr int DPP_Q0 = 0x00, DPP_Q1 = 0x55, DPP_Q2 = 0xaa, DPP_Q3 = 0xff;
+// lane i + lane (i ^ 16), both < p: the sum of the two rows of a half-wave, canonical
+__device__ __forceinline__ uint32_t row_pair_sum(uint32_t v) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return bb::ucanon(r[0] + r[1]);
+}
+constexpr uint32_t R2_NQ = bb::R2 * (0u - bb::MPRIME);  // bb::umul_const companion of 2^64 mod p
+
+template <class C>
+struct CellPerm {
+    static constexpr int W = C::CELLS;
+    uint32_t m0, m1, m2, m3;  // this lane's row of the 4x4 block
+    uint32_t diag;
+    uint32_t rc[2 * p2::ROUNDS_HALF_FULL];  // rc - p of this cell, per full round
+    unsigned cell;
+    bool active;
+
+    __device__ __forceinline__ void init(const typename C::Consts& k, unsigned cell_) {
+        cell = cell_;
+        active = cell < (unsigned)W;
+        const unsigned j = cell & 3u;
+        // rows of the block, one nibble per coefficient (see m_ext_redc)
+        const uint32_t pk = C::M4_KIND == 0 ? (j == 0 ? 0x3175u : j == 1 ? 0x1164u : j == 2 ? 0x7531u : 0x6411u)
+                                            : (j == 0 ? 0x1132u : j == 1 ? 0x1321u : j == 2 ? 0x3211u : 0x2113u);
+        m0 = pk & 15u;
+        m1 = (pk >> 4) & 15u;
+        m2 = (pk >> 8) & 15u;
+        m3 = pk >> 12;
+        diag = active ? k.diag[cell] : 0u;
+#pragma unroll
+        for (int r = 0; r < 2 * p2::ROUNDS_HALF_FULL; r++) rc[r] = (active ? k.rc_ext[r * W + cell] : 0u) - bb::P;
+    }
+    __device__ __forceinline__ uint32_t ext(uint32_t x) const {
+        uint32_t X = bb::ucanon(x + dpp_mov<DPP_ROR4>(x));
+        X = bb::ucanon(X + dpp_mov<DPP_ROR8>(X));
+        X = row_pair_sum(X);
+        const uint32_t z = bb::ucanon(x + X);
+        uint64_t w = (uint64_t)dpp_mov<DPP_Q0>(z) * m0;
+        w += (uint64_t)dpp_mov<DPP_Q1>(z) * m1;
+        w += (uint64_t)dpp_mov<DPP_Q2>(z) * m2;
+        w += (uint64_t)dpp_mov<DPP_Q3>(z) * m3;
+        // w < 16 p: REDC gives w / 2^32 (< p + 8), the product by 2^64 / 2^32 restores w mod p
+        const uint32_t u = bb::ucanon(bb::umul_const(bb::uredc64(w), bb::R2, R2_NQ));
+        return active ? u : 0u;
+    }
+    __device__ __forceinline__ uint32_t internal(uint32_t x, uint32_t rc_mp) const {
+        const uint32_t y = bb::sbox7_add(x, rc_mp);
+        x = cell == 0 ? y : x;
+        uint32_t s = bb::ucanon(x + dpp_mov<DPP_ROR1>(x));
+        s = bb::ucanon(s + dpp_mov<DPP_ROR2>(s));
+        s = bb::ucanon(s + dpp_mov<DPP_ROR4>(s));
+        s = bb::ucanon(s + dpp_mov<DPP_ROR8>(s));
+        s = row_pair_sum(s);
+        const uint32_t r = bb::add(bb::mul(x, diag), s);
+        return active ? r : 0u;
+    }
+    // x: this lane's cell (canonical, zero beyond the width); every lane of the wave must be here
+    __device__ __forceinline__ uint32_t permute(uint32_t x, const typename C::Consts& k) const {
+        x = ext(x);
+#pragma unroll
+        for (int r = 0; r < p2::ROUNDS_HALF_FULL; r++) x = ext(bb::sbox7_add(x, rc[r]));
+        // unrolled: the round constants are wave-uniform scalar loads, which a rolled loop would wait for one by one
+#pragma unroll
+        for (int r = 0; r < C::ROUNDS_PARTIAL; r++) x = internal(x, k.rc_int_mp[r]);
+#pragma unroll
+        for (int r = p2::ROUNDS_HALF_FULL; r < 2 * p2::ROUNDS_HALF_FULL; r++) x = ext(bb::sbox7_add(x, rc[r]));
+        return x;
+    }
+};
+
+// `levels` (<= CELLS_MAX_LEVELS) levels of a tree in one launch: workgroup b owns the 2^levels nodes
+// [b 2^levels, (b + 1) 2^levels) of the level with 2 first_out nodes and everything above them; a level lives
+// in LDS (ping-pong) between steps and every parent also goes to its heap slot.  blockDim = 32 lanes per
+// parent of the first step, capped at 1024.
+constexpr unsigned CELLS_MAX_LEVELS = 6;
+template <class C>
+__global__ __launch_bounds__(1024) void hash_fold_cells_kernel(uint32_t* __restrict__ nodes, unsigned first_out, unsigned levels,
+                                                               const typename C::Consts* __restrict__ kc) {
+    __shared__ uint32_t buf[2][(1u << CELLS_MAX_LEVELS) * p2::OUT];
+    const typename C::Consts& k = *kc;
+    const unsigned tid = threadIdx.x, b = blockIdx.x;
+    const unsigned nhw = blockDim.x >> 5, h = tid >> 5, cell = tid & 31u;
+    const unsigned in_cnt = 1u << levels;
+    for (unsigned i = tid; i < in_cnt * p2::OUT; i += blockDim.x)
+        buf[0][i] = nodes[((size_t)2 * first_out + (size_t)b * in_cnt) * p2::OUT + i];
+    CellPerm<C> cp;
+    cp.init(k, cell);
+    __syncthreads();
+    for (unsigned l = 0; l < levels; l++) {
+        const unsigned cnt = in_cnt >> (l + 1);
+        const size_t out_base = (size_t)(first_out >> l) + (size_t)b * cnt;
+        const uint32_t* src = buf[l & 1];
+        uint32_t* dst = buf[(l + 1) & 1];
+        for (unsigned t0 = 0; t0 < cnt; t0 += nhw) {  // uniform trip count: idle half-waves redo parent 0 and drop it
+            const unsigned t = t0 + h;
+            const bool valid = t < cnt;
+            const unsigned tt = valid ? t : 0u;
+            uint32_t x = cell < 2 * p2::OUT ? src[2 * tt * p2::OUT + cell] : 0u;
+            x = cp.permute(x, k);
+            if (valid && cell < (unsigned)p2::OUT) {
+                dst[t * p2::OUT + cell] = x;
+                nodes[(out_base + t) * p2::OUT + cell] = x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Proof of work on the transcript: candidate w = base + lane.  digest = hash([w]) (one block of the
 // sponge), the generator absorbs it (cells[0..8) += digest, permute) and the next four outputs,
 // decoded and xor-ed, must be zero in their low `bits` bits -- exactly what Transcript::commit and
@@ -167,8 +295,8 @@ int merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_
     if (!is_pow2(rows)) return RK_ERR_INVALID;
     RK_TRY(hash_rows(ctx, d_nodes + rows * p2::OUT, d_matrix, rows, cols));
     size_t layer = rows / 2;
-    for (; layer > TAIL_MAX; layer /= 2) RK_TRY(hash_fold(ctx, d_nodes, layer));
-    if (layer >= 1) RK_TRY(hash_fold_tail(ctx, d_nodes, layer));
+    for (; layer > CELLS_MAX_OUT; layer /= 2) RK_TRY(hash_fold(ctx, d_nodes, layer));
+    if (layer >= 1) RK_TRY(hash_fold_top(ctx, d_nodes, layer));
     return RK_OK;
 }
 
@@ -203,6 +331,27 @@ int pow_grind(rk_ctx* ctx, const uint32_t* h_cells, unsigned bits, uint32_t* non
         }
     }
     return RK_ERR_INTERNAL;
+}
+
+// every level from the one with `top_output_size` parents up to the root, cell-parallel: launches of up to five
+// levels, the last one of up to six (one workgroup)
+int hash_fold_top(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
+    if (!is_pow2(top_output_size) || top_output_size > CELLS_MAX_OUT) return RK_ERR_INVALID;
+    unsigned remaining = 1;  // levels left, the root's included
+    for (size_t n = top_output_size; n > 1; n >>= 1) remaining++;
+    unsigned first_out = (unsigned)top_output_size;
+    while (remaining) {
+        const unsigned m = remaining <= CELLS_MAX_LEVELS ? remaining : std::min(remaining - CELLS_MAX_LEVELS, CELLS_MAX_LEVELS - 1);
+        const unsigned blocks = (2 * first_out) >> m;
+        const unsigned threads = std::max(64u, std::min(1024u, 32u << (m - 1)));
+        KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)blocks * ((1u << m) - 1) * 96);
+        RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_fold_cells_kernel<C>, dim3(blocks), dim3(threads), 0, ctx->stream, d_nodes,
+                                               first_out, m, (const typename C::Consts*)ctx->d_p2));
+        RK_TRY(post_launch(ctx, "hash_fold_cells_kernel"));
+        first_out >>= m;
+        remaining -= m;
+    }
+    return RK_OK;
 }
 
 int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {

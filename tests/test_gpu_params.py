@@ -90,6 +90,28 @@ def test_hash_rows_fold_merkle_instances(cfg, orc, kw, cols):
     assert np.array_equal(leaves.to_host().reshape(rows, 8), want[rows:])
 
 
+@pytest.mark.parametrize("kw", [dict(), SP1_HASH, dict(p2_width=16, p2_m4=0), dict(p2_width=24, p2_m4=1)])
+def test_merkle_heights_all_instances(cfg, orc, kw):
+    """Every split of a tree into cell-parallel launches (hash_fold_top: up to five levels per launch, six in the
+    last) and the lane-per-parent levels below them, for each Poseidon2 instance: heap == the oracle's."""
+    h, apply = cfg
+    apply(**kw)
+    for log_rows in list(range(1, 15)) + [17, 18]:
+        rows, cols = 1 << log_rows, 3
+        rng = np.random.default_rng(7000 + log_rows)
+        m = o.rand_elems(rng, (cols, rows))
+        want = np.zeros((2 * rows, 8), dtype=np.uint32)
+        orc.or_hash_rows(o.ptr(want[rows:]), o.ptr(m), rows, cols)
+        size = rows
+        while size > 1:
+            orc.or_hash_fold(o.ptr(want), size, size // 2)
+            size //= 2
+        nodes = h.alloc_elem(2 * rows * 8)
+        h.merkle_build(nodes, h.copy_from_elem(m), rows, cols)
+        got = nodes.to_host().reshape(2 * rows, 8)
+        assert np.array_equal(got[1:], want[1:]), log_rows
+
+
 def test_custom_width16_tables(cfg, orc):
     h, apply = cfg
     rng = np.random.default_rng(16)
