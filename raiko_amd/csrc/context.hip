@@ -100,6 +100,27 @@ int dev_free(rk_ctx* ctx, void* p) {
     }
     return RK_OK;
 }
+int upload(rk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    constexpr size_t RING = (size_t)4 << 20;
+    if (bytes == 0) return RK_OK;
+    if (bytes > RING / 4) {
+        RK_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RK_OK;
+    }
+    if (!ctx->h_ring) RK_HIP_TRY(ctx, hipHostMalloc(&ctx->h_ring, RING, hipHostMallocDefault));
+    size_t at = (ctx->h_ring_at + 63) & ~(size_t)63;
+    if (at + bytes > RING) {
+        // wrap: every copy out of the ring was queued on this stream, so after this wait none is pending
+        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        at = 0;
+    }
+    std::memcpy((char*)ctx->h_ring + at, h_src, bytes);
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d_dst, (char*)ctx->h_ring + at, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_ring_at = at + bytes;
+    return RK_OK;
+}
+
 int scratch(rk_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->scratch_bytes) {
         // stream-ordered users of the old buffer must finish before it is released
@@ -247,6 +268,7 @@ int rk_ctx_destroy(rk_ctx* ctx) {
     }
     for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_p2) (void)hipFree(ctx->d_p2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

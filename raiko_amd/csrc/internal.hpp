@@ -40,6 +40,9 @@ struct rk_ctx {
     // small staging area for per-call parameter uploads
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // page-locked ring the small uploads are staged in (rk::upload): no wait per upload
+    void* h_ring = nullptr;
+    size_t h_ring_at = 0;
 
     rk_timing timing{};
     std::vector<hipEvent_t> stage_events;            // pool behind the per-stage brackets of prove_segment
@@ -104,6 +107,9 @@ void trace_pop();
 int dev_alloc(rk_ctx* ctx, size_t bytes, void** out);
 int dev_free(rk_ctx* ctx, void* p);
 int scratch(rk_ctx* ctx, size_t bytes, void** out);  // valid until the next scratch() call
+// host -> device on the ctx stream without waiting: the bytes are staged in the context's page-locked ring, so the
+// caller's buffer is free on return (large uploads fall back to copy + wait)
+int upload(rk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int post_launch(rk_ctx* ctx, const char* what);
 
 // NTT (kernels_ntt.hip)
@@ -133,6 +139,8 @@ int gather_rows(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_matrix, size_t r
 // digests: d_dst[i] = d_nodes[d_idx[i]]
 int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const uint32_t* d_idx, size_t n_idx);
 int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool bit_reversed);
+// n_pts tables of n powers each, one launch: table j (at d_pw_ext + j * n * 4) holds h_pts[j]^k
+int ext_powers_many(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext* h_pts, size_t n_pts, size_t n, bool bit_reversed);
 int bit_reverse_ext(rk_ctx* ctx, uint32_t* d_io_ext, size_t size, size_t count);
 // levels of a Merkle tree with <= 1024 parents, fused in one launch (kernels_hash.hip)
 int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size);
@@ -146,7 +154,7 @@ int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& 
 // n_items polynomials of `count` ext coefficients at d_base_ext + h_offsets[i] (in ext elements), each divided
 // by (x - h_z[i]) in one batch of launches; remainders to h_rems (may be null)
 int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size_t* h_offsets, const bb::Ext* h_z,
-                     size_t n_items, bb::Ext* h_rems);
+                     size_t n_items, bb::Ext* h_rems, uint32_t* d_rems = nullptr);  // d_rems: n_items x 4 words, no wait
 int prefix_products(rk_ctx* ctx, uint32_t* d_io_ext, size_t count);
 int scatter(rk_ctx* ctx, uint32_t* d_into, size_t into_words, const uint32_t* h_index, size_t n_cycles,
             const uint32_t* h_offsets, const uint32_t* h_values);

@@ -111,6 +111,21 @@ __global__ void ext_powers_kernel(uint32_t* pw, Ext x, size_t n, unsigned rev_bi
         cur = bb::mul(cur, x, wm);
     }
 }
+// the same for blockIdx.y = table index, base points read from device memory
+__global__ void ext_powers_many_kernel(uint32_t* pw, const Ext* xs, size_t n, unsigned rev_bits, uint32_t wm) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t start = t * PW_CH;
+    if (start >= n) return;
+    const Ext x = xs[blockIdx.y];
+    pw += (size_t)blockIdx.y * n * 4;
+    Ext cur = bb::pow(x, (uint64_t)start, wm);
+    size_t end = start + PW_CH < n ? start + PW_CH : n;
+    for (size_t k = start; k < end; k++) {
+        size_t pos = rev_bits ? (size_t)bb::bitrev((uint32_t)k, rev_bits) : k;
+        store_ext(pw + pos * 4, cur);
+        cur = bb::mul(cur, x, wm);
+    }
+}
 // in-place bit reversal of `count` polynomials of `size` extension elements (16-byte items)
 __global__ void bit_reverse_ext_kernel(uint32_t* io, size_t total, size_t size, unsigned bits) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
@@ -398,6 +413,18 @@ int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool
                        x, n, bit_reversed ? log2u(n) : 0u, ctx->sys.wm);
     return post_launch(ctx, "ext_powers_kernel");
 }
+int ext_powers_many(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext* h_pts, size_t n_pts, size_t n, bool bit_reversed) {
+    if (n == 0 || n_pts == 0) return RK_OK;
+    if ((bit_reversed && !is_pow2(n)) || n_pts > 65535) return RK_ERR_INVALID;
+    void* d = nullptr;
+    RK_TRY(scratch(ctx, n_pts * 16, &d));
+    RK_TRY(upload(ctx, d, h_pts, n_pts * 16));
+    size_t lanes = (n + PW_CH - 1) / PW_CH;
+    KTimer kt(ctx, RK_KCLASS_POLY, (double)n * 16 * n_pts);
+    hipLaunchKernelGGL(ext_powers_many_kernel, dim3((unsigned)((lanes + TPB - 1) / TPB), (unsigned)n_pts), dim3(TPB), 0, ctx->stream,
+                       d_pw_ext, (const Ext*)d, n, bit_reversed ? log2u(n) : 0u, ctx->sys.wm);
+    return post_launch(ctx, "ext_powers_many_kernel");
+}
 int bit_reverse_ext(rk_ctx* ctx, uint32_t* d_io_ext, size_t size, size_t count) {
     if (!is_pow2(size) || count == 0) return RK_ERR_INVALID;
     if (size <= 2) return RK_OK;
@@ -463,9 +490,8 @@ int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, 
     std::memcpy(&pack[o_pows], pows.data(), input_size * 16);
     void* d = nullptr;
     RK_TRY(scratch(ctx, words * 4, &d));
-    // the previous user of the scratch area may still be running: pageable H2D on the same stream is ordered
-    RK_HIP_TRY(ctx, hipMemcpyAsync(d, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack is a stack-lifetime host buffer
+    // the previous user of the scratch area may still be running: the copy is ordered behind it on the stream
+    RK_TRY(upload(ctx, d, pack.data(), words * 4));
     const uint32_t* dp = (const uint32_t*)d;
     KTimer kt(ctx, RK_KCLASS_POLY, (double)count * (input_size * 4 + n_slots * 32));
     hipLaunchKernelGGL(mix_kernel, dim3(grid_for(count, 4096), (unsigned)n_slots), dim3(TPB), 0, ctx->stream, d_out_ext,
@@ -474,7 +500,7 @@ int mix_poly_coeffs(rk_ctx* ctx, uint32_t* d_out_ext, const bb::Ext& mix_start, 
 }
 
 int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size_t* h_offsets, const bb::Ext* h_z,
-                     size_t n_items, bb::Ext* h_rems) {
+                     size_t n_items, bb::Ext* h_rems, uint32_t* d_rems) {
     if (count == 0 || n_items == 0 || n_items > 65535) return RK_ERR_INVALID;
     size_t nchunks = (count + DIV_CH - 1) / DIV_CH;
     if (nchunks > (size_t)DIV_NT * 4096) return RK_ERR_INVALID;
@@ -495,13 +521,9 @@ int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size
     uint32_t* rem = carry + n_items * nchunks * 4;
     int st = RK_OK;
     do {
-        hipError_t e = hipMemcpyAsync(d_items, items.data(), n_items * sizeof(DivItem), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `items` is a local
-        if (e != hipSuccess) {
-            ctx->last_error = std::string("poly_divide h2d: ") + hipGetErrorString(e);
-            st = RK_ERR_HIP;
-            break;
-        }
+        hipError_t e = hipSuccess;
+        st = upload(ctx, d_items, items.data(), n_items * sizeof(DivItem));
+        if (st != RK_OK) break;
         unsigned blocks = (unsigned)((nchunks + TPB - 1) / TPB);
         KTimer kt(ctx, RK_KCLASS_POLY, (double)count * 48 * n_items);
         hipLaunchKernelGGL(div_tops_kernel, dim3(blocks, (unsigned)n_items), dim3(TPB), 0, ctx->stream, tops, d_base_ext,
@@ -516,7 +538,14 @@ int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size
                            count, nchunks, d_items);
         st = post_launch(ctx, "div_apply_kernel");
         if (st != RK_OK) break;
-        if (h_rems) {
+        if (d_rems) {  // remainders stay on the device: the caller reads several rounds' worth at once
+            e = hipMemcpyAsync(d_rems, rem, n_items * 16, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                ctx->last_error = std::string("poly_divide d2d: ") + hipGetErrorString(e);
+                st = RK_ERR_HIP;
+            }
+        }
+        if (h_rems && st == RK_OK) {
             e = hipMemcpyAsync(h_rems, rem, n_items * 16, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) {
@@ -530,7 +559,7 @@ int poly_divide_many(rk_ctx* ctx, uint32_t* d_base_ext, size_t count, const size
 }
 int poly_divide(rk_ctx* ctx, uint32_t* d_poly_ext, size_t count, const bb::Ext& z, bb::Ext* h_rem) {
     size_t off = 0;
-    return poly_divide_many(ctx, d_poly_ext, count, &off, &z, 1, h_rem);
+    return poly_divide_many(ctx, d_poly_ext, count, &off, &z, 1, h_rem, nullptr);
 }
 
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n) {
@@ -541,8 +570,7 @@ int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ex
     std::memcpy(&pack[o_delta], h_delta, n * 16);
     void* d = nullptr;
     RK_TRY(scratch(ctx, pack.size() * 4, &d));
-    RK_HIP_TRY(ctx, hipMemcpyAsync(d, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RK_TRY(upload(ctx, d, pack.data(), pack.size() * 4));
     const uint32_t* dp = (const uint32_t*)d;
     hipLaunchKernelGGL(ext_sub_at_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_ext, dp,
                        dp + o_delta, n);

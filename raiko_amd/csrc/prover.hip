@@ -109,39 +109,63 @@ struct MerkleDev {
     size_t path_len() const { return layers - top_layer; }
 };
 
-// Openings of one tree at n query positions, fetched with two gathers and one D2H each.
+// Openings of several trees at n query positions each: one upload of every index, two gathers per tree, one
+// download of everything (a proof opens 4 + FRI-round trees: one host round trip instead of two per tree).
 struct Openings {
     std::vector<uint32_t> rows;   // n x cols
     std::vector<uint32_t> paths;  // n x path_len x 8
 };
-int open_many(rk_ctx* ctx, const MerkleDev& m, const std::vector<uint32_t>& pos, Openings& out) {
-    size_t n = pos.size(), pl = m.path_len();
-    std::vector<uint32_t> node_idx(n * pl);
-    for (size_t q = 0; q < n; q++) {
-        size_t idx = pos[q] + m.rows, j = 0;
-        while (idx >= 2 * m.top_size) {
-            size_t low = idx & 1;
-            idx >>= 1;
-            node_idx[q * pl + j++] = (uint32_t)(2 * idx + (1 - low));
-        }
+struct OpenJob {
+    const MerkleDev* m;
+    std::vector<uint32_t> pos;
+    Openings* out;
+};
+int open_many(rk_ctx* ctx, std::vector<OpenJob>& jobs) {
+    size_t idx_words = 0, out_words = 0;
+    for (const OpenJob& j : jobs) {
+        const size_t n = j.pos.size(), pl = j.m->path_len();
+        idx_words += n + n * pl;
+        out_words += n * j.m->cols + n * pl * p2::OUT;
     }
-    DevBuf d_idx, d_rows, d_paths;
-    RK_TRY(d_idx.alloc(ctx, (n + n * pl) * 4));
-    RK_TRY(d_rows.alloc(ctx, n * m.cols * 4));
-    RK_TRY(d_paths.alloc(ctx, n * pl * p2::OUT * 4 + 16));
-    RK_HIP_TRY(ctx, hipMemcpyAsync(d_idx.u32(), pos.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (pl)
-        RK_HIP_TRY(ctx, hipMemcpyAsync(d_idx.u32() + n, node_idx.data(), n * pl * 4, hipMemcpyHostToDevice, ctx->stream));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors are about to go out of scope
-    RK_TRY(rk::gather_rows(ctx, d_rows.u32(), m.matrix, m.rows, m.cols, d_idx.u32(), n));
-    RK_TRY(rk::gather_digests(ctx, d_paths.u32(), m.nodes.u32(), d_idx.u32() + n, n * pl));
-    out.rows.resize(n * m.cols);
-    out.paths.resize(n * pl * p2::OUT);
-    RK_HIP_TRY(ctx, hipMemcpyAsync(out.rows.data(), d_rows.u32(), n * m.cols * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (pl)
-        RK_HIP_TRY(ctx, hipMemcpyAsync(out.paths.data(), d_paths.u32(), n * pl * p2::OUT * 4, hipMemcpyDeviceToHost,
-                                       ctx->stream));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_words == 0) return RK_OK;
+    std::vector<uint32_t> h_idx(idx_words), h_out(out_words);
+    size_t at = 0;
+    for (const OpenJob& j : jobs) {
+        const MerkleDev& m = *j.m;
+        const size_t n = j.pos.size(), pl = m.path_len();
+        std::copy(j.pos.begin(), j.pos.end(), h_idx.begin() + at);
+        uint32_t* node_idx = h_idx.data() + at + n;
+        for (size_t q = 0; q < n; q++) {
+            size_t idx = j.pos[q] + m.rows, k = 0;
+            while (idx >= 2 * m.top_size) {
+                size_t low = idx & 1;
+                idx >>= 1;
+                node_idx[q * pl + k++] = (uint32_t)(2 * idx + (1 - low));
+            }
+        }
+        at += n + n * pl;
+    }
+    DevBuf d_idx, d_out;
+    RK_TRY(d_idx.alloc(ctx, idx_words * 4));
+    RK_TRY(d_out.alloc(ctx, out_words * 4 + 16));
+    RK_HIP_TRY(ctx, hipMemcpyAsync(d_idx.u32(), h_idx.data(), idx_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    size_t ia = 0, oa = 0;
+    for (const OpenJob& j : jobs) {
+        const MerkleDev& m = *j.m;
+        const size_t n = j.pos.size(), pl = m.path_len();
+        if (n && m.cols) RK_TRY(rk::gather_rows(ctx, d_out.u32() + oa, m.matrix, m.rows, m.cols, d_idx.u32() + ia, n));
+        if (n * pl) RK_TRY(rk::gather_digests(ctx, d_out.u32() + oa + n * m.cols, m.nodes.u32(), d_idx.u32() + ia + n, n * pl));
+        ia += n + n * pl;
+        oa += n * m.cols + n * pl * p2::OUT;
+    }
+    RK_TRY(d2h_sync(ctx, h_out.data(), d_out.u32(), out_words * 4));  // h_idx outlives its upload: this is the first wait
+    oa = 0;
+    for (OpenJob& j : jobs) {
+        const size_t n = j.pos.size(), pl = j.m->path_len(), rw = n * j.m->cols, pw = n * pl * p2::OUT;
+        j.out->rows.assign(h_out.begin() + oa, h_out.begin() + oa + rw);
+        j.out->paths.assign(h_out.begin() + oa + rw, h_out.begin() + oa + rw + pw);
+        oa += rw + pw;
+    }
     return RK_OK;
 }
 void write_opening(Transcript& iop, const MerkleDev& m, const Openings& o, size_t q) {
@@ -440,30 +464,15 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     {
         DevBuf d_pw, d_small;
         RK_TRY(d_pw.alloc(ctx, n_pts * N * 16));
-        for (size_t j = 0; j < n_pts; j++) RK_TRY(rk::ext_powers(ctx, d_pw.u32() + j * N * 4, pts[j], N, true));
-        size_t max_evals = tot_taps > CHECK_SIZE ? tot_taps : CHECK_SIZE;
-        RK_TRY(d_small.alloc(ctx, max_evals * (4 + 4 + 16) + 32));
+        RK_TRY(rk::ext_powers_many(ctx, d_pw.u32(), pts.data(), n_pts, N, true));
+        // every evaluation of the four groups is queued before the one download: which polynomial / which power
+        // table per evaluation depend on the tap set only
         std::vector<Ext> eval_u(tot_taps + CHECK_SIZE);
         std::vector<uint32_t> which, sel;
+        std::vector<size_t> first(5, 0);
         size_t pos = 0;
         uint32_t reg = 0;
-        auto run_evals = [&](const PolyGroup& pg, size_t out_pos) -> int {
-            size_t n = which.size();
-            if (n == 0) return RK_OK;
-            uint32_t* d_which = d_small.u32();
-            uint32_t* d_sel = d_which + n;
-            uint32_t* d_out = d_sel + n;
-            if (((uintptr_t)d_out & 15) != 0) d_out += (16 - ((uintptr_t)d_out & 15)) / 4;
-            RK_HIP_TRY(ctx, hipMemcpyAsync(d_which, which.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-            RK_HIP_TRY(ctx, hipMemcpyAsync(d_sel, sel.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-            RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            RK_TRY(rk::eval_dot(ctx, d_out, pg.coeffs.u32(), N, d_which, d_pw.u32(), d_sel, n));
-            return d2h_sync(ctx, &eval_u[out_pos], d_out, n * 16);
-        };
         for (uint32_t gid = 0; gid < 3; gid++) {
-            which.clear();
-            sel.clear();
-            size_t start = pos;
             for (; reg < taps.n_regs && taps.reg_group[reg] == gid; reg++) {
                 uint32_t cb = taps.reg_combo[reg];
                 for (uint32_t b = taps.combo_off[cb]; b < taps.combo_off[cb + 1]; b++) {
@@ -472,8 +481,27 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
                     all_xs[pos++] = pts[taps.combo_backs[b]];
                 }
             }
-            RK_TRY(run_evals(groups[gid], start));
+            first[gid + 1] = pos;
         }
+        for (uint32_t i = 0; i < CHECK_SIZE; i++) {
+            which.push_back(i);
+            sel.push_back(max_back + 1);
+        }
+        first[4] = pos + CHECK_SIZE;
+        const size_t n_ev = first[4];
+        RK_TRY(d_small.alloc(ctx, n_ev * (4 + 4 + 16) + 32));
+        uint32_t* d_which = d_small.u32();
+        uint32_t* d_sel = d_which + n_ev;
+        uint32_t* d_out = d_sel + n_ev;
+        if (((uintptr_t)d_out & 15) != 0) d_out += (16 - ((uintptr_t)d_out & 15)) / 4;
+        RK_TRY(rk::upload(ctx, d_which, which.data(), n_ev * 4));
+        RK_TRY(rk::upload(ctx, d_sel, sel.data(), n_ev * 4));
+        for (uint32_t gid = 0; gid < 4; gid++) {
+            const PolyGroup& pg = gid < 3 ? groups[gid] : check;
+            const size_t a = first[gid], n = first[gid + 1] - a;
+            if (n) RK_TRY(rk::eval_dot(ctx, d_out + a * 4, pg.coeffs.u32(), N, d_which + a, d_pw.u32(), d_sel + a, n));
+        }
+        RK_TRY(d2h_sync(ctx, eval_u.data(), d_out, n_ev * 16));
         // registers -> coefficients of their interpolating polynomials
         size_t p = 0;
         for (uint32_t r = 0; r < taps.n_regs; r++) {
@@ -482,13 +510,6 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
             poly_interpolate(&coeff_u[p], &all_xs[p], &eval_u[p], sz, wm);
             p += sz;
         }
-        which.clear();
-        sel.clear();
-        for (uint32_t i = 0; i < CHECK_SIZE; i++) {
-            which.push_back(i);
-            sel.push_back(max_back + 1);
-        }
-        RK_TRY(run_evals(check, tot_taps));
         for (uint32_t i = 0; i < CHECK_SIZE; i++) coeff_u[tot_taps + i] = eval_u[tot_taps + i];
     }
     iop.write((const uint32_t*)coeff_u.data(), coeff_u.size() * 4);
@@ -550,6 +571,9 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         // (x - z^4): round j handles the j-th back of every combo that has one, in one batch
         size_t max_sz = 1;
         for (size_t c = 0; c < combo_count; c++) max_sz = std::max<size_t>(max_sz, taps.combo_off[c + 1] - taps.combo_off[c]);
+        DevBuf d_rems;  // every round's remainders, read once after the last round
+        RK_TRY(d_rems.alloc(ctx, max_sz * (combo_count + 1) * 16));
+        size_t n_rems = 0;
         for (size_t j = 0; j < max_sz; j++) {
             std::vector<size_t> offs;
             std::vector<Ext> zs;
@@ -564,11 +588,14 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
                 offs.push_back(combo_count * N);
                 zs.push_back(z_pow);
             }
-            std::vector<Ext> rems(offs.size());
-            RK_TRY(rk::poly_divide_many(ctx, combos.u32(), N, offs.data(), zs.data(), offs.size(), rems.data()));
-            for (const Ext& rem : rems)
-                if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+            RK_TRY(rk::poly_divide_many(ctx, combos.u32(), N, offs.data(), zs.data(), offs.size(), nullptr,
+                                        d_rems.u32() + n_rems * 4));
+            n_rems += offs.size();
         }
+        std::vector<Ext> rems(n_rems);
+        RK_TRY(d2h_sync(ctx, rems.data(), d_rems.p, n_rems * 16));
+        for (const Ext& rem : rems)
+            if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
     }
     DevBuf final_poly;
     RK_TRY(final_poly.alloc(ctx, N * 16));
@@ -633,15 +660,17 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     std::vector<uint32_t> pos0(QUERIES);
     for (size_t q = 0; q < QUERIES; q++) pos0[q] = iop.random_bits(log2u(orig_domain)) % (uint32_t)orig_domain;
     Openings og[3], ocheck;
-    for (int g = 0; g < 3; g++) RK_TRY(open_many(ctx, groups[g].merkle, pos0, og[g]));
-    RK_TRY(open_many(ctx, check.merkle, pos0, ocheck));
     std::vector<Openings> oround(rounds.size());
     {
+        std::vector<OpenJob> jobs;
+        for (int g = 0; g < 3; g++) jobs.push_back(OpenJob{&groups[g].merkle, pos0, &og[g]});
+        jobs.push_back(OpenJob{&check.merkle, pos0, &ocheck});
         std::vector<uint32_t> pos = pos0;
         for (size_t k = 0; k < rounds.size(); k++) {
             for (size_t q = 0; q < QUERIES; q++) pos[q] %= (uint32_t)(rounds[k]->domain / FRI_FOLD);
-            RK_TRY(open_many(ctx, rounds[k]->merkle, pos, oround[k]));
+            jobs.push_back(OpenJob{&rounds[k]->merkle, pos, &oround[k]});
         }
+        RK_TRY(open_many(ctx, jobs));
     }
     for (size_t q = 0; q < QUERIES; q++) {
         for (int g = 0; g < 3; g++) write_opening(iop, groups[g].merkle, og[g], q);
