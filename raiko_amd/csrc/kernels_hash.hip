@@ -333,15 +333,20 @@ int pow_grind(rk_ctx* ctx, const uint32_t* h_cells, unsigned bits, uint32_t* non
     return RK_ERR_INTERNAL;
 }
 
-// every level from the one with `top_output_size` parents up to the root, cell-parallel: launches of up to five
-// levels, the last one of up to six (one workgroup)
+// every level from the one with `top_output_size` parents up to the root, cell-parallel, a few levels per launch
 int hash_fold_top(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
     if (!is_pow2(top_output_size) || top_output_size > CELLS_MAX_OUT) return RK_ERR_INVALID;
     unsigned remaining = 1;  // levels left, the root's included
     for (size_t n = top_output_size; n > 1; n >>= 1) remaining++;
     unsigned first_out = (unsigned)top_output_size;
     while (remaining) {
-        const unsigned m = remaining <= CELLS_MAX_LEVELS ? remaining : std::min(remaining - CELLS_MAX_LEVELS, CELLS_MAX_LEVELS - 1);
+        // the last launch is one workgroup: four levels keep it at one wave per SIMD (eight parents first); the
+        // launches below it take up to five levels each, split evenly
+        unsigned m = std::min(remaining, 4u);
+        if (remaining > 4) {
+            const unsigned rest = remaining - 4, k = (rest + 4) / 5;
+            m = (rest + k - 1) / k;
+        }
         const unsigned blocks = (2 * first_out) >> m;
         const unsigned threads = std::max(64u, std::min(1024u, 32u << (m - 1)));
         KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)blocks * ((1u << m) - 1) * 96);

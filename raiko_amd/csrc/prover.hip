@@ -297,12 +297,14 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     uint32_t digest[8];
     ctx->timing = rk_timing{};
     StageClock sw(ctx);
+    std::vector<Ext> rems;  // filled by a download that is only waited for later: must outlive `finish_on_exit`
     sw.start("segment");
     const size_t total_bracket = sw.used.size() - 1;
     struct Finish {  // also on the error returns
         StageClock& c;
         bool ranged;
         ~Finish() {
+            (void)hipStreamSynchronize(c.ctx->stream);  // nothing of this proof is in flight once it returns
             c.resolve();
             if (ranged) rk::trace_pop();
         }
@@ -538,6 +540,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         // inputs were bit-reversed, so are the mixed polynomials: natural order for the division
         RK_TRY(rk::bit_reverse_ext(ctx, combos.u32(), N, combo_count + 1));
     }
+    DevBuf d_rems;
     {
         // combos[size*combo + i] -= cur * coeff_u[...]: accumulate per touched coefficient on the host
         std::vector<Ext> delta((combo_count + 1) * (max_back + 2), bb::ext_zero());
@@ -571,7 +574,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         // (x - z^4): round j handles the j-th back of every combo that has one, in one batch
         size_t max_sz = 1;
         for (size_t c = 0; c < combo_count; c++) max_sz = std::max<size_t>(max_sz, taps.combo_off[c + 1] - taps.combo_off[c]);
-        DevBuf d_rems;  // every round's remainders, read once after the last round
+        // every round's remainders, read with the next download the transcript needs anyway (FRI's last polynomial)
         RK_TRY(d_rems.alloc(ctx, max_sz * (combo_count + 1) * 16));
         size_t n_rems = 0;
         for (size_t j = 0; j < max_sz; j++) {
@@ -592,10 +595,8 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
                                         d_rems.u32() + n_rems * 4));
             n_rems += offs.size();
         }
-        std::vector<Ext> rems(n_rems);
-        RK_TRY(d2h_sync(ctx, rems.data(), d_rems.p, n_rems * 16));
-        for (const Ext& rem : rems)
-            if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
+        rems.resize(n_rems);
+        RK_HIP_TRY(ctx, hipMemcpyAsync(rems.data(), d_rems.p, n_rems * 16, hipMemcpyDeviceToHost, ctx->stream));
     }
     DevBuf final_poly;
     RK_TRY(final_poly.alloc(ctx, N * 16));
@@ -639,6 +640,8 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
         RK_TRY(rk::bit_reverse(ctx, fin.u32(), cur_words / 4, 4));
         std::vector<uint32_t> h(cur_words);
         RK_TRY(d2h_sync(ctx, h.data(), fin.p, cur_words * 4));
+        for (const Ext& rem : rems)  // queued after the DEEP divisions: every division was exact
+            if (!bb::eq(rem, bb::ext_zero())) return RK_ERR_INTERNAL;
         iop.write(h.data(), h.size());
         kc.hash_elems(h.data(), h.size(), digest);
         iop.commit(digest);
