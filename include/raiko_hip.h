@@ -184,6 +184,24 @@ int rk_mmcs_open(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, const uint
 int rk_mmcs_verify(const rk_params* params, const uint32_t* heights, const uint32_t* widths, uint32_t n_mats,
                    uint32_t index, const uint32_t* rows, const uint32_t* path, const uint32_t root[8]);
 
+/* ---- Plonky3 two-adic FRI PCS, the data-parallel steps (SP1: provers/sp1/driver/src/lib.rs:48-57 -> sp1-core ->
+ * p3-fri TwoAdicFriPcs::commit / open; RECALLED, the crates are outside the reference tree).  Matrices are
+ * row-major height x width; coset shift, 2-adic generator, extension and blow-up come from rk_set_params. ----
+ * commit: `coset_lde_batch(evals, log_blowup, shift).bit_reverse_rows()`: d_in = evaluations of `width` polynomials
+ * over the subgroup of order `height` (natural order); d_out = (height << blowup_log2) x width, row r = their values
+ * at shift * g^bitrev(r), g generating the larger subgroup.  Feed d_out to rk_mmcs_commit. */
+int rk_pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t height, size_t width);
+/* open: the opened values of one committed matrix at the extension point z (`interpolate_coset` on the LDE's low
+ * coset, i.e. its first lde_height >> blowup_log2 rows): d_out_ext = width extension elements p_c(z). */
+int rk_pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t lde_height, size_t width, const uint32_t z[4]);
+/* open, "reduce rows": for the n_points (<= 8) opening points of one matrix, h_points = n_points x 4 words and
+ * h_opened = n_points x width x 4 words (the values rk_pcs_eval_at returned),
+ *   d_ro_ext[r] += alpha^(alpha_offset + j * width) * (sum_c alpha^c M[r][c] - sum_c alpha^c opened_j[c]) / (x_r - z_j)
+ * over all rows r and points j, x_r = shift * g^bitrev(r).  d_ro_ext (lde_height extension elements, one vector per
+ * matrix height, zeroed by the caller) is what the FRI commit phase folds with rk_fri_fold_evals. */
+int rk_pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,
+                           const uint32_t* h_points, const uint32_t* h_opened, const uint32_t alpha[4], uint64_t alpha_offset);
+
 /* synthetic division of one extension polynomial (count coefficients, natural order) by (x - z),
  * in place (core/poly.rs poly_divide); the remainder f(z) goes to h_rem (4 words, may be NULL). */
 int rk_poly_divide(rk_ctx* ctx, uint32_t* d_polys_ext, size_t count, const uint32_t z[4], uint32_t* h_rem);

@@ -100,6 +100,12 @@ void or_gather_sample(fp* dst, const fp* src, size_t idx, size_t size, size_t st
 void or_prefix_products(fp4* io, size_t count);              /* io[i] *= io[i-1], sequential */
 void or_scatter(fp* into, const uint32_t* index, size_t n_cycles, const uint32_t* offsets, const fp* values);
 
+/* ---- Plonky3 two-adic FRI PCS, data-parallel steps (or_pcs.c; row-major matrices) ---- */
+void or_pcs_coset_lde_rows(fp* out, const fp* in, size_t h, size_t w);
+void or_pcs_eval_at(fp4* out, const fp* lde, size_t H, size_t w, const uint32_t* z);
+void or_pcs_reduce_openings(fp4* ro, const fp* lde, size_t H, size_t w, size_t n_points, const uint32_t* points,
+                            const uint32_t* ys, const uint32_t* alpha, uint64_t alpha_offset);
+
 /* ---- risc0-zkp core/poly.rs ---- */
 void or_poly_interpolate(fp4* out, const fp4* x, const fp4* fx, size_t n);
 void or_poly_divide(fp4* p, size_t n, const uint32_t* z, uint32_t* remainder);

@@ -163,6 +163,11 @@ int program_eval_check(const rk_program* prog, const rk_circuit_view* view, cons
 int program_poly_ext(const rk_program* prog, uint32_t wm, const uint32_t poly_mix[4], const uint32_t* eval_u_ext, size_t n_taps,
                      const uint32_t* globals, uint32_t n_globals, const uint32_t* mix, uint32_t n_mix, uint32_t out_ext[4]);
 // d_ext[idx[i]] -= delta[i]
+// Plonky3 two-adic PCS steps on row-major matrices (kernels_pcs.hip)
+int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t h, size_t w);
+int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const bb::Ext& z);
+int pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t H, size_t w, size_t n_points,
+                        const uint32_t* h_points, const uint32_t* h_ys, const bb::Ext& alpha, uint64_t alpha_offset);
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n);
 
 }  // namespace rk

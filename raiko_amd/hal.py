@@ -193,6 +193,26 @@ class HipHal:
         b = np.ascontiguousarray(beta, dtype=np.uint32)
         self._ck(self._lib.rk_fri_fold_evals(self._ctx, _ptr(out), _ptr(inp), n_out, _u32p(b)))
 
+    # ---- Plonky3 two-adic FRI PCS steps on row-major matrices (SP1's prover: provers/sp1/driver/src/lib.rs:48-57) ----
+    def pcs_coset_lde_rows(self, out, inp, height: int, width: int):
+        """TwoAdicFriPcs::commit for one matrix: coset LDE (blow-up / shift of the parameter set), bit-reversed rows"""
+        self._ck(self._lib.rk_pcs_coset_lde_rows(self._ctx, _ptr(out), _ptr(inp), height, width))
+
+    def pcs_eval_at(self, lde, lde_height: int, width: int, z) -> np.ndarray:
+        """the opened values p_c(z) of one committed matrix: (width, 4) words"""
+        zz = np.ascontiguousarray(z, dtype=np.uint32)
+        out = self.alloc_elem(width * 4)
+        self._ck(self._lib.rk_pcs_eval_at(self._ctx, _ptr(out), _ptr(lde), lde_height, width, _u32p(zz)))
+        return out.to_host().reshape(width, 4)
+
+    def pcs_reduce_openings(self, ro, lde, lde_height: int, width: int, points, opened, alpha, alpha_offset: int = 0):
+        """ro[r] += alpha^(offset + j width) (sum_c alpha^c M[r][c] - sum_c alpha^c opened_j[c]) / (x_r - z_j), all j"""
+        pts = np.ascontiguousarray(points, dtype=np.uint32).reshape(-1, 4)
+        ys = np.ascontiguousarray(opened, dtype=np.uint32).reshape(pts.shape[0], width, 4)
+        a = np.ascontiguousarray(alpha, dtype=np.uint32)
+        self._ck(self._lib.rk_pcs_reduce_openings(self._ctx, _ptr(ro), _ptr(lde), lde_height, width, pts.shape[0], _u32p(pts),
+                                                  _u32p(ys), _u32p(a), alpha_offset))
+
     def gather_sample(self, dst, src, idx: int, size: int, stride: int):
         self._ck(self._lib.rk_gather_sample(self._ctx, _ptr(dst), _ptr(src), idx, size, stride))
 

@@ -1,0 +1,109 @@
+"""Plonky3 two-adic PCS steps on the GPU (rk_pcs_*) against the oracle (oracle/or_pcs.c, itself pinned by big-integer
+algebra in tests/test_pcs.py), under risc0's and SP1's parameter sets, plus the commit -> open -> fold chain at a
+size the oracle does not reach: a reduced opening folded down with rk_fri_fold_evals is constant."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from raiko_amd import hal as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def cfg():
+    h = H.HipHal(0)
+
+    def apply(preset):
+        o.oracle_set_params(preset)
+        h.set_params(preset=preset)
+        return h.get_params()
+
+    yield h, apply
+    o.oracle_set_params()
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("k,w", [(2, 1), (3, 3), (6, 40), (10, 70), (13, 16), (15, 5)])
+def test_coset_lde_rows(cfg, preset, k, w):
+    h, apply = cfg
+    blow = int(apply(preset).blowup_log2)
+    orc = o.oracle()
+    rng = np.random.default_rng(100 * preset + k)
+    n = 1 << k
+    ev = o.rand_elems(rng, (n, w))
+    want = np.zeros((n << blow, w), dtype=np.uint32)
+    orc.or_pcs_coset_lde_rows(o.ptr(want), o.ptr(ev), n, w)
+    out = h.alloc_elem((n << blow) * w)
+    h.pcs_coset_lde_rows(out, h.copy_from_elem(ev), n, w)
+    assert np.array_equal(out.to_host().reshape(n << blow, w), want)
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("k,w,npts", [(2, 1, 1), (5, 3, 2), (9, 70, 2), (12, 130, 3), (14, 8, 8)])
+def test_eval_at_and_reduce_openings(cfg, preset, k, w, npts):
+    h, apply = cfg
+    blow = int(apply(preset).blowup_log2)
+    orc = o.oracle()
+    rng = np.random.default_rng(200 * preset + k)
+    n = 1 << k
+    Hh = n << blow
+    lde = np.zeros((Hh, w), dtype=np.uint32)
+    orc.or_pcs_coset_lde_rows(o.ptr(lde), o.ptr(o.rand_elems(rng, (n, w))), n, w)
+    d_lde = h.copy_from_elem(lde)
+    zs = o.rand_elems(rng, (npts, 4))
+    alpha = o.rand_elems(rng, (4,))
+    ys = np.zeros((npts, w, 4), dtype=np.uint32)
+    for j in range(npts):
+        orc.or_pcs_eval_at(o.ptr(ys[j]), o.ptr(lde), Hh, w, o.ptr(zs[j]))
+        assert np.array_equal(h.pcs_eval_at(d_lde, Hh, w, zs[j]), ys[j])
+    ro0 = o.rand_elems(rng, (Hh, 4))
+    want = ro0.copy()
+    orc.or_pcs_reduce_openings(o.ptr(want), o.ptr(lde), Hh, w, npts, o.ptr(zs), o.ptr(ys), o.ptr(alpha), 11)
+    d_ro = h.copy_from_elem(ro0)
+    h.pcs_reduce_openings(d_ro, d_lde, Hh, w, zs, ys, alpha, 11)
+    assert np.array_equal(d_ro.to_host().reshape(Hh, 4), want)
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_commit_open_fold_chain_is_low_degree(cfg, preset):
+    """two matrices of one height opened at zeta and zeta * g, 2^18 rows: the reduced opening folds to a constant;
+    with one opened value off by one it does not"""
+    h, apply = cfg
+    par = apply(preset)
+    blow = int(par.blowup_log2)
+    rng = np.random.default_rng(31)
+    k = 18
+    n, Hh = 1 << k, (1 << k) << blow
+    widths = [24, 7]
+    ldes = []
+    for w in widths:
+        d = h.alloc_elem(Hh * w)
+        h.pcs_coset_lde_rows(d, h.copy_from_elem(o.rand_elems(rng, (n, w))), n, w)
+        ldes.append(d)
+    zeta = o.rand_elems(rng, (4,))
+    g = o.oracle().or_rou_fwd(k)
+    zeta_g = np.array([o.oracle().or_fp_mul(int(v), g) for v in zeta], dtype=np.uint32)
+    pts = np.stack([zeta, zeta_g])
+    alpha = o.rand_elems(rng, (4,))
+
+    def folded(tamper):
+        ro = h.copy_from_elem(np.zeros((Hh, 4), dtype=np.uint32))
+        off = 0
+        for d, w in zip(ldes, widths):
+            ys = np.stack([h.pcs_eval_at(d, Hh, w, z) for z in pts])
+            if tamper and w == 7:
+                ys[1, 2, 0] = (int(ys[1, 2, 0]) + 1) % o.P
+            h.pcs_reduce_openings(ro, d, Hh, w, pts, ys, alpha, off)
+            off += 2 * w
+        cur, size = ro, Hh
+        while size > (1 << blow):
+            nxt = h.alloc_elem(size // 2 * 4)
+            h.fri_fold_evals(nxt, cur, size // 2, o.rand_elems(rng, (4,)))
+            cur, size = nxt, size // 2
+        return cur.to_host().reshape(size, 4)
+
+    good = folded(False)
+    assert good.any() and (good == good[0]).all()
+    bad = folded(True)
+    assert not (bad == bad[0]).all()
