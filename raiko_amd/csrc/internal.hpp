@@ -138,6 +138,15 @@ int gather_rows(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_matrix, size_t r
                 const uint32_t* d_idx, size_t n_idx);
 // digests: d_dst[i] = d_nodes[d_idx[i]]
 int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const uint32_t* d_idx, size_t n_idx);
+// openings of several trees in two launches: job k gathers rows idx[idx_off .. +n) of its column-major matrix to
+// dst[dst_off ..) (n x cols) and, behind them, the digests idx[idx_off + n .. + n * path_len) of its node heap
+struct GatherJob {
+    const uint32_t* matrix;
+    const uint32_t* nodes;
+    uint64_t rows, cols, idx_off, dst_off;
+    uint32_t n, path_len;
+};
+int gather_many(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_idx, const GatherJob* d_jobs, const GatherJob* h_jobs, size_t n_jobs);
 int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool bit_reversed);
 // n_pts tables of n powers each, one launch: table j (at d_pw_ext + j * n * 4) holds h_pts[j]^k
 int ext_powers_many(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext* h_pts, size_t n_pts, size_t n, bool bit_reversed);

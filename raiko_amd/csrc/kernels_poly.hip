@@ -96,6 +96,22 @@ __global__ void gather_digests_kernel(uint32_t* dst, const uint32_t* nodes, cons
     dst[i] = nodes[(size_t)idx[i >> 3] * 8 + (i & 7)];
 }
 
+// the two gathers for every tree of a proof in one launch each: blockIdx.z = job
+__global__ void gather_rows_many_kernel(uint32_t* dst, const uint32_t* idx, const rk::GatherJob* jobs) {
+    const rk::GatherJob j = jobs[blockIdx.z];
+    const size_t q = blockIdx.y;
+    if (q >= j.n) return;
+    const size_t r = idx[j.idx_off + q];
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < j.cols; c += (size_t)gridDim.x * blockDim.x)
+        dst[j.dst_off + q * j.cols + c] = j.matrix[c * j.rows + r];
+}
+__global__ void gather_digests_many_kernel(uint32_t* dst, const uint32_t* idx, const rk::GatherJob* jobs) {
+    const rk::GatherJob j = jobs[blockIdx.z];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.n * j.path_len * 8) return;
+    dst[j.dst_off + j.n * j.cols + i] = j.nodes[(size_t)idx[j.idx_off + j.n + (i >> 3)] * 8 + (i & 7)];
+}
+
 // pw[k] = x^k: each lane seeds x^(lane_start) by square-and-multiply, then walks CH powers
 constexpr int PW_CH = 32;
 // rev_bits != 0: x^k is stored at position bitrev(k), matching bit-reversed coefficient storage
@@ -403,6 +419,27 @@ int gather_digests(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_nodes, const 
     hipLaunchKernelGGL(gather_digests_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_dst,
                        d_nodes, d_idx, n_idx);
     return post_launch(ctx, "gather_digests_kernel");
+}
+int gather_many(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_idx, const GatherJob* d_jobs, const GatherJob* h_jobs, size_t n_jobs) {
+    if (n_jobs == 0) return RK_OK;
+    size_t max_n = 0, max_cols = 0, max_dig = 0;
+    for (size_t k = 0; k < n_jobs; k++) {
+        max_n = std::max<size_t>(max_n, h_jobs[k].n);
+        max_cols = std::max<size_t>(max_cols, h_jobs[k].cols);
+        max_dig = std::max<size_t>(max_dig, (size_t)h_jobs[k].n * h_jobs[k].path_len * 8);
+    }
+    if (max_n > 65535 || n_jobs > 65535) return RK_ERR_INVALID;
+    if (max_n && max_cols) {
+        hipLaunchKernelGGL(gather_rows_many_kernel, dim3(grid_for(max_cols, 64), (unsigned)max_n, (unsigned)n_jobs), dim3(TPB), 0,
+                           ctx->stream, d_dst, d_idx, d_jobs);
+        RK_TRY(post_launch(ctx, "gather_rows_many_kernel"));
+    }
+    if (max_dig) {
+        hipLaunchKernelGGL(gather_digests_many_kernel, dim3((unsigned)((max_dig + TPB - 1) / TPB), 1, (unsigned)n_jobs), dim3(TPB), 0,
+                           ctx->stream, d_dst, d_idx, d_jobs);
+        RK_TRY(post_launch(ctx, "gather_digests_many_kernel"));
+    }
+    return RK_OK;
 }
 int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool bit_reversed) {
     if (n == 0) return RK_OK;

@@ -145,20 +145,26 @@ int open_many(rk_ctx* ctx, std::vector<OpenJob>& jobs) {
         }
         at += n + n * pl;
     }
-    DevBuf d_idx, d_out;
-    RK_TRY(d_idx.alloc(ctx, idx_words * 4));
-    RK_TRY(d_out.alloc(ctx, out_words * 4 + 16));
-    RK_HIP_TRY(ctx, hipMemcpyAsync(d_idx.u32(), h_idx.data(), idx_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    // [indices | job table]: one upload
+    const size_t jobs_at = (idx_words + 3) & ~(size_t)3;
+    std::vector<uint32_t> pack(jobs_at + jobs.size() * (sizeof(rk::GatherJob) / 4));
+    std::copy(h_idx.begin(), h_idx.end(), pack.begin());
+    std::vector<rk::GatherJob> h_jobs(jobs.size());
     size_t ia = 0, oa = 0;
-    for (const OpenJob& j : jobs) {
-        const MerkleDev& m = *j.m;
-        const size_t n = j.pos.size(), pl = m.path_len();
-        if (n && m.cols) RK_TRY(rk::gather_rows(ctx, d_out.u32() + oa, m.matrix, m.rows, m.cols, d_idx.u32() + ia, n));
-        if (n * pl) RK_TRY(rk::gather_digests(ctx, d_out.u32() + oa + n * m.cols, m.nodes.u32(), d_idx.u32() + ia + n, n * pl));
+    for (size_t k = 0; k < jobs.size(); k++) {
+        const MerkleDev& m = *jobs[k].m;
+        const size_t n = jobs[k].pos.size(), pl = m.path_len();
+        h_jobs[k] = rk::GatherJob{m.matrix, m.nodes.u32(), m.rows, m.cols, ia, oa, (uint32_t)n, (uint32_t)pl};
         ia += n + n * pl;
         oa += n * m.cols + n * pl * p2::OUT;
     }
-    RK_TRY(d2h_sync(ctx, h_out.data(), d_out.u32(), out_words * 4));  // h_idx outlives its upload: this is the first wait
+    std::memcpy(&pack[jobs_at], h_jobs.data(), h_jobs.size() * sizeof(rk::GatherJob));
+    DevBuf d_idx, d_out;
+    RK_TRY(d_idx.alloc(ctx, pack.size() * 4));
+    RK_TRY(d_out.alloc(ctx, out_words * 4 + 16));
+    RK_TRY(rk::upload(ctx, d_idx.p, pack.data(), pack.size() * 4));
+    RK_TRY(rk::gather_many(ctx, d_out.u32(), d_idx.u32(), (const rk::GatherJob*)(d_idx.u32() + jobs_at), h_jobs.data(), jobs.size()));
+    RK_TRY(d2h_sync(ctx, h_out.data(), d_out.u32(), out_words * 4));
     oa = 0;
     for (OpenJob& j : jobs) {
         const size_t n = j.pos.size(), pl = j.m->path_len(), rw = n * j.m->cols, pw = n * pl * p2::OUT;
