@@ -71,40 +71,6 @@ __global__ __launch_bounds__(HASH_BLOCK) void hash_fold_kernel(uint32_t* __restr
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// The last levels of a tree (<= 1024 parents) in one launch: the level lives in LDS between
-// steps, every parent is also written to its heap slot in HBM.  Replaces ~11 latency-bound
-// launches per tree.
-constexpr int TAIL_MAX = 1024;
-template <class C>
-__global__ __launch_bounds__(TAIL_MAX) void hash_fold_tail_kernel(uint32_t* __restrict__ nodes, unsigned top_out,
-                                                                  const typename C::Consts* __restrict__ kc) {
-    __shared__ uint32_t level[2 * TAIL_MAX * p2::OUT];
-    const unsigned tid = threadIdx.x;
-    const typename C::Consts& k = *kc;
-    for (unsigned i = tid; i < 2 * top_out * p2::OUT; i += blockDim.x) level[i] = nodes[(size_t)2 * top_out * p2::OUT + i];
-    __syncthreads();
-    for (unsigned out = top_out; out >= 1; out >>= 1) {
-        uint32_t s[C::CELLS];
-        const bool active = tid < out;
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < 2 * p2::OUT; i++) s[i] = level[2 * tid * p2::OUT + i];
-#pragma unroll
-            for (int i = 2 * p2::OUT; i < C::CELLS; i++) s[i] = 0;
-            C::permute(s, k);
-        }
-        __syncthreads();  // every child has been read before the level is overwritten
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < p2::OUT; i++) {
-                level[tid * p2::OUT + i] = s[i];
-                nodes[(size_t)(out + tid) * p2::OUT + i] = s[i];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ---- cell-parallel permutation: one 32-lane half-wave per permutation, one lane per cell --------------
 // The levels near the root have too few parents to fill the chip, so a lane-per-permutation launch costs the
 // latency of one permutation (~6.7 k dependent instructions, ~15 us) per level whatever its size.  Here the
@@ -195,10 +161,10 @@ struct CellPerm {
 // `levels` (<= CELLS_MAX_LEVELS) levels of a tree in one launch: workgroup b owns the 2^levels nodes
 // [b 2^levels, (b + 1) 2^levels) of the level with 2 first_out nodes and everything above them; a level lives
 // in LDS (ping-pong) between steps and every parent also goes to its heap slot.  blockDim = 32 lanes per
-// parent of the first step, capped at 1024.
-constexpr unsigned CELLS_MAX_LEVELS = 6;
+// parent of the first step (at most 512: a workgroup then has at most two waves per SIMD).
+constexpr unsigned CELLS_MAX_LEVELS = 5;
 template <class C>
-__global__ __launch_bounds__(1024) void hash_fold_cells_kernel(uint32_t* __restrict__ nodes, unsigned first_out, unsigned levels,
+__global__ __launch_bounds__(512) void hash_fold_cells_kernel(uint32_t* __restrict__ nodes, unsigned first_out, unsigned levels,
                                                                const typename C::Consts* __restrict__ kc) {
     __shared__ uint32_t buf[2][(1u << CELLS_MAX_LEVELS) * p2::OUT];
     const typename C::Consts& k = *kc;
@@ -348,7 +314,7 @@ int hash_fold_top(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
             m = (rest + k - 1) / k;
         }
         const unsigned blocks = (2 * first_out) >> m;
-        const unsigned threads = std::max(64u, std::min(1024u, 32u << (m - 1)));
+        const unsigned threads = std::max(64u, 32u << (m - 1));  // m <= CELLS_MAX_LEVELS: at most 512
         KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)blocks * ((1u << m) - 1) * 96);
         RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_fold_cells_kernel<C>, dim3(blocks), dim3(threads), 0, ctx->stream, d_nodes,
                                                first_out, m, (const typename C::Consts*)ctx->d_p2));
@@ -357,15 +323,6 @@ int hash_fold_top(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
         remaining -= m;
     }
     return RK_OK;
-}
-
-int hash_fold_tail(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
-    if (!is_pow2(top_output_size) || top_output_size > TAIL_MAX) return RK_ERR_INVALID;
-    unsigned threads = top_output_size < 64 ? 64u : (unsigned)top_output_size;
-    KTimer kt(ctx, RK_KCLASS_HASH_FOLD, (double)(2 * top_output_size - 1) * 96);
-    RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_fold_tail_kernel<C>, dim3(1), dim3(threads), 0, ctx->stream, d_nodes,
-                                           (unsigned)top_output_size, (const typename C::Consts*)ctx->d_p2));
-    return post_launch(ctx, "hash_fold_tail_kernel");
 }
 
 }  // namespace rk

@@ -107,3 +107,37 @@ def test_commit_open_fold_chain_is_low_degree(cfg, preset):
     assert good.any() and (good == good[0]).all()
     bad = folded(True)
     assert not (bad == bad[0]).all()
+
+
+def test_gpu_matches_committed_digests(cfg):
+    import json, os
+    from pcs_cases import PCS_CASES, pcs_inputs, sha
+    h, apply = cfg
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pcs_digests.json")))
+    for key in PCS_CASES:
+        preset, k, w, npts, ev, zs, alpha, rng = pcs_inputs(key)
+        blow = int(apply(preset).blowup_log2)
+        n, Hh = 1 << k, (1 << k) << blow
+        lde = h.alloc_elem(Hh * w)
+        h.pcs_coset_lde_rows(lde, h.copy_from_elem(ev), n, w)
+        ys = np.stack([h.pcs_eval_at(lde, Hh, w, z) for z in zs])
+        ro = h.copy_from_elem(o.rand_elems(rng, (Hh, 4)))
+        h.pcs_reduce_openings(ro, lde, Hh, w, zs, ys, alpha, 5)
+        got = {"lde": sha(lde.to_host()), "opened": sha(ys), "reduced": sha(ro.to_host())}
+        assert got == gold[key], key
+
+
+def test_invalid_arguments_are_refused(cfg):
+    h, apply = cfg
+    apply(0)
+    buf = h.alloc_elem(4096)
+    z = np.zeros(4, dtype=np.uint32)
+    for bad in (lambda: h.pcs_coset_lde_rows(buf, buf, 3, 4),          # height not a power of two
+                lambda: h.pcs_coset_lde_rows(buf, buf, 8, 0),          # no columns
+                lambda: h.pcs_coset_lde_rows(buf, buf, 1 << 23, 1),    # LDE beyond 2^24 rows under blow-up 4
+                lambda: h.pcs_eval_at(buf, 24, 4, z),                  # LDE height not a power of two
+                lambda: h.pcs_eval_at(buf, 16, 4, np.full(4, o.P, dtype=np.uint32)),  # point not reduced
+                lambda: h.pcs_reduce_openings(buf, buf, 16, 4, np.zeros((9, 4), np.uint32), np.zeros((9, 4, 4), np.uint32), z),
+                lambda: h.pcs_reduce_openings(buf, buf, 16, 4, np.zeros((0, 4), np.uint32), np.zeros((0, 4, 4), np.uint32), z)):
+        with pytest.raises(H._lib.RkError):
+            bad()

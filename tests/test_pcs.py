@@ -162,3 +162,12 @@ def test_reduced_opening_folds_to_a_constant(params, preset):
         orc.or_fri_fold_evals(o.ptr(nxt), o.ptr(bad), nxt.shape[0], o.ptr(o.rand_elems(rng, (4,))))
         bad = nxt
     assert not (bad == bad[0]).all()
+
+
+def test_oracle_matches_committed_digests():
+    import json, os
+    from pcs_cases import PCS_CASES, oracle_outputs
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pcs_digests.json")))
+    assert sorted(gold) == sorted(PCS_CASES)
+    for key in PCS_CASES:
+        assert oracle_outputs(key) == gold[key], key
