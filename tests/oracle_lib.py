@@ -202,8 +202,15 @@ def rand_elems(rng, shape):
     return rng.integers(0, P, size=shape, dtype=np.uint32)
 
 
+class _Addr(int):
+    """an address that keeps its array alive: `f(ptr(make_array()))` would otherwise hand C a freed buffer (the
+    temporary dies as soon as ptr() has returned a plain integer)"""
+
+
 def ptr(a: np.ndarray):
-    return a.ctypes.data
+    r = _Addr(a.ctypes.data)
+    r._keep = a
+    return r
 
 
 def make_or_segment(seg):
