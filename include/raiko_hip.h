@@ -478,6 +478,10 @@ int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* le
 #define RK_TRACE_CODE_COLS 2
 #define RK_TRACE_DATA_COLS 16
 int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t* data);
+/* the same columns written on the GPU into device buffers (2 and 16 columns of 2^po2 words), asynchronously on the
+ * ctx stream: only the executed cycles (28 bytes each) cross PCIe; the trace has been copied when the call returns.
+ * Hand the buffers to rk_prove_segment / a session as on_device inputs after rk_sync(ctx). */
+int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data);
 const char* rk_exec_error(const rk_exec* ex);
 int rk_exec_free(rk_exec* ex);
 

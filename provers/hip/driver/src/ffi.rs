@@ -330,6 +330,7 @@ extern "C" {
     pub fn rk_exec_segment_get(ex: *const rk_exec, index: u32, out: *mut rk_exec_segment) -> c_int;
     pub fn rk_exec_journal(ex: *const rk_exec, out: *mut u8, capacity: usize, len: *mut usize) -> c_int;
     pub fn rk_exec_witness(ex: *const rk_exec, index: u32, code: *mut u32, data: *mut u32) -> c_int;
+    pub fn rk_exec_witness_device(ctx: *mut rk_ctx, ex: *const rk_exec, index: u32, d_code: *mut u32, d_data: *mut u32) -> c_int;
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
     pub fn rk_last_timing(ctx: *mut rk_ctx, out: *mut rk_timing) -> c_int;

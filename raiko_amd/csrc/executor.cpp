@@ -402,6 +402,39 @@ int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exe
 
 }  // namespace
 
+// The same columns written by the GPU: one lane per row, the trace rows (28 bytes per cycle) are the only upload --
+// 2.5x less over PCIe than the 18 finished columns and none of the host's time (rk_exec_witness_device).
+__global__ void exec_witness_kernel(uint32_t* __restrict__ code, uint32_t* __restrict__ data, const TraceRow* __restrict__ tr,
+                                    size_t cycles, size_t n, uint32_t end_pc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool active = i < cycles;
+    TraceRow r{};
+    if (active) r = tr[i];
+    else r.pc = r.next = end_pc;
+    const uint32_t lo = r.pc & 0xffffu, carry = (active && lo + 4 > 0xffffu) ? 1u : 0u;
+    const uint32_t seq = (active && r.next == r.pc + 4 && r.pc <= 0xfffffffbu) ? 1u : 0u;
+    auto put = [&](uint32_t* base, unsigned col, uint32_t canon) { base[(size_t)col * n + i] = bb::mul(canon, bb::R2); };
+    put(code, 0, i == 0 ? 1u : 0u);
+    put(code, 1, i + 1 == n ? 1u : 0u);
+    put(data, 0, lo);
+    put(data, 1, r.pc >> 16);
+    put(data, 2, r.next & 0xffffu);
+    put(data, 3, r.next >> 16);
+    put(data, 4, r.ins & 0xffffu);
+    put(data, 5, r.ins >> 16);
+    put(data, 6, seq);
+    put(data, 7, seq ? carry : 0u);
+    put(data, 8, r.a & 0xffffu);
+    put(data, 9, r.a >> 16);
+    put(data, 10, r.b & 0xffffu);
+    put(data, 11, r.b >> 16);
+    put(data, 12, r.res & 0xffffu);
+    put(data, 13, r.res >> 16);
+    put(data, 14, r.wr);
+    put(data, 15, active ? 1u : 0u);
+}
+
 extern "C" {
 
 int rk_exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* opts, rk_exec** out) {
@@ -482,6 +515,35 @@ int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t*
     fill(0, n / n_threads);
     for (auto& th : pool) th.join();
     return RK_OK;
+    RK_GUARD_END
+}
+int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data) {
+    RK_GUARD_BEGIN
+    if (!ctx || !ex || !d_code || !d_data || index >= ex->segments.size() || index >= ex->traces.size()) return RK_ERR_INVALID;
+    const rk_exec_segment& seg = ex->segments[index];
+    const std::vector<TraceRow>& tr = ex->traces[index];
+    const size_t n = (size_t)1 << seg.po2;
+    if (tr.size() != seg.cycles || tr.size() > n) return RK_ERR_INTERNAL;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* d_tr = nullptr;
+    RK_TRY(rk::dev_alloc(ctx, std::max<size_t>(tr.size(), 1) * sizeof(TraceRow), &d_tr));
+    int st = RK_OK;
+    if (!tr.empty()) {
+        // the trace stays valid while `ex` lives, but the caller may free `ex` right after this call: wait for the copy
+        hipError_t e = hipMemcpyAsync(d_tr, tr.data(), tr.size() * sizeof(TraceRow), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("rk_exec_witness_device h2d: ") + hipGetErrorString(e);
+            st = RK_ERR_HIP;
+        }
+    }
+    if (st == RK_OK) {
+        hipLaunchKernelGGL(exec_witness_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_code, d_data,
+                           (const TraceRow*)d_tr, tr.size(), n, seg.end_pc);
+        st = rk::post_launch(ctx, "exec_witness_kernel");
+    }
+    rk::dev_free(ctx, d_tr);
+    return st;
     RK_GUARD_END
 }
 const char* rk_exec_error(const rk_exec* ex) { return ex ? ex->error.c_str() : ""; }

@@ -124,8 +124,9 @@ class Stepper:
         self.more = True
         self.n = 0
 
-    def next(self):
-        """-> (ExecSegment, code, data) of the next executed segment, or None after the last"""
+    def next(self, hal=None):
+        """-> (ExecSegment, code, data) of the next executed segment, or None after the last.  With `hal` (a HipHal)
+        the witness columns are written on the GPU (rk_exec_witness_device) and code / data are device buffers."""
         if not self.more:
             return None
         more = C.c_int(0)
@@ -137,9 +138,15 @@ class Stepper:
         self._lib.rk_exec_segment_get(self._h, self.n, C.byref(s))
         seg = ExecSegment(s.index, s.po2, int(s.cycles), s.start_pc, s.end_pc, s.exit, tuple(s.pre_state), tuple(s.post_state))
         rows = 1 << seg.po2
-        code = np.zeros((TRACE_CODE_COLS, rows), dtype=np.uint32)
-        data = np.zeros((TRACE_DATA_COLS, rows), dtype=np.uint32)
-        _lib.check(None, self._lib.rk_exec_witness(self._h, self.n, code.ctypes.data_as(_lib.u32p), data.ctypes.data_as(_lib.u32p)))
+        if hal is not None:
+            code = hal.alloc_elem(TRACE_CODE_COLS * rows)
+            data = hal.alloc_elem(TRACE_DATA_COLS * rows)
+            _lib.check(None, self._lib.rk_exec_witness_device(hal._ctx, self._h, self.n, C.c_void_p(code.ptr), C.c_void_p(data.ptr)))
+            hal.sync()   # the session's contexts run on other streams
+        else:
+            code = np.zeros((TRACE_CODE_COLS, rows), dtype=np.uint32)
+            data = np.zeros((TRACE_DATA_COLS, rows), dtype=np.uint32)
+            _lib.check(None, self._lib.rk_exec_witness(self._h, self.n, code.ctypes.data_as(_lib.u32p), data.ctypes.data_as(_lib.u32p)))
         self.n += 1
         return seg, code, data
 
@@ -173,43 +180,59 @@ def trace_segments(ex: Execution, program=None) -> List[Segment]:
         program = Program(*trace_program(taps), taps)
     out = []
     for s, (code, data) in zip(ex.segments, ex.witness):
-        mont = lambda v: (int(v) << 32) % P
-        pcs = [s.start_pc & 0xFFFF, s.start_pc >> 16, s.end_pc & 0xFFFF, s.end_pc >> 16]
-        globals_ = np.array([mont(v) for v in pcs] + list(s.pre_state) + list(s.post_state), dtype=np.uint32)
         accum = np.ascontiguousarray(data[:TRACE_ACCUM_COLS])      # unconstrained in this circuit; no accumulate hook
-        seg = Segment(po2=s.po2, taps=taps, groups=[accum, code, data], check=None, globals_=globals_, n_accum_mix=4,
-                      circuit_info=b"RV32_TRACE:v1___")
-        seg.program = program
-        out.append(seg)
+        out.append(_trace_segment(s, taps, program, [accum, code, data]))
     return out
+
+
+def _trace_segment(s: ExecSegment, taps, program, groups) -> Segment:
+    mont = lambda v: (int(v) << 32) % P
+    pcs = [s.start_pc & 0xFFFF, s.start_pc >> 16, s.end_pc & 0xFFFF, s.end_pc >> 16]
+    globals_ = np.array([mont(v) for v in pcs] + list(s.pre_state) + list(s.post_state), dtype=np.uint32)
+    seg = Segment(po2=s.po2, taps=taps, groups=groups, check=None, globals_=globals_, n_accum_mix=4,
+                  circuit_info=b"RV32_TRACE:v1___")
+    seg.program = program
+    return seg
 
 
 def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20,
                       widths: Tuple[int, int, int] = (16, 16, 224), device: int = 0, inflight: int = 3,
-                      circuit: str = "synthetic", pipeline: bool = False):
+                      circuit: str = "synthetic", pipeline: bool = False, device_witness: bool = True):
     """`prove_locally` end to end (bonsai.rs:230-272): execute, segment, prove every segment through
     rk_prove_session, assemble the receipt around the journal the guest committed.
     circuit = "synthetic": stand-in columns of the executed size (the shape of the S20 workload);
     circuit = "trace": the execution trace as witness under the stand-in trace circuit, every seal's
-    constraint identity verified inside the session.  Returns (Execution, Receipt)."""
+    constraint identity verified inside the session; with `pipeline` the executor steps segment by segment and
+    each segment is proven while the next one executes, its witness columns generated on the GPU unless
+    device_witness is False.  Returns (Execution, Receipt)."""
     from .hal import prove_session
     from .receipt import Receipt, SegmentReceipt
     if circuit == "trace" and pipeline:
-        # segment k is proven (rk_stream_*) while the executor runs segment k + 1
-        from .hal import SessionStream
+        # segment k is proven (rk_stream_*) while the executor runs segment k + 1; the witness columns are written
+        # on the GPU from the executed cycles (rk_exec_witness_device), so the host only runs the machine
+        from .circuit_program import Program, trace_program
+        from .hal import HipHal, SessionStream
+        from .segment import make_tapset
+        taps = make_tapset([[(0,)] * TRACE_ACCUM_COLS, [(0,)] * TRACE_CODE_COLS,
+                            [((0, 1) if c in (2, 3, 15) else (0,)) for c in range(TRACE_DATA_COLS)]])
+        program = Program(*trace_program(taps), taps)
+        wit_hal = HipHal(device) if device_witness else None
         stepper = Stepper(elf, input_words, segment_limit_po2)
         stream, segs, metas = None, [], []
         try:
             while True:
-                item = stepper.next()
+                item = stepper.next(wit_hal)
                 if item is None:
                     break
                 meta, code, data = item
-                one = Execution([meta], b"", 0, 0, 0, [(code, data)])
-                seg = trace_segments(one, program=segs[0].program if segs else None)[0]
                 if stream is None:
-                    stream = SessionStream(device=device, inflight=inflight, program=seg.program)
-                stream.submit(seg)
+                    stream = SessionStream(device=device, inflight=inflight, program=program)
+                if device_witness:
+                    seg = _trace_segment(meta, taps, program, [None, None, None])
+                    stream.submit(seg, device_inputs=([data, code, data], None))   # accum = the first columns of data
+                else:
+                    seg = _trace_segment(meta, taps, program, [np.ascontiguousarray(data[:TRACE_ACCUM_COLS]), code, data])
+                    stream.submit(seg)
                 segs.append(seg)
                 metas.append(meta)
             ex = stepper.finish()

@@ -365,8 +365,9 @@ class SessionStream:
         _lib.check(None, self._lib.rk_stream_open(C.byref(opts), C.byref(h)))
         self._h = h
 
-    def submit(self, seg: Segment):
-        c, k = make_c_segment(seg)
+    def submit(self, seg: Segment, device_inputs=None):
+        """`device_inputs` = (groups[3], check) of device buffers: the segment's columns are already in HBM"""
+        c, k = make_c_segment(seg, device_inputs)
         cap = int(self._lib.rk_seal_bound_words_params(C.byref(c), C.byref(self._params))) if self._params is not None else \
             int(self._lib.rk_seal_bound_words(C.byref(c)))
         if cap == 0:

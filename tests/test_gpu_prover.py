@@ -380,11 +380,26 @@ def test_pipelined_execute_and_prove_matches_the_batch_route():
                                ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + A.li("t0", 0) + [("ecall",)]
     image = A.elf(A.assemble(prog)[0])
     ex_a, rc_a = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace")
-    ex_b, rc_b = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace", pipeline=True)
+    ex_b, rc_b = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace", pipeline=True)   # witness written on the GPU
+    ex_c, rc_c = X.execute_and_prove(image, segment_limit_po2=13, circuit="trace", pipeline=True, device_witness=False)
     assert ex_a.total_cycles == ex_b.total_cycles and ex_a.journal == ex_b.journal and len(rc_b.segments) == 3
-    assert [s.cycles for s in ex_a.segments] == [s.cycles for s in ex_b.segments]
-    for a, b in zip(rc_a.segments, rc_b.segments):
-        assert np.array_equal(a.seal, b.seal)
+    assert [s.cycles for s in ex_a.segments] == [s.cycles for s in ex_b.segments] == [s.cycles for s in ex_c.segments]
+    for a, b, c in zip(rc_a.segments, rc_b.segments, rc_c.segments):
+        assert np.array_equal(a.seal, b.seal) and np.array_equal(a.seal, c.seal)
+    # the columns themselves: rk_exec_witness_device == rk_exec_witness, padding rows of the short last segment included
+    from raiko_amd.hal import HipHal
+    h = HipHal(0)
+    st_host, st_dev = X.Stepper(image, segment_limit_po2=13), X.Stepper(image, segment_limit_po2=13)
+    try:
+        for _ in range(3):
+            _, code_h, data_h = st_host.next()
+            _, code_d, data_d = st_dev.next(h)
+            assert np.array_equal(code_d.to_host().reshape(code_h.shape), code_h)
+            assert np.array_equal(data_d.to_host().reshape(data_h.shape), data_h)
+        assert st_host.next() is None and st_dev.next(h) is None
+    finally:
+        st_host.close()
+        st_dev.close()
     segs = X.trace_segments(X.execute(image, segment_limit_po2=13, record_trace=True))
     segs[2].groups[2][2, 7] = segs[2].groups[2][2, 8]
     stream = SessionStream(inflight=2, program=segs[0].program)
