@@ -361,6 +361,7 @@ int exec_next(rk_exec* ex, int* more) {
     state_digest(*ex->k, m, seg.pre_state);
     uint64_t cycles = 0;
     std::vector<TraceRow> trace;
+    if (o.record_trace) trace.reserve((size_t)std::min<uint64_t>(limit, (uint64_t)1 << 22));  // 28 bytes per cycle, no regrowth copies
     while (cycles < limit) {
         if (o.session_limit && ex->total >= o.session_limit) {
             ex->error = "session limit reached";
