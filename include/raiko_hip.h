@@ -201,6 +201,13 @@ int rk_pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size
  * matrix height, zeroed by the caller) is what the FRI commit phase folds with rk_fri_fold_evals. */
 int rk_pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,
                            const uint32_t* h_points, const uint32_t* h_opened, const uint32_t alpha[4], uint64_t alpha_offset);
+/* `challenger.grind(bits)` of Plonky3's DuplexChallenger (p3-challenger, RECALLED): sponge_state = the challenger's
+ * `width` state cells (Montgomery words), input_buffer = its n_input (< rate = width - 8) buffered observations.
+ * *witness = the smallest field element w (canonical integer) for which observing w and then sample_bits(bits) gives
+ * zero: w joins the inputs, they overwrite the first cells, one permutation, the last rate cell is the sample.
+ * Plonky3 accepts any such w (`find_any`); the smallest is returned so that the result is reproducible. */
+int rk_duplex_grind(rk_ctx* ctx, const uint32_t* sponge_state, const uint32_t* input_buffer, uint32_t n_input, uint32_t bits,
+                    uint32_t* witness);
 
 /* synthetic division of one extension polynomial (count coefficients, natural order) by (x - z),
  * in place (core/poly.rs poly_divide); the remainder f(z) goes to h_rem (4 words, may be NULL). */

@@ -97,3 +97,38 @@ void or_pcs_reduce_openings(fp4* ro, const fp* lde, size_t H, size_t w, size_t n
     }
     free(apow);
 }
+
+/* DuplexChallenger::grind (p3-challenger, RECALLED): the literal definition -- for w = 0, 1, ... clone the challenger,
+ * observe(w) (clear the outputs, push the input, duplex when the rate is full), sample_bits(bits) (duplex first if
+ * inputs are buffered or no outputs are left, pop the LAST output, mask its canonical value) -- smallest w giving 0.
+ * state: OR_CELLS sponge cells; input: the buffered observations (n_input < rate). */
+uint32_t or_duplex_grind(const fp* state, const fp* input, size_t n_input, unsigned bits) {
+    const size_t width = OR_CELLS, rate = OR_CELLS_RATE;
+    for (uint32_t w = 0; w < OR_P; w++) {
+        fp s[OR_MAX_CELLS], in[OR_MAX_CELLS], out[OR_MAX_CELLS];
+        size_t n_in = n_input, n_out = 0;
+        memcpy(s, state, width * sizeof(fp));
+        memcpy(in, input, n_input * sizeof(fp));
+        /* observe */
+        n_out = 0;
+        in[n_in++] = fp_from_u32(w);
+        if (n_in == rate) {
+            for (size_t i = 0; i < n_in; i++) s[i] = in[i];
+            n_in = 0;
+            or_poseidon2_mix(s);
+            for (size_t i = 0; i < rate; i++) out[i] = s[i];
+            n_out = rate;
+        }
+        /* sample_bits */
+        if (n_in != 0 || n_out == 0) {
+            for (size_t i = 0; i < n_in; i++) s[i] = in[i];
+            n_in = 0;
+            or_poseidon2_mix(s);
+            for (size_t i = 0; i < rate; i++) out[i] = s[i];
+            n_out = rate;
+        }
+        uint32_t v = or_fp_decode(out[--n_out]);
+        if ((v & (uint32_t)(((uint64_t)1 << bits) - 1)) == 0) return w;
+    }
+    return 0xffffffffu;
+}

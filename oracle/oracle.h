@@ -106,6 +106,8 @@ void or_pcs_eval_at(fp4* out, const fp* lde, size_t H, size_t w, const uint32_t*
 void or_pcs_reduce_openings(fp4* ro, const fp* lde, size_t H, size_t w, size_t n_points, const uint32_t* points,
                             const uint32_t* ys, const uint32_t* alpha, uint64_t alpha_offset);
 
+uint32_t or_duplex_grind(const fp* state, const fp* input, size_t n_input, unsigned bits);
+
 /* ---- risc0-zkp core/poly.rs ---- */
 void or_poly_interpolate(fp4* out, const fp4* x, const fp4* fx, size_t n);
 void or_poly_divide(fp4* p, size_t n, const uint32_t* z, uint32_t* remainder);

@@ -125,6 +125,7 @@ int hash_fold(rk_ctx* ctx, uint32_t* d_nodes, size_t output_size);
 int merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols);
 // smallest proof-of-work nonce for the transcript generator state h_cells (host, p2 width words)
 int pow_grind(rk_ctx* ctx, const uint32_t* h_cells, unsigned bits, uint32_t* nonce);
+int duplex_grind(rk_ctx* ctx, const uint32_t* h_state, const uint32_t* h_input, unsigned n_input, unsigned bits, uint32_t* witness);
 
 // polynomial / elementwise (kernels_poly.hip)
 int eltwise_add(rk_ctx* ctx, uint32_t* d_out, const uint32_t* a, const uint32_t* b, size_t n);

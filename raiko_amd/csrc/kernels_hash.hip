@@ -223,6 +223,24 @@ __global__ __launch_bounds__(HASH_BLOCK) void pow_grind_kernel(uint32_t* __restr
     if ((v & mask) == 0) atomicMin(best, w);
 }
 
+// Plonky3 DuplexChallenger::grind (p3-challenger duplex_challenger.rs + grinding_challenger.rs, RECALLED): candidate
+// w = base + lane is observed on a copy of the challenger -- it joins the buffered inputs, which overwrite the first
+// cells of the sponge state, and whether the push fills the rate or the following sample forces it, exactly one
+// permutation runs before sample_bits pops the last rate cell of the new state.  Smallest hit wins.
+template <class C>
+__global__ __launch_bounds__(HASH_BLOCK) void duplex_grind_kernel(uint32_t* __restrict__ best, const uint32_t* __restrict__ state,
+                                                                  unsigned n_input, uint32_t base, uint32_t count, uint32_t mask,
+                                                                  const typename C::Consts* __restrict__ kc) {
+    const uint32_t gid = blockIdx.x * HASH_BLOCK + threadIdx.x;
+    if (gid >= count) return;
+    const uint32_t w = base + gid;
+    uint32_t s[C::CELLS];
+#pragma unroll
+    for (int i = 0; i < C::CELLS; i++) s[i] = (unsigned)i == n_input ? bb::mul(w, bb::R2) : state[i];  // state already holds the buffered inputs
+    C::permute(s, *kc);
+    if ((bb::decode(s[C::RATE - 1]) & mask) == 0) atomicMin(best, w);
+}
+
 // run F<Core> for the context's Poseidon2 instance
 #define RK_P2_DISPATCH(ctx, CALL)                         \
     switch ((ctx)->h_p2.kind) {                           \
@@ -299,6 +317,39 @@ int pow_grind(rk_ctx* ctx, const uint32_t* h_cells, unsigned bits, uint32_t* non
     return RK_ERR_INTERNAL;
 }
 
+int duplex_grind(rk_ctx* ctx, const uint32_t* h_state, const uint32_t* h_input, unsigned n_input, unsigned bits, uint32_t* witness) {
+    const unsigned width = (unsigned)ctx->h_p2.cells(), rate = width - p2::OUT;
+    if (bits == 0 || bits > 24 || !h_state || !witness || n_input >= rate || (n_input && !h_input)) return RK_ERR_INVALID;
+    uint32_t host[p2::MAX_CELLS + 1] = {0};
+    std::memcpy(host, h_state, width * 4);
+    if (n_input) std::memcpy(host, h_input, n_input * 4);  // duplexing overwrites the first cells with the buffered inputs
+    for (unsigned i = 0; i < width; i++)
+        if (host[i] >= bb::P) return RK_ERR_INVALID;
+    host[p2::MAX_CELLS] = 0xffffffffu;
+    void* d = nullptr;
+    RK_TRY(scratch(ctx, sizeof host, &d));
+    uint32_t* d_cells = (uint32_t*)d;
+    uint32_t* d_best = d_cells + p2::MAX_CELLS;
+    RK_TRY(upload(ctx, d, host, sizeof host));
+    const uint64_t batch = (uint64_t)1 << (bits + 2 < 16 ? 16 : bits + 2);
+    const uint32_t mask = (uint32_t)(((uint64_t)1 << bits) - 1);
+    for (uint64_t base = 0; base < bb::P; base += batch) {
+        const uint32_t count = (uint32_t)std::min<uint64_t>(batch, bb::P - base);
+        const unsigned blocks = (count + HASH_BLOCK - 1) / HASH_BLOCK;
+        RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(duplex_grind_kernel<C>, dim3(blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_best, d_cells,
+                                               n_input, (uint32_t)base, count, mask, (const typename C::Consts*)ctx->d_p2));
+        RK_TRY(post_launch(ctx, "duplex_grind_kernel"));
+        uint32_t best = 0;
+        RK_HIP_TRY(ctx, hipMemcpyAsync(&best, d_best, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != 0xffffffffu) {
+            *witness = best;
+            return RK_OK;
+        }
+    }
+    return RK_ERR_INTERNAL;
+}
+
 // every level from the one with `top_output_size` parents up to the root, cell-parallel, a few levels per launch
 int hash_fold_top(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size) {
     if (!is_pow2(top_output_size) || top_output_size > CELLS_MAX_OUT) return RK_ERR_INVALID;
@@ -348,6 +399,14 @@ int rk_pow_grind(rk_ctx* ctx, const uint32_t* sponge_cells, uint32_t bits, uint3
     if (!ctx || !sponge_cells || !nonce) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rk::pow_grind(ctx, sponge_cells, bits, nonce);
+    RK_GUARD_END
+}
+int rk_duplex_grind(rk_ctx* ctx, const uint32_t* sponge_state, const uint32_t* input_buffer, uint32_t n_input, uint32_t bits,
+                    uint32_t* witness) {
+    RK_GUARD_BEGIN
+    if (!ctx || !sponge_state || !witness) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::duplex_grind(ctx, sponge_state, input_buffer, n_input, bits, witness);
     RK_GUARD_END
 }
 int rk_merkle_build(rk_ctx* ctx, uint32_t* d_nodes, const uint32_t* d_matrix, size_t rows, size_t cols) {

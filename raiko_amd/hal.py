@@ -213,6 +213,15 @@ class HipHal:
         self._ck(self._lib.rk_pcs_reduce_openings(self._ctx, _ptr(ro), _ptr(lde), lde_height, width, pts.shape[0], _u32p(pts),
                                                   _u32p(ys), _u32p(a), alpha_offset))
 
+    def duplex_grind(self, sponge_state, input_buffer, bits: int) -> int:
+        """Plonky3 DuplexChallenger::grind on a challenger in the given state: the smallest witness (canonical integer)"""
+        st = np.ascontiguousarray(sponge_state, dtype=np.uint32)
+        inp = np.ascontiguousarray(input_buffer, dtype=np.uint32).reshape(-1)
+        w = np.zeros(1, dtype=np.uint32)
+        pad = inp if inp.size else np.zeros(1, dtype=np.uint32)
+        self._ck(self._lib.rk_duplex_grind(self._ctx, _u32p(st), _u32p(pad), inp.size, bits, _u32p(w)))
+        return int(w[0])
+
     def gather_sample(self, dst, src, idx: int, size: int, stride: int):
         self._ck(self._lib.rk_gather_sample(self._ctx, _ptr(dst), _ptr(src), idx, size, stride))
 

@@ -135,6 +135,7 @@ def oracle():
             "or_mmcs_commit": (None, [vp, u32, vp]),
             "or_mmcs_verify": (C.c_int, [vp, vp, u32, u32, vp, vp, vp]),
             "or_scatter": (None, [vp, vp, sz, vp, vp]),
+            "or_duplex_grind": (u32, [vp, vp, sz, C.c_uint]),
             "or_pcs_coset_lde_rows": (None, [vp, vp, sz, sz]), "or_pcs_eval_at": (None, [vp, vp, sz, sz, vp]),
             "or_pcs_reduce_openings": (None, [vp, vp, sz, sz, sz, vp, vp, vp, C.c_uint64]),
             "or_free": (None, [vp]), "or_max_threads": (C.c_int, []), "or_set_threads": (None, [C.c_int]),

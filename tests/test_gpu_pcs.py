@@ -141,3 +141,17 @@ def test_invalid_arguments_are_refused(cfg):
                 lambda: h.pcs_reduce_openings(buf, buf, 16, 4, np.zeros((0, 4), np.uint32), np.zeros((0, 4, 4), np.uint32), z)):
         with pytest.raises(H._lib.RkError):
             bad()
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("bits,n_input", [(8, 0), (12, 5), (16, 7), (16, "last")])
+def test_duplex_grind(cfg, preset, bits, n_input):
+    h, apply = cfg
+    width = int(apply(preset).p2_width)
+    n_in = width - 9 if n_input == "last" else n_input
+    rng = np.random.default_rng(500 + bits + preset)
+    state, inputs = o.rand_elems(rng, (width,)), o.rand_elems(rng, (max(n_in, 1),))[:n_in]
+    want = o.oracle().or_duplex_grind(o.ptr(state), o.ptr(inputs if n_in else np.zeros(1, dtype=np.uint32)), n_in, bits)
+    assert h.duplex_grind(state, inputs, bits) == want
+    with pytest.raises(H._lib.RkError):
+        h.duplex_grind(state, o.rand_elems(rng, (width - 8,)), bits)      # a full buffer would already have been absorbed

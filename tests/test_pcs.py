@@ -171,3 +171,63 @@ def test_oracle_matches_committed_digests():
     assert sorted(gold) == sorted(PCS_CASES)
     for key in PCS_CASES:
         assert oracle_outputs(key) == gold[key], key
+
+
+class DuplexChallengerPy:
+    """p3-challenger DuplexChallenger, literally (RECALLED): the specification or_duplex_grind is checked against"""
+
+    def __init__(self, orc, width, state, inputs):
+        self.orc, self.width, self.rate = orc, width, width - 8
+        self.state = np.array(state, dtype=np.uint32).copy()
+        self.inputs = [int(v) for v in inputs]
+        self.outputs = []
+
+    def clone(self):
+        c = DuplexChallengerPy(self.orc, self.width, self.state, self.inputs)
+        c.outputs = list(self.outputs)
+        return c
+
+    def duplexing(self):
+        assert len(self.inputs) <= self.rate
+        for i, v in enumerate(self.inputs):
+            self.state[i] = v
+        self.inputs = []
+        buf = np.zeros(24, dtype=np.uint32)
+        buf[: self.width] = self.state
+        self.orc.or_poseidon2_mix(o.ptr(buf))
+        self.state = buf[: self.width].copy()
+        self.outputs = [int(v) for v in self.state[: self.rate]]
+
+    def observe(self, v):
+        self.outputs = []
+        self.inputs.append(int(v))
+        if len(self.inputs) == self.rate:
+            self.duplexing()
+
+    def sample(self):
+        if self.inputs or not self.outputs:
+            self.duplexing()
+        return self.outputs.pop()
+
+    def sample_bits(self, bits):
+        return int(o.from_mont(np.array([self.sample()], dtype=np.uint32))[0]) & ((1 << bits) - 1)
+
+    def check_witness(self, bits, w):
+        self.observe(int(o.to_mont(np.array([w], dtype=np.uint64))[0]))
+        return self.sample_bits(bits) == 0
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("n_input", [0, 3, "last"])
+def test_duplex_grind_is_the_smallest_accepted_witness(params, preset, n_input):
+    p = params(preset)
+    orc = o.oracle()
+    width = int(p.p2_width)
+    n_in = width - 9 if n_input == "last" else n_input      # "last": the witness fills the rate
+    rng = np.random.default_rng(40 + preset)
+    state, inputs = o.rand_elems(rng, (width,)), o.rand_elems(rng, (max(n_in, 1),))[:n_in]
+    bits = 7
+    w = orc.or_duplex_grind(o.ptr(state), o.ptr(inputs if n_in else np.zeros(1, dtype=np.uint32)), n_in, bits)
+    ch = DuplexChallengerPy(orc, width, state, inputs)
+    assert ch.clone().check_witness(bits, w)
+    assert not any(ch.clone().check_witness(bits, v) for v in range(w))
