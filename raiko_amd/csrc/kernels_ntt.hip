@@ -62,15 +62,16 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel_u(ntt::PassArgs a, ntt::
 // shape-specialised two-pass kernels for 2^18 .. 2^22 points (ntt_fused.hpp).
 // 8 waves per SIMD (<= 64 VGPRs): two 1024-lane workgroups per CU, so one group's barriers and LDS
 // round trips are covered by the other's arithmetic
-template <bool EXPAND>
+template <int EXPAND_BITS>
 __global__ __launch_bounds__(1024, 8) void nf_fwd_contig_kernel(nf::Args a, ntt::Tables tb) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[nf::LDS_WORDS];
     const unsigned tid = threadIdx.x;
-    const nf::CTile t = nf::ctile_of(a, blockIdx.x, EXPAND ? 2 : 0);
-    if (EXPAND) {
+    const nf::CTile t = nf::ctile_of(a, blockIdx.x, EXPAND_BITS);
+    if (EXPAND_BITS == 2) {
         nf::fwd_contig_a(a, tb, t, lds, tid);
     } else {
-        nf::fwd_contig0_a(a, tb, t, lds, tid);
+        if (EXPAND_BITS == 1) nf::fwd_contig1_a(a, tb, t, lds, tid);
+        else nf::fwd_contig0_a(a, tb, t, lds, tid);
         __syncthreads();
         nf::fwd_contig0_b(tb, lds, tid);
     }
@@ -246,10 +247,12 @@ int launch_nf_fwd_contig(rk_ctx* ctx, const nf::Args& a, unsigned expand_bits) {
     size_t blocks = (size_t)a.count * (a.n >> nf::TILE_LOG);
     if (blocks == 0 || blocks > 0x7fffffffu) return RK_ERR_INVALID;
     rk::KTimer kt(ctx, RK_KCLASS_NTT_PASS, (double)a.count * 4 * (a.n_src + a.n));
-    if (expand_bits)
-        hipLaunchKernelGGL(nf_fwd_contig_kernel<true>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
+    if (expand_bits == 2)
+        hipLaunchKernelGGL(nf_fwd_contig_kernel<2>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
+    else if (expand_bits == 1)
+        hipLaunchKernelGGL(nf_fwd_contig_kernel<1>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
     else
-        hipLaunchKernelGGL(nf_fwd_contig_kernel<false>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
+        hipLaunchKernelGGL(nf_fwd_contig_kernel<0>, dim3((unsigned)blocks), dim3(nf::NTHR), 0, ctx->stream, a, ctx->tb);
     return rk::post_launch(ctx, "nf_fwd_contig_kernel");
 }
 int launch_nf_inv_contig(rk_ctx* ctx, const nf::Args& a) {

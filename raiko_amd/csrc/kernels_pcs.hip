@@ -93,12 +93,22 @@ __global__ void bary_dot_kernel(uint32_t* __restrict__ partial, const uint32_t* 
         __syncthreads();
     }
 }
+// out[c] = scaling * sum over chunks of partial[chunk][c]: 64 columns x 16 chunk classes per block, combined through LDS
+constexpr int FIN_X = 64, FIN_Y = 16;
 __global__ void bary_finish_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ partial, size_t chunks, size_t w, Ext scaling,
                                    uint32_t wm) {
-    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= w) return;
+    __shared__ uint32_t red[FIN_Y][FIN_X][4];
+    const size_t c = (size_t)blockIdx.x * FIN_X + threadIdx.x;
     Ext acc = bb::ext_zero();
-    for (size_t k = 0; k < chunks; k++) acc = bb::add(acc, load_ext(partial + (k * w + c) * 4));
+    if (c < w)
+        for (size_t k = threadIdx.y; k < chunks; k += FIN_Y) acc = bb::add(acc, load_ext(partial + (k * w + c) * 4));
+#pragma unroll
+    for (int t = 0; t < 4; t++) red[threadIdx.y][threadIdx.x][t] = acc.c[t];
+    __syncthreads();
+    if (threadIdx.y != 0 || c >= w) return;
+    for (int y = 1; y < FIN_Y; y++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc.c[t] = bb::add(acc.c[t], red[y][threadIdx.x][t]);
     store_ext(out + c * 4, bb::mul(acc, scaling, wm));
 }
 
@@ -205,7 +215,7 @@ int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t 
             st = post_launch(ctx, "bary_dot_kernel");
         }
         if (st == RK_OK) {
-            hipLaunchKernelGGL(bary_finish_kernel, dim3((unsigned)((w + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_out_ext,
+            hipLaunchKernelGGL(bary_finish_kernel, dim3((unsigned)((w + FIN_X - 1) / FIN_X)), dim3(FIN_X, FIN_Y), 0, ctx->stream, d_out_ext,
                                (const uint32_t*)partial, chunks, w, scaling, wm);
             st = post_launch(ctx, "bary_finish_kernel");
         }

@@ -62,19 +62,20 @@ RK_HD void stage_tw(uint32_t* w, const uint32_t* tw, unsigned rlow) {
 //   t = y * w via an unsigned REDC (any u32 y, result < 2p), t and x brought to [0, p) with one
 //   conditional subtraction each, then x + t and x - t + p need no reduction (both < 2p < 2^32).
 // CANON_IN: the 16 inputs are canonical (fresh from global memory): the first stage skips its ucanon of x
-template <int LS, int NST, bool CANON_IN = false>
+// B0: first stage of the round to run (the earlier ones were done some other way: a broadcast in the 2x expanding pass)
+template <int LS, int NST, bool CANON_IN = false, int B0 = 0>
 RK_HD void dit(uint32_t* v, const uint32_t* tw, unsigned rlow) {
-    static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+    static_for<B0, NST>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
         uint32_t w[1 << b];
         stage_tw<LS, b>(w, tw, rlow);
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             if (m & (1 << b)) continue;
-            uint32_t x = (CANON_IN && b == 0) ? v[m] : bb::ucanon(v[m]);
+            uint32_t x = (CANON_IN && b == B0) ? v[m] : bb::ucanon(v[m]);
             uint32_t t;
             if (LS == 0 && (m & ((1 << b) - 1)) == 0)  // position 0 of its half: the twiddle is w^0 = 1
-                t = (CANON_IN && b == 0) ? v[m | (1 << b)] : bb::ucanon(v[m | (1 << b)]);
+                t = (CANON_IN && b == B0) ? v[m | (1 << b)] : bb::ucanon(v[m | (1 << b)]);
             else
                 t = bb::ucanon(bb::uredc64((uint64_t)v[m | (1 << b)] * w[m & ((1 << b) - 1)]));
             v[m] = x + t;
@@ -203,6 +204,24 @@ RK_HD void fwd_contig0_a(const Args& a, const ntt::Tables& tb, const CTile& t, u
         v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
     }
     dit<0, 2, true>(v, tb.small[0], 0);
+    V4* p = reinterpret_cast<V4*>(lds + phys(16 * tid));
+#pragma unroll
+    for (int q = 0; q < 4; q++) p[q] = V4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+// 2x expanding: stage 0 of a zero-interleaved input is a broadcast (x, 0) -> (x, x): the lane reads 8 source words
+// and runs stage 1 only; the other rounds are the non-expanding ones
+RK_HD void fwd_contig1_a(const Args& a, const ntt::Tables& tb, const CTile& t, uint32_t* lds, unsigned tid) {
+    uint32_t v[16];
+    const V4* s = reinterpret_cast<const V4*>(a.src + t.src_base + 8 * (size_t)tid);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        V4 u = s[q];
+        v[8 * q] = v[8 * q + 1] = u.x;
+        v[8 * q + 2] = v[8 * q + 3] = u.y;
+        v[8 * q + 4] = v[8 * q + 5] = u.z;
+        v[8 * q + 6] = v[8 * q + 7] = u.w;
+    }
+    dit<0, 2, true, 1>(v, tb.small[0], 0);
     V4* p = reinterpret_cast<V4*>(lds + phys(16 * tid));
 #pragma unroll
     for (int q = 0; q < 4; q++) p[q] = V4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -339,10 +358,10 @@ RK_HD uint32_t zk_entry(const ntt::Tables& tb, unsigned k, uint32_t scale, size_
     return bb::mul(scale, ntt::pow3(tb, bb::bitrev((uint32_t)pos, k)));
 }
 
-// shapes served: 2^18 .. 2^22 points, forward with 4x expansion or none, 16-byte aligned buffers
+// shapes served: 2^18 .. 2^22 points, forward with 4x or 2x expansion or none, 16-byte aligned buffers
 inline bool usable(unsigned k, unsigned expand_bits, bool aligned16) {
     if (!aligned16 || k < TILE_LOG + 4 || k > TILE_LOG + 8) return false;
-    return expand_bits == 0 || expand_bits == 2;
+    return expand_bits <= 2;
 }
 
 }  // namespace nf

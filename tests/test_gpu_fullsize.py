@@ -141,3 +141,17 @@ def test_baseline_size_seal_bit_exact(hal, name):
     with open(LARGE_GOLDEN) as f:
         golden = json.load(f)
     assert golden[name] == {"words": int(got.size), "sha256": digest(got)}
+
+
+@pytest.mark.parametrize("k_in", [17, 19, 21])
+def test_expanding_ntt_by_two_matches_the_oracle(hal, orc, k_in):
+    """blow-up 2 (SP1's shape) through the fused two-pass kernels: the first round of the contiguous pass reads half a
+    tile and broadcasts (stage 0 of a zero-interleaved input), bit for bit the oracle's expand + evaluate"""
+    rng = np.random.default_rng(300 + k_in)
+    n, cnt = 1 << k_in, 3
+    coeffs = o.rand_elems(rng, (cnt, n))
+    want = np.zeros((cnt, 2 * n), dtype=np.uint32)
+    orc.or_batch_expand_into_evaluate_ntt(o.ptr(want), o.ptr(coeffs), n, cnt, 1)
+    out = hal.alloc_elem(cnt * 2 * n)
+    hal.batch_expand_into_evaluate_ntt(out, hal.copy_from_elem(coeffs), cnt, 1)
+    assert np.array_equal(out.to_host().reshape(cnt, 2 * n), want)
