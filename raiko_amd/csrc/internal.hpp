@@ -153,6 +153,8 @@ int ext_powers(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext& x, size_t n, bool
 int ext_powers_many(rk_ctx* ctx, uint32_t* d_pw_ext, const bb::Ext* h_pts, size_t n_pts, size_t n, bool bit_reversed);
 int bit_reverse_ext(rk_ctx* ctx, uint32_t* d_io_ext, size_t size, size_t count);
 // levels of a Merkle tree with <= 1024 parents, fused in one launch (kernels_hash.hip)
+// every level from the one with top_output_size (<= HASH_FOLD_TOP_MAX, a power of two) parents up to the root
+constexpr size_t HASH_FOLD_TOP_MAX = 4096;
 int hash_fold_top(rk_ctx* ctx, uint32_t* d_nodes, size_t top_output_size);
 // d_out_ext[e] = sum_k coeffs[which[e]*size + k] * pw[pw_sel[e]*size + k]
 int eval_dot(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_coeffs, size_t size, const uint32_t* d_which,

@@ -12,7 +12,7 @@ namespace {
 constexpr int HASH_BLOCK = 256;
 // levels with at most this many parents go cell-parallel (hash_fold_top): a cell-parallel permutation costs ~6x the
 // lane-cycles of a lane-per-parent one, so it only pays where the level is latency-bound anyway
-constexpr size_t CELLS_MAX_OUT = 4096;
+constexpr size_t CELLS_MAX_OUT = rk::HASH_FOLD_TOP_MAX;
 
 // C = the configured p2::Core (width 24 or 16, external 4x4 block): one kernel instance per Core.
 // pad_free: the last partial block leaves the remaining rate cells as they are (Plonky3

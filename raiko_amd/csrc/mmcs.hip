@@ -153,7 +153,12 @@ int rk_mmcs_commit(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, uint32_t
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RK_TRY(hash_level(ctx, mats, n_mats, H, d_nodes + (size_t)H * p2::OUT));
     void* d_extra = nullptr;
-    for (uint32_t size = H / 2; size >= 1; size /= 2) {
+    // above the shortest matrix nothing joins any more: those levels (at most HASH_FOLD_TOP_MAX parents) go through
+    // the cell-parallel launches of hash_fold_top, a few levels each, instead of one latency-bound launch per level
+    uint32_t shortest = H;
+    for (uint32_t m = 0; m < n_mats; m++) shortest = std::min(shortest, mats[m].height);
+    const uint32_t top = (uint32_t)std::min<size_t>(shortest / 2, rk::HASH_FOLD_TOP_MAX);
+    for (uint32_t size = H / 2; size >= 1 && size > top; size /= 2) {
         RK_TRY(rk::hash_fold(ctx, d_nodes, size));  // nodes[size + i] = compress(children)
         bool inject = false;
         for (uint32_t m = 0; m < n_mats; m++) inject |= mats[m].height == size;
@@ -174,6 +179,7 @@ int rk_mmcs_commit(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, uint32_t
         }
     }
     if (d_extra) RK_TRY(rk::dev_free(ctx, d_extra));
+    if (top >= 1) RK_TRY(rk::hash_fold_top(ctx, d_nodes, top));
     if (h_root) {
         RK_HIP_TRY(ctx, hipMemcpyAsync(h_root, d_nodes + p2::OUT, p2::OUT * 4, hipMemcpyDeviceToHost, ctx->stream));
         RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
