@@ -313,7 +313,10 @@ int rk_program_eval_check(const rk_program* prog, const rk_circuit_view* view, c
  * -- what tools/circuit_gen.py emits at build time -- compiled with hiprtc; seconds for 10^4 steps).  From then on
  * rk_program_eval_check on that GPU runs the generated kernel (about 3x the interpreter's speed) instead of the
  * interpreter; results are identical.  RK_ERR_HIP with the compiler's log in rk_last_error if it cannot be
- * built -- the interpreter stays in charge. */
+ * built -- the interpreter stays in charge.
+ * With RK_JIT_CACHE_DIR set, the code object is kept there under a name derived from the generated source, the
+ * architecture and the hiprtc version, and loaded instead of compiled the next time (a host restart then costs
+ * milliseconds, not the ~20 s of a 30 k-step list). */
 int rk_program_compile(rk_program* prog, rk_ctx* ctx);
 /* the HIP source rk_program_compile hands to the compiler (NUL-terminated; *length without the NUL;
  * RK_ERR_CAPACITY with *length set when `out` is too small) */

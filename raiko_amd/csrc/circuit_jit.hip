@@ -14,6 +14,9 @@
 //     leaves are re-read where they are used.
 #include <hip/hiprtc.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 #include <set>
@@ -342,30 +345,74 @@ int rk_program_compile(rk_program* pg, rk_ctx* ctx) {
     rk::JitEntry je;
     const std::string src = generate(*pg, &je.powers);
     je.n_powers = (uint32_t)je.powers.size();
-    hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "rk_program.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-        ctx->last_error = "hiprtcCreateProgram failed";
-        return RK_ERR_HIP;
-    }
     hipDeviceProp_t props;
     RK_HIP_TRY(ctx, hipGetDeviceProperties(&props, ctx->device));
-    const std::string arch = std::string("--offload-arch=") + props.gcnArchName;
-    const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
-    const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
-    if (cr != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        (void)hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, '\0');
-        if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
-        ctx->last_error = "hiprtcCompileProgram: " + log.substr(0, 2000);
-        (void)hiprtcDestroyProgram(&prog);
-        return RK_ERR_HIP;
+    // RK_JIT_CACHE_DIR (opt-in): code objects keyed by a hash of the generated source, the architecture string and
+    // the hiprtc version -- a circuit of 30 k steps costs ~20 s to compile, a host restart should not pay it again
+    int rtc_major = 0, rtc_minor = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    std::string cache_path;
+    if (const char* dir = std::getenv("RK_JIT_CACHE_DIR")) {
+        if (*dir) {
+            uint64_t hsh = 1469598103934665603ull;  // FNV-1a
+            auto mix = [&](const char* ptr, size_t n) {
+                for (size_t i = 0; i < n; i++) hsh = (hsh ^ (unsigned char)ptr[i]) * 1099511628211ull;
+            };
+            mix(src.data(), src.size());
+            mix(props.gcnArchName, std::strlen(props.gcnArchName));
+            char tail[96];
+            std::snprintf(tail, sizeof tail, "|hiprtc %d.%d|%zu", rtc_major, rtc_minor, src.size());
+            mix(tail, std::strlen(tail));
+            char name[64];
+            std::snprintf(name, sizeof name, "/rkjit_%016llx.hsaco", (unsigned long long)hsh);
+            cache_path = std::string(dir) + name;
+        }
     }
-    size_t code_size = 0;
-    (void)hiprtcGetCodeSize(prog, &code_size);
-    std::vector<char> code(code_size);
-    (void)hiprtcGetCode(prog, code.data());
-    (void)hiprtcDestroyProgram(&prog);
+    std::vector<char> code;
+    if (!cache_path.empty()) {
+        if (FILE* f = std::fopen(cache_path.c_str(), "rb")) {
+            std::fseek(f, 0, SEEK_END);
+            const long n = std::ftell(f);
+            std::fseek(f, 0, SEEK_SET);
+            if (n > 0) {
+                code.resize((size_t)n);
+                if (std::fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
+            }
+            std::fclose(f);
+        }
+    }
+    if (code.empty()) {
+        hiprtcProgram prog = nullptr;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "rk_program.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+            ctx->last_error = "hiprtcCreateProgram failed";
+            return RK_ERR_HIP;
+        }
+        const std::string arch = std::string("--offload-arch=") + props.gcnArchName;
+        const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+        const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+        if (cr != HIPRTC_SUCCESS) {
+            size_t n = 0;
+            (void)hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n, '\0');
+            if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+            ctx->last_error = "hiprtcCompileProgram: " + log.substr(0, 2000);
+            (void)hiprtcDestroyProgram(&prog);
+            return RK_ERR_HIP;
+        }
+        size_t code_size = 0;
+        (void)hiprtcGetCodeSize(prog, &code_size);
+        code.resize(code_size);
+        (void)hiprtcGetCode(prog, code.data());
+        (void)hiprtcDestroyProgram(&prog);
+        if (!cache_path.empty()) {  // best effort: written under a temporary name, renamed when complete
+            const std::string tmp = cache_path + ".tmp" + std::to_string((unsigned long long)(uintptr_t)&je);
+            if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+                const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+                std::fclose(f);
+                if (!ok || std::rename(tmp.c_str(), cache_path.c_str()) != 0) (void)std::remove(tmp.c_str());
+            }
+        }
+    }
     RK_HIP_TRY(ctx, hipModuleLoadData(&je.module, code.data()));
     hipError_t e = hipModuleGetFunction(&je.kernel, je.module, "rk_jit_eval_check");
     if (e != hipSuccess) {

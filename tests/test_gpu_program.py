@@ -254,3 +254,35 @@ def test_runtime_compiled_toy_circuit_seal(hal, toy):
     got = hal.prove_segment(seg)
     assert np.array_equal(got, want)
     assert verify_segment(seg, got, program=seg.program) == 0
+
+
+def test_jit_cache_directory(hal, tmp_path, monkeypatch):
+    """RK_JIT_CACHE_DIR: the code object of a compiled list is written once and loaded by the next program with the
+    same generated source (a second host process in real life); a truncated file is not trusted blindly -- the
+    module fails to load and the call reports it instead of running garbage"""
+    import time
+    rng = np.random.default_rng(4242)
+    taps = synthetic_tapset(6, 4, 20)
+    steps, ret = random_program(rng, taps, 3, 2, n_fp_ops=400, n_live=20, depth=3, n_constraints=40)
+    monkeypatch.setenv("RK_JIT_CACHE_DIR", str(tmp_path))
+    first, second, interp = cp.Program(steps, ret, taps), cp.Program(steps, ret, taps), cp.Program(steps, ret, taps)
+    t0 = time.perf_counter()
+    first.compile(hal)
+    t1 = time.perf_counter()
+    files = list(tmp_path.glob("rkjit_*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > 1000
+    second.compile(hal)
+    t2 = time.perf_counter()
+    assert len(list(tmp_path.iterdir())) == 1               # nothing new, no temporary left behind
+    assert (t2 - t1) < 0.5 * (t1 - t0)                       # loaded, not compiled
+    po2 = 8
+    d = 4 << po2
+    lde = [o.rand_elems(rng, (int(w), d)) for w in taps.group_size]
+    globals_, mix, pm = o.rand_elems(rng, (3,)), o.rand_elems(rng, (2,)), o.rand_elems(rng, (4,))
+    want = run_eval_check(hal, interp, po2, lde, globals_, mix, pm)
+    assert np.array_equal(run_eval_check(hal, first, po2, lde, globals_, mix, pm), want)
+    assert np.array_equal(run_eval_check(hal, second, po2, lde, globals_, mix, pm), want)
+    files[0].write_bytes(files[0].read_bytes()[:200])
+    third = cp.Program(steps, ret, taps)
+    with pytest.raises(Exception):
+        third.compile(hal)
