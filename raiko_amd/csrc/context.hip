@@ -103,12 +103,18 @@ int dev_free(rk_ctx* ctx, void* p) {
 int upload(rk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     constexpr size_t RING = (size_t)4 << 20;
     if (bytes == 0) return RK_OK;
-    if (bytes > RING / 4) {
+    if (!ctx->h_ring && !ctx->h_ring_failed && bytes <= RING / 4) {
+        if (hipHostMalloc(&ctx->h_ring, RING, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();  // no page-locked memory to be had: every upload waits instead
+            ctx->h_ring = nullptr;
+            ctx->h_ring_failed = true;
+        }
+    }
+    if (bytes > RING / 4 || !ctx->h_ring) {
         RK_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return RK_OK;
     }
-    if (!ctx->h_ring) RK_HIP_TRY(ctx, hipHostMalloc(&ctx->h_ring, RING, hipHostMallocDefault));
     size_t at = (ctx->h_ring_at + 63) & ~(size_t)63;
     if (at + bytes > RING) {
         // wrap: every copy out of the ring was queued on this stream, so after this wait none is pending

@@ -43,6 +43,7 @@ struct rk_ctx {
     // page-locked ring the small uploads are staged in (rk::upload): no wait per upload
     void* h_ring = nullptr;
     size_t h_ring_at = 0;
+    bool h_ring_failed = false;
 
     rk_timing timing{};
     std::vector<hipEvent_t> stage_events;            // pool behind the per-stage brackets of prove_segment

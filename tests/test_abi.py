@@ -103,6 +103,9 @@ def test_plain_c_caller_compiles_against_the_header(tmp_path):
     exe2 = _build_demo(tmp_path, "program_demo")
     r = subprocess.run([exe2, "6"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no usable GPU" in r.stderr and "19 steps, 11 ops" in r.stdout
+    exe3 = _build_demo(tmp_path, "pcs_demo")
+    r = subprocess.run([exe3], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no usable GPU" in r.stderr
 
 
 @pytest.mark.gpu
@@ -129,3 +132,16 @@ def test_plain_c_caller_proves_from_a_constraint_list(tmp_path):
         r = subprocess.run([exe, po2], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout, r.stderr)
         assert "verifier says 0" in r.stdout and "with it 70" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_runs_the_pcs_steps(tmp_path):
+    """examples/pcs_demo.c: commit -> open -> reduce rows -> folds from C under SP1's parameter set; the folded
+    reduced opening is a constant (Plonky3's assertion at the end of the commit phase)"""
+    import subprocess
+    exe = _build_demo(tmp_path, "pcs_demo")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "raiko_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for args in (["5", "3"], ["14", "20"], ["18", "8"]):
+        r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "constant" in r.stdout and "NOT constant" not in r.stdout and "grind(12 bits) -> witness" in r.stdout
