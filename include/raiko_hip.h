@@ -194,6 +194,10 @@ int rk_pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, si
 /* open: the opened values of one committed matrix at the extension point z (`interpolate_coset` on the LDE's low
  * coset, i.e. its first lde_height >> blowup_log2 rows): d_out_ext = width extension elements p_c(z). */
 int rk_pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t lde_height, size_t width, const uint32_t z[4]);
+/* the same for n_points (<= 4) points in one pass over the low coset (a trace is opened at zeta and zeta * g):
+ * h_points = n_points x 4 words, d_out_ext = n_points x width extension elements, point-major. */
+int rk_pcs_eval_at_many(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,
+                        const uint32_t* h_points);
 /* open, "reduce rows": for the n_points (<= 8) opening points of one matrix, h_points = n_points x 4 words and
  * h_opened = n_points x width x 4 words (the values rk_pcs_eval_at returned),
  *   d_ro_ext[r] += alpha^(alpha_offset + j * width) * (sum_c alpha^c M[r][c] - sum_c alpha^c opened_j[c]) / (x_r - z_j)

@@ -59,49 +59,66 @@ __global__ void cols_to_rows_bitrev_kernel(uint32_t* __restrict__ dst, const uin
     }
 }
 
-// barycentric weights at the LDE's row positions: wts[bitrev_k(i)] = g^i / (z - s g^i), i < h = 2^k
-__global__ void bary_weights_kernel(uint32_t* __restrict__ wts, Ext z, size_t h, unsigned k, uint32_t shiftm, uint32_t wm,
-                                    ntt::Tables tb) {
+// barycentric weights at the LDE's row positions, blockIdx.y = point: wts[p][bitrev_k(i)] = g^i / (z_p - s g^i), i < h = 2^k
+struct BaryPoint {
+    Ext z, scaling;  // the point; (z^h - s^h) / (h s^(h-1))
+};
+constexpr int BARY_MAX_POINTS = 4;
+__global__ void bary_weights_kernel(uint32_t* __restrict__ wts, const BaryPoint* __restrict__ pts, size_t h, unsigned k, uint32_t shiftm,
+                                    uint32_t wm, ntt::Tables tb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h) return;
     const uint32_t gi = ntt::root_pow(tb, 0, (uint32_t)(i << (ntt::LAMBDA - k)));
-    Ext d = z;
+    Ext d = pts[blockIdx.y].z;
     d.c[0] = bb::sub(d.c[0], bb::mul(shiftm, gi));
-    store_ext(wts + (size_t)bb::bitrev((uint32_t)i, k) * 4, bb::scale(bb::inv(d, wm), gi));
+    store_ext(wts + ((size_t)blockIdx.y * h + bb::bitrev((uint32_t)i, k)) * 4, bb::scale(bb::inv(d, wm), gi));
 }
-// partial[chunk][c] = sum over the chunk's rows of wts[r] * M[r][c]: lanes along the row (coalesced), the rows of a
-// chunk split over the blockDim.y sub-rows, combined through LDS
+// partial[chunk][p][c] = sum over the chunk's rows of wts[p][r] * M[r][c]: lanes along the row (coalesced), the rows of
+// a chunk split over the blockDim.y sub-rows, combined through LDS; the matrix is read once for all NP points
 constexpr int BARY_X = 64, BARY_Y = 4;
+template <int NP>
 __global__ void bary_dot_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ wts, const uint32_t* __restrict__ M,
                                 size_t h, size_t w, size_t rows_per_chunk) {
     __shared__ uint32_t red[BARY_Y][BARY_X][4];
     const size_t r_begin = (size_t)blockIdx.x * rows_per_chunk, r_end = r_begin + rows_per_chunk < h ? r_begin + rows_per_chunk : h;
     for (size_t c0 = 0; c0 < w; c0 += BARY_X) {
         const size_t c = c0 + threadIdx.x;
-        Ext acc = bb::ext_zero();
+        Ext acc[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) acc[q] = bb::ext_zero();
         if (c < w)
-            for (size_t r = r_begin + threadIdx.y; r < r_end; r += BARY_Y) acc = bb::add(acc, bb::scale(load_ext(wts + r * 4), M[r * w + c]));
+            for (size_t r = r_begin + threadIdx.y; r < r_end; r += BARY_Y) {
+                const uint32_t m = M[r * w + c];
 #pragma unroll
-        for (int t = 0; t < 4; t++) red[threadIdx.y][threadIdx.x][t] = acc.c[t];
-        __syncthreads();
-        if (threadIdx.y == 0 && c < w) {
-            for (int y = 1; y < BARY_Y; y++)
+                for (int q = 0; q < NP; q++) acc[q] = bb::add(acc[q], bb::scale(load_ext(wts + ((size_t)q * h + r) * 4), m));
+            }
 #pragma unroll
-                for (int t = 0; t < 4; t++) acc.c[t] = bb::add(acc.c[t], red[y][threadIdx.x][t]);
-            store_ext(partial + ((size_t)blockIdx.x * w + c) * 4, acc);
+        for (int q = 0; q < NP; q++) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) red[threadIdx.y][threadIdx.x][t] = acc[q].c[t];
+            __syncthreads();
+            if (threadIdx.y == 0 && c < w) {
+                Ext tot = acc[q];
+                for (int y = 1; y < BARY_Y; y++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) tot.c[t] = bb::add(tot.c[t], red[y][threadIdx.x][t]);
+                store_ext(partial + (((size_t)blockIdx.x * NP + q) * w + c) * 4, tot);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
-// out[c] = scaling * sum over chunks of partial[chunk][c]: 64 columns x 16 chunk classes per block, combined through LDS
+// out[p][c] = scaling_p * sum over chunks of partial[chunk][p][c]: blockIdx.y = point, 64 columns x 16 chunk classes
+// per block, combined through LDS
 constexpr int FIN_X = 64, FIN_Y = 16;
-__global__ void bary_finish_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ partial, size_t chunks, size_t w, Ext scaling,
-                                   uint32_t wm) {
+__global__ void bary_finish_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ partial, size_t chunks, size_t w,
+                                   const BaryPoint* __restrict__ pts, unsigned n_points, uint32_t wm) {
     __shared__ uint32_t red[FIN_Y][FIN_X][4];
     const size_t c = (size_t)blockIdx.x * FIN_X + threadIdx.x;
+    const unsigned q = blockIdx.y;
     Ext acc = bb::ext_zero();
     if (c < w)
-        for (size_t k = threadIdx.y; k < chunks; k += FIN_Y) acc = bb::add(acc, load_ext(partial + (k * w + c) * 4));
+        for (size_t k = threadIdx.y; k < chunks; k += FIN_Y) acc = bb::add(acc, load_ext(partial + ((k * n_points + q) * w + c) * 4));
 #pragma unroll
     for (int t = 0; t < 4; t++) red[threadIdx.y][threadIdx.x][t] = acc.c[t];
     __syncthreads();
@@ -109,7 +126,7 @@ __global__ void bary_finish_kernel(uint32_t* __restrict__ out, const uint32_t* _
     for (int y = 1; y < FIN_Y; y++)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc.c[t] = bb::add(acc.c[t], red[y][threadIdx.x][t]);
-    store_ext(out + c * 4, bb::mul(acc, scaling, wm));
+    store_ext(out + ((size_t)q * w + c) * 4, bb::mul(acc, pts[q].scaling, wm));
 }
 
 // One lane per row.  A block takes 256 rows; the matrix goes through LDS in tiles of 256 rows x 32 columns so that
@@ -188,35 +205,46 @@ int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_
     return st;
 }
 
-int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const bb::Ext& z) {
+int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const uint32_t* h_points, size_t n_points) {
     const unsigned blow = ctx->sys.blowup_log2;
-    if (!is_pow2(H) || (H >> blow) < 1 || w == 0 || log2u(H) > 24) return RK_ERR_INVALID;
+    if (!is_pow2(H) || (H >> blow) < 1 || w == 0 || log2u(H) > 24 || n_points == 0 || n_points > BARY_MAX_POINTS) return RK_ERR_INVALID;
     const size_t h = H >> blow;
     const unsigned k = log2u(h);
     const uint32_t wm = ctx->sys.wm, s = ctx->sys.shiftm;
-    // (z^h - s^h) / (h s^(h-1))
-    bb::Ext zer = bb::pow(z, (uint64_t)h, wm);
-    zer.c[0] = bb::sub(zer.c[0], bb::pow(s, (uint64_t)h));
-    const uint32_t denom = bb::mul(bb::encode((uint32_t)(h % bb::P)), bb::pow(s, (uint64_t)h - 1));
-    const bb::Ext scaling = bb::scale(zer, bb::inv(denom));
+    // per point (z^h - s^h) / (h s^(h-1))
+    const uint32_t denom_inv = bb::inv(bb::mul(bb::encode((uint32_t)(h % bb::P)), bb::pow(s, (uint64_t)h - 1)));
+    BaryPoint pts[BARY_MAX_POINTS];
+    for (size_t q = 0; q < n_points; q++) {
+        std::memcpy(pts[q].z.c, h_points + 4 * q, 16);
+        bb::Ext zer = bb::pow(pts[q].z, (uint64_t)h, wm);
+        zer.c[0] = bb::sub(zer.c[0], bb::pow(s, (uint64_t)h));
+        pts[q].scaling = bb::scale(zer, denom_inv);
+    }
     const size_t rows_per_chunk = std::max<size_t>(BARY_Y * 16, (h + 1023) / 1024), chunks = (h + rows_per_chunk - 1) / rows_per_chunk;
     void* buf = nullptr;
-    RK_TRY(dev_alloc(ctx, h * 16 + chunks * w * 16, &buf));
+    RK_TRY(dev_alloc(ctx, n_points * h * 16 + chunks * n_points * w * 16 + sizeof pts, &buf));
     uint32_t* wts = (uint32_t*)buf;
-    uint32_t* partial = wts + h * 4;
-    int st;
-    {
-        KTimer kt(ctx, RK_KCLASS_POLY, (double)h * w * 4 + (double)h * 32);
-        hipLaunchKernelGGL(bary_weights_kernel, dim3((unsigned)((h + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, wts, z, h, k, s, wm, ctx->tb);
+    uint32_t* partial = wts + n_points * h * 4;
+    BaryPoint* d_pts = (BaryPoint*)(partial + chunks * n_points * w * 4);
+    int st = upload(ctx, d_pts, pts, n_points * sizeof(BaryPoint));
+    if (st == RK_OK) {
+        KTimer kt(ctx, RK_KCLASS_POLY, (double)h * w * 4 + (double)h * 32 * n_points);
+        hipLaunchKernelGGL(bary_weights_kernel, dim3((unsigned)((h + TPB - 1) / TPB), (unsigned)n_points), dim3(TPB), 0, ctx->stream, wts,
+                           (const BaryPoint*)d_pts, h, k, s, wm, ctx->tb);
         st = post_launch(ctx, "bary_weights_kernel");
         if (st == RK_OK) {
-            hipLaunchKernelGGL(bary_dot_kernel, dim3((unsigned)chunks), dim3(BARY_X, BARY_Y), 0, ctx->stream, partial, (const uint32_t*)wts,
-                               d_lde, h, w, rows_per_chunk);
+            const dim3 grid((unsigned)chunks), block(BARY_X, BARY_Y);
+            switch (n_points) {
+                case 1: hipLaunchKernelGGL(bary_dot_kernel<1>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, w, rows_per_chunk); break;
+                case 2: hipLaunchKernelGGL(bary_dot_kernel<2>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, w, rows_per_chunk); break;
+                case 3: hipLaunchKernelGGL(bary_dot_kernel<3>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, w, rows_per_chunk); break;
+                default: hipLaunchKernelGGL(bary_dot_kernel<4>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, w, rows_per_chunk); break;
+            }
             st = post_launch(ctx, "bary_dot_kernel");
         }
         if (st == RK_OK) {
-            hipLaunchKernelGGL(bary_finish_kernel, dim3((unsigned)((w + FIN_X - 1) / FIN_X)), dim3(FIN_X, FIN_Y), 0, ctx->stream, d_out_ext,
-                               (const uint32_t*)partial, chunks, w, scaling, wm);
+            hipLaunchKernelGGL(bary_finish_kernel, dim3((unsigned)((w + FIN_X - 1) / FIN_X), (unsigned)n_points), dim3(FIN_X, FIN_Y), 0, ctx->stream,
+                               d_out_ext, (const uint32_t*)partial, chunks, w, (const BaryPoint*)d_pts, (unsigned)n_points, wm);
             st = post_launch(ctx, "bary_finish_kernel");
         }
     }
@@ -275,7 +303,17 @@ int rk_pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size
     for (int i = 0; i < 4; i++)
         if (z[i] >= bb::P) return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return rk::pcs_eval_at(ctx, d_out_ext, d_lde, lde_height, width, bb::Ext{{z[0], z[1], z[2], z[3]}});
+    return rk::pcs_eval_at(ctx, d_out_ext, d_lde, lde_height, width, z, 1);
+    RK_GUARD_END
+}
+int rk_pcs_eval_at_many(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,
+                        const uint32_t* h_points) {
+    RK_GUARD_BEGIN
+    if (!ctx || !d_out_ext || !d_lde || !h_points || n_points == 0 || n_points > 4) return RK_ERR_INVALID;
+    for (uint32_t i = 0; i < 4 * n_points; i++)
+        if (h_points[i] >= bb::P) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::pcs_eval_at(ctx, d_out_ext, d_lde, lde_height, width, h_points, n_points);
     RK_GUARD_END
 }
 int rk_pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,

@@ -205,6 +205,13 @@ class HipHal:
         self._ck(self._lib.rk_pcs_eval_at(self._ctx, _ptr(out), _ptr(lde), lde_height, width, _u32p(zz)))
         return out.to_host().reshape(width, 4)
 
+    def pcs_eval_at_many(self, lde, lde_height: int, width: int, points) -> np.ndarray:
+        """opened values at up to four points in one pass over the low coset: (n_points, width, 4) words"""
+        pts = np.ascontiguousarray(points, dtype=np.uint32).reshape(-1, 4)
+        out = self.alloc_elem(pts.shape[0] * width * 4)
+        self._ck(self._lib.rk_pcs_eval_at_many(self._ctx, _ptr(out), _ptr(lde), lde_height, width, pts.shape[0], _u32p(pts)))
+        return out.to_host().reshape(pts.shape[0], width, 4)
+
     def pcs_reduce_openings(self, ro, lde, lde_height: int, width: int, points, opened, alpha, alpha_offset: int = 0):
         """ro[r] += alpha^(offset + j width) (sum_c alpha^c M[r][c] - sum_c alpha^c opened_j[c]) / (x_r - z_j), all j"""
         pts = np.ascontiguousarray(points, dtype=np.uint32).reshape(-1, 4)

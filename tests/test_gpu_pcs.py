@@ -57,6 +57,11 @@ def test_eval_at_and_reduce_openings(cfg, preset, k, w, npts):
     for j in range(npts):
         orc.or_pcs_eval_at(o.ptr(ys[j]), o.ptr(lde), Hh, w, o.ptr(zs[j]))
         assert np.array_equal(h.pcs_eval_at(d_lde, Hh, w, zs[j]), ys[j])
+    for a in range(0, npts, 4):                                   # several points per pass over the low coset
+        assert np.array_equal(h.pcs_eval_at_many(d_lde, Hh, w, zs[a:a + 4]), ys[a:a + 4])
+    for a in (1, 2, 3):
+        if a <= npts:
+            assert np.array_equal(h.pcs_eval_at_many(d_lde, Hh, w, zs[:a]), ys[:a])
     ro0 = o.rand_elems(rng, (Hh, 4))
     want = ro0.copy()
     orc.or_pcs_reduce_openings(o.ptr(want), o.ptr(lde), Hh, w, npts, o.ptr(zs), o.ptr(ys), o.ptr(alpha), 11)
@@ -137,6 +142,7 @@ def test_invalid_arguments_are_refused(cfg):
                 lambda: h.pcs_coset_lde_rows(buf, buf, 1 << 23, 1),    # LDE beyond 2^24 rows under blow-up 4
                 lambda: h.pcs_eval_at(buf, 24, 4, z),                  # LDE height not a power of two
                 lambda: h.pcs_eval_at(buf, 16, 4, np.full(4, o.P, dtype=np.uint32)),  # point not reduced
+                lambda: h.pcs_eval_at_many(buf, 16, 4, np.zeros((5, 4), np.uint32)),     # more than four points per pass
                 lambda: h.pcs_reduce_openings(buf, buf, 16, 4, np.zeros((9, 4), np.uint32), np.zeros((9, 4, 4), np.uint32), z),
                 lambda: h.pcs_reduce_openings(buf, buf, 16, 4, np.zeros((0, 4), np.uint32), np.zeros((0, 4, 4), np.uint32), z)):
         with pytest.raises(H._lib.RkError):

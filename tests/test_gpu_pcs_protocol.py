@@ -83,7 +83,7 @@ def run(h, par):
             if lh not in ro:
                 ro[lh] = h.copy_from_elem(np.zeros((1 << lh, 4), dtype=np.uint32))
                 num_reduced[lh] = 0
-            m["opened"] = np.stack([h.pcs_eval_at(m["lde"], m["H"], m["w"], z) for z in m["points"]])
+            m["opened"] = h.pcs_eval_at_many(m["lde"], m["H"], m["w"], m["points"])
             h.pcs_reduce_openings(ro[lh], m["lde"], m["H"], m["w"], m["points"], m["opened"], alpha, num_reduced[lh])
             num_reduced[lh] += m["w"] * m["npts"]
     # FRI commit phase

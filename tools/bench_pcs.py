@@ -36,6 +36,7 @@ def main():
         ys0 = h.pcs_eval_at(lde, Hh, w, z[0])
         t_eval = timed(h, lambda: h.pcs_eval_at(lde, Hh, w, z[0]))
         ys = np.stack([ys0, h.pcs_eval_at(lde, Hh, w, z[1])])
+        t_eval2 = timed(h, lambda: h.pcs_eval_at_many(lde, Hh, w, z))
         t_red = timed(h, lambda: h.pcs_reduce_openings(ro, lde, Hh, w, z, ys, alpha, 0))
         nxt = h.alloc_elem(Hh // 2 * 4)
         t_fold = timed(h, lambda: h.fri_fold_evals(nxt, ro, Hh // 2, alpha))
@@ -45,6 +46,7 @@ def main():
             "coset_lde_rows_ms": round(t_lde * 1e3, 3), "coset_lde_rows_GBps": gb((n + Hh) * w * 4, t_lde),
             "mmcs_commit_ms": round(t_mmcs * 1e3, 3),
             "eval_at_ms": round(t_eval * 1e3, 3), "eval_at_GBps": gb(n * w * 4 + n * 16, t_eval),
+            "eval_at_2pts_one_pass_ms": round(t_eval2 * 1e3, 3),
             "reduce_openings_2pts_ms": round(t_red * 1e3, 3), "reduce_openings_GBps": gb(Hh * w * 4 + Hh * 32, t_red),
             "fri_fold_evals_ms": round(t_fold * 1e3, 3), "fri_fold_evals_GBps": gb(Hh * 16 * 1.5, t_fold),
         }), flush=True)
