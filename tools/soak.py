@@ -80,8 +80,11 @@ def main():
     t0 = time.time()
     for th in threads:
         th.start()
-    for th in threads:
-        th.join()
+    while any(th.is_alive() for th in threads):          # a line a minute: a silent run looks hung to the job runner
+        for th in threads:
+            th.join(timeout=15)
+        with lock:
+            print("soak: %.0f s, %d segments, %d errors" % (time.time() - t0, sum(counts.values()), len(errors)), file=sys.stderr, flush=True)
     print(json.dumps({"what": "soak: four host threads against one GPU, every seal verified inside the library", "seconds": round(time.time() - t0, 1),
                       "segments_proven": counts, "total": sum(counts.values()), "errors": errors}))
     sys.exit(1 if errors else 0)
