@@ -161,3 +161,26 @@ def test_duplex_grind(cfg, preset, bits, n_input):
     assert h.duplex_grind(state, inputs, bits) == want
     with pytest.raises(H._lib.RkError):
         h.duplex_grind(state, o.rand_elems(rng, (width - 8,)), bits)      # a full buffer would already have been absorbed
+
+
+@pytest.mark.parametrize("blow", [1, 2, 3, 4])
+@pytest.mark.parametrize("k,w", [(1, 2), (6, 9), (16, 3)])
+def test_coset_lde_rows_other_blowups(cfg, blow, k, w):
+    """every blow-up the parameter blob allows, the smallest height, and a size that takes the fused NTT path for some
+    of them (2^16 rows: 2^18 ... 2^20 points) and the general passes for the others"""
+    h, _ = cfg
+    o.oracle_set_params(1, blowup_log2=blow)
+    h.set_params(preset=1, blowup_log2=blow)
+    orc = o.oracle()
+    rng = np.random.default_rng(900 + 10 * blow + k)
+    n = 1 << k
+    ev = o.rand_elems(rng, (n, w))
+    want = np.zeros((n << blow, w), dtype=np.uint32)
+    orc.or_pcs_coset_lde_rows(o.ptr(want), o.ptr(ev), n, w)
+    out = h.alloc_elem((n << blow) * w)
+    h.pcs_coset_lde_rows(out, h.copy_from_elem(ev), n, w)
+    assert np.array_equal(out.to_host().reshape(n << blow, w), want)
+    z = o.rand_elems(rng, (4,))
+    ys = np.zeros((w, 4), dtype=np.uint32)
+    orc.or_pcs_eval_at(o.ptr(ys), o.ptr(want), n << blow, w, o.ptr(z))
+    assert np.array_equal(h.pcs_eval_at(out, n << blow, w, z), ys)
