@@ -20,7 +20,7 @@ def pcs_inputs(key):
     ev = o.rand_elems(rng, (1 << k, w))
     zs = o.rand_elems(rng, (npts, 4))
     alpha = o.rand_elems(rng, (4,))
-    ro0 = None  # sized by the blow-up of the preset: drawn by the caller from the same generator
+    # the reduced opening's starting value is sized by the preset's blow-up: the caller draws it from the same generator
     return preset, k, w, npts, ev, zs, alpha, rng
 
 
