@@ -143,7 +143,7 @@ __global__ __launch_bounds__(RO_ROWS) void reduce_openings_kernel(uint32_t* __re
                                                                   const PcsPoint* __restrict__ pts, unsigned n_points, uint32_t shiftm,
                                                                   uint32_t wm, ntt::Tables tb) {
     __shared__ uint32_t tile[RO_ROWS][RO_COLS + 1];
-    __shared__ uint32_t ap[RO_COLS][4];
+    __shared__ __attribute__((aligned(16))) uint32_t ap[RO_COLS][4];  // one 16-byte broadcast read per column
     const unsigned tid = threadIdx.x;
     const size_t r0 = (size_t)blockIdx.x * RO_ROWS, r = r0 + tid;
     Ext acc = bb::ext_zero();
@@ -157,8 +157,11 @@ __global__ __launch_bounds__(RO_ROWS) void reduce_openings_kernel(uint32_t* __re
 #pragma unroll 8
         for (int col = 0; col < RO_COLS; col++) {
             const uint32_t m = tile[tid][col];
-#pragma unroll
-            for (int t = 0; t < 4; t++) acc.c[t] = bb::add(acc.c[t], bb::mul(ap[col][t], m));
+            const uint4 a4 = *reinterpret_cast<const uint4*>(ap[col]);
+            acc.c[0] = bb::add(acc.c[0], bb::mul(a4.x, m));
+            acc.c[1] = bb::add(acc.c[1], bb::mul(a4.y, m));
+            acc.c[2] = bb::add(acc.c[2], bb::mul(a4.z, m));
+            acc.c[3] = bb::add(acc.c[3], bb::mul(a4.w, m));
         }
         __syncthreads();
     }
