@@ -131,8 +131,8 @@ __global__ void bary_finish_kernel(uint32_t* __restrict__ out, const uint32_t* _
 
 // One lane per row.  A block takes 256 rows; the matrix goes through LDS in tiles of 256 rows x 32 columns so that
 // the global loads are 128-byte runs along the rows while every lane walks its own row (stride 33: conflict-free);
-// the powers of alpha of a tile sit next to it.  Then the lane adds its row's quotient for every point -- one
-// extension inversion per point, all lanes at once.
+// the powers of alpha of a tile sit next to it; the next tile travels from HBM into registers meanwhile.  Then the
+// lane adds its row's quotient for every point -- one extension inversion per point, all lanes at once.
 struct PcsPoint {
     Ext z, coef, rys;  // the point, alpha^(offset + j w), sum_c alpha^c p_c(z)
 };
@@ -147,13 +147,26 @@ __global__ __launch_bounds__(RO_ROWS) void reduce_openings_kernel(uint32_t* __re
     const unsigned tid = threadIdx.x;
     const size_t r0 = (size_t)blockIdx.x * RO_ROWS, r = r0 + tid;
     Ext acc = bb::ext_zero();
+    // the next tile's words are fetched into registers while the current tile is being summed out of LDS
+    constexpr int PER = RO_COLS;  // RO_ROWS * RO_COLS words / RO_ROWS lanes
+    uint32_t nxt[PER];
+    auto fetch = [&](size_t c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const unsigned e = tid + (unsigned)k * RO_ROWS, row = e / RO_COLS, col = e % RO_COLS;
+            nxt[k] = (r0 + row < H && c0 + col < w) ? M[(r0 + row) * w + c0 + col] : 0u;
+        }
+    };
+    fetch(0);
     for (size_t c0 = 0; c0 < w; c0 += RO_COLS) {
-        for (unsigned e = tid; e < RO_ROWS * RO_COLS; e += RO_ROWS) {
-            const unsigned row = e / RO_COLS, col = e % RO_COLS;
-            tile[row][col] = (r0 + row < H && c0 + col < w) ? M[(r0 + row) * w + c0 + col] : 0u;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const unsigned e = tid + (unsigned)k * RO_ROWS;
+            tile[e / RO_COLS][e % RO_COLS] = nxt[k];
         }
         if (tid < RO_COLS * 4) ap[tid >> 2][tid & 3] = (c0 + (tid >> 2) < w) ? apow[(c0 + (tid >> 2)) * 4 + (tid & 3)] : 0u;
         __syncthreads();
+        if (c0 + RO_COLS < w) fetch(c0 + RO_COLS);
 #pragma unroll 8
         for (int col = 0; col < RO_COLS; col++) {
             const uint32_t m = tile[tid][col];
