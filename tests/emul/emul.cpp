@@ -122,10 +122,11 @@ void run_nf_fwd_contig(const nf::Args& a, unsigned expand_bits) {
     std::vector<uint32_t> lds(nf::LDS_WORDS);
     for (size_t blk = 0; blk < blocks; blk++) {
         nf::CTile t = nf::ctile_of(a, blk, expand_bits);
-        if (expand_bits) {
+        if (expand_bits == 2) {
             all_lanes([&](unsigned tid) { nf::fwd_contig_a(a, g_tb, t, lds.data(), tid); });
         } else {
-            all_lanes([&](unsigned tid) { nf::fwd_contig0_a(a, g_tb, t, lds.data(), tid); });
+            if (expand_bits == 1) all_lanes([&](unsigned tid) { nf::fwd_contig1_a(a, g_tb, t, lds.data(), tid); });
+            else all_lanes([&](unsigned tid) { nf::fwd_contig0_a(a, g_tb, t, lds.data(), tid); });
             all_lanes([&](unsigned tid) { nf::fwd_contig0_b(g_tb, lds.data(), tid); });
         }
         all_lanes([&](unsigned tid) { nf::fwd_contig_b(g_tb, lds.data(), tid); });

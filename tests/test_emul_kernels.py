@@ -66,6 +66,12 @@ def test_register_blocked_passes_match_oracle(orc, emu, k, cnt):
         got_e = np.zeros((cnt, 4 * n), dtype=np.uint32)
         assert emu.emul_ntt_forward(got_e.ctypes.data, got_zk.ctypes.data, n, cnt, 2, 14, 64) == 102
         assert np.array_equal(got_e, want_e)
+    if k <= 21:      # 2x expansion (SP1's blow-up): the first round reads half a tile and broadcasts
+        want_2 = np.zeros((cnt, 2 * n), dtype=np.uint32)
+        orc.or_batch_expand_into_evaluate_ntt(want_2.ctypes.data, want_zk.ctypes.data, n, cnt, 1)
+        got_2 = np.zeros((cnt, 2 * n), dtype=np.uint32)
+        assert emu.emul_ntt_forward(got_2.ctypes.data, got_zk.ctypes.data, n, cnt, 1, 14, 64) == 102
+        assert np.array_equal(got_2, want_2)
 
 
 def test_poseidon2_many_states(orc, emu):
