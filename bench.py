@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,16,224", help="accum,code,data column counts")
@@ -206,7 +206,7 @@ def main():
                                      device_inputs=[(s18[i % 2][1], s18[i % 2][2]) for i in range(n)])
             session18(2 * inflight, False)
             torch.cuda.synchronize()
-            n18 = 4 * args.steps
+            n18 = 2 * args.steps
             t2 = time.perf_counter()
             session18(n18, not args.no_verify)
             torch.cuda.synchronize()
