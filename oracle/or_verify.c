@@ -54,6 +54,9 @@ int or_verify_segment_circuit(const or_segment* seg, const uint32_t* seal, size_
                               or_poly_ext_fn poly_ext, void* user) {
     const or_taps* taps = &seg->taps;
     if (seg->po2 < 1 || seg->po2 + g_or.blowup_log2 > 24) return -4;
+    /* read_iop: a word that is not a canonical field element (>= p) is refused -- fp_add / fp_mul are arithmetic
+     * mod p only for operands below p.  Every seal word is an element, a digest word or the small integer po2. */
+    for (size_t i = 0; i < seal_words; i++) if (seal[i] >= OR_P) return 63;
     riop r; memset(&r, 0, sizeof r);
     r.p = seal; r.len = seal_words;
     uint32_t digest[8];

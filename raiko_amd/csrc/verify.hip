@@ -92,6 +92,7 @@ Ext poly_eval(const Ext* c, size_t n, const Ext& x, uint32_t wm) {
 // RK_ERR_INVALID: malformed arguments; otherwise a positive reason code:
 //   10 header mismatch, 2x group opening failed (x = group id, 3 = check), 3x FRI round opening,
 //   4x fold inconsistency, 50 final polynomial mismatch, 60 seal too short, 61 trailing words,
+//   62 proof of work, 63 a seal word that is not a canonical field element (>= p),
 //   70 constraint identity (only with opts->poly_ext), 71 poly_ext callback failed
 int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint32_t* seal, size_t seal_words) {
     if (!pub || !seal) return RK_ERR_INVALID;
@@ -122,6 +123,12 @@ int verify_segment(const rk_segment* pub, const rk_verify_opts* opts, const uint
     const uint32_t wm = sys.wm;
     const unsigned BLOW = shape.blowup_log2, FOLD_LOG = shape.fold_log2;
     const size_t QUERIES = shape.queries, FOLD = (size_t)1 << FOLD_LOG, MIN_DEGREE = shape.min_degree, CHECK = (size_t)4 << BLOW;
+    // Every word of a seal is a field element in Montgomery form (values, digests, the nonce) or the small integer
+    // po2: the arithmetic below (bb::add / sub / mont_reduce) is arithmetic mod p only for operands < p, so a seal
+    // from elsewhere carrying a + p in place of a is refused before anything is computed from it (risc0's read_iop
+    // rejects invalid elements the same way; rk_mmcs_verify does it per opened row)
+    for (size_t i = 0; i < seal_words; i++)
+        if (seal[i] >= bb::P) return 63;
     Reader r{seal, seal_words};
     Sponge rng(&k);
     uint32_t digest[8], e16[16];

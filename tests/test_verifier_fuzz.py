@@ -50,6 +50,14 @@ def test_mutated_seals_are_rejected(preset):
             assert rc != 0, "a mutated seal verified"
             assert rc == -1 or 10 <= rc <= 71
         assert hal.verify_segment(seg, seal[:0], params=blob) != 0
+        # a + p in place of a (the same residue, another word): refused as non-canonical by both verifiers -- opened
+        # rows, coeff_u, digests and the final coefficients alike (reason 63), whatever p + a would have computed to
+        for off in rng.integers(0, seal.size, size=60):
+            s = seal.copy()
+            if int(s[off]) + o.P < (1 << 32):
+                s[off] = int(s[off]) + o.P
+                assert hal.verify_segment(seg, s, params=blob) == 63
+                assert o.oracle_verify(seg, s) == 63
     finally:
         o.oracle_set_params()
 
