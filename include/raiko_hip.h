@@ -499,6 +499,81 @@ int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint3
 const char* rk_exec_error(const rk_exec* ex);
 int rk_exec_free(rk_exec* ex);
 
+/* ---- Plonky3-style STARK for AIRs handed over as data: the proof system behind SP1's `client.setup(ELF)` /
+ * `client.prove(&pk, stdin)` (provers/sp1/driver/src/lib.rs:44-57; shard knobs docs/README_Sp1.md:19-32) as far as it
+ * exists without SP1's chips -- p3-uni-stark prove / verify over p3-fri's TwoAdicFriPcs with a DuplexChallenger
+ * (Plonky3@88ea2b8, Cargo.lock:4889-5127; RECALLED, the crates are outside the reference tree), for one or several
+ * tables under shared challenges, the way sp1-core proves the chips of a shard.  NOT here: SP1's chips, its
+ * permutation (lookup) argument, its recursion / compress VM.
+ *
+ * An AIR is a step list, the shape `Air::eval` leaves in a symbolic builder: every step except ASSERT_ZERO pushes one
+ * value; a, b name earlier values by their position in that list.
+ *   CONST a              the canonical integer a
+ *   LOCAL a / NEXT a     column a of the current / the next row (cyclic)
+ *   PUBLIC a             public value a
+ *   IS_FIRST_ROW, IS_LAST_ROW, IS_TRANSITION     the Lagrange selectors (unnormalised, as p3-commit domain.rs has them)
+ *   ADD | SUB | MUL a b, NEG a
+ *   ASSERT_ZERO a        ConstraintFolder::assert_zero: accumulator = accumulator * alpha + a
+ * rk_air_create validates, derives the quotient degree from the symbolic degrees (get_log_quotient_degree: a cell and
+ * is_first_row / is_last_row count 1, is_transition and constants 0) and translates the list into an rk_program whose
+ * taps are the columns of the LDE, so the quotient is evaluated by the same GPU evaluator as risc0's eval_check;
+ * rk_air_compile builds the straight-line kernel with hiprtc (optional, about 3x the interpreter). */
+typedef enum {
+    RK_AIR_CONST = 0, RK_AIR_LOCAL = 1, RK_AIR_NEXT = 2, RK_AIR_PUBLIC = 3, RK_AIR_IS_FIRST_ROW = 4, RK_AIR_IS_LAST_ROW = 5,
+    RK_AIR_IS_TRANSITION = 6, RK_AIR_ADD = 7, RK_AIR_SUB = 8, RK_AIR_MUL = 9, RK_AIR_NEG = 10, RK_AIR_ASSERT_ZERO = 11
+} rk_air_op;
+typedef struct { uint32_t op, a, b; } rk_air_step;
+typedef struct rk_air rk_air;
+typedef struct {
+    uint64_t n_steps;              /* as given */
+    uint64_t n_ops;                /* arithmetic steps a point of the quotient domain costs */
+    uint32_t n_constraints;
+    uint32_t max_degree;           /* symbolic degree of the highest constraint */
+    uint32_t log_quotient_degree;  /* log2_ceil(max(max_degree, 2) - 1): the quotient has 2^this chunks */
+    uint32_t n_fp_slots;           /* live intermediate values (rk_program_info) */
+} rk_air_info;
+int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, rk_air** out);
+int rk_air_destroy(rk_air* air);
+int rk_air_get_info(const rk_air* air, rk_air_info* out);
+int rk_air_compile(rk_air* air, rk_ctx* ctx);
+/* One table of a proof.  trace: row-major 2^log_height x width Montgomery words (Plonky3's RowMajorMatrix), in host
+ * memory or -- on_device = 1 -- in the memory of the context's GPU (left untouched). */
+typedef struct {
+    const uint32_t* trace;
+    uint32_t log_height;           /* 1 .. 24 - blowup_log2; the verifier reads it from the proof */
+    uint32_t width;                /* = the AIR's */
+    const rk_air* air;
+    const uint32_t* public_values; /* host, Montgomery words */
+    uint32_t n_public;             /* = the AIR's */
+    uint32_t on_device;
+} rk_p3_table;
+/* p3-uni-stark `prove` under the context's parameter set (rk_set_params: field, coset shift = Val::generator(), Poseidon2
+ * instance, blowup_log2 = FriConfig::log_blowup, queries, pow_bits; fri_fold_log2 / fri_min_degree are not used -- the
+ * PCS folds by two down to a constant).  Every table's quotient degree must fit the blow-up.  Transcript:
+ * observe(init_words) -- whatever binds the statement: SP1 observes the verifying key and pc_start there --,
+ * observe(trace root), observe(public values of every table), alpha, observe(quotient root), zeta, then the PCS's own
+ * challenges.  Proof = u32 words (field elements as Montgomery words):
+ *   n_tables | log_height per table | trace root 8 | quotient root 8 |
+ *   per table: opened trace row at zeta (4 words per column), at zeta * g, 2^log_quotient_degree chunks x 4 x 4 |
+ *   n_rounds | n_rounds x 8 commit-phase roots | final polynomial 4 | proof-of-work witness (canonical integer) |
+ *   per query: the trace batch (every table's LDE row, then the Merkle path), the quotient batch (every chunk's row,
+ *   then the path), then per FRI round the sibling value (4) and its path.
+ * RK_ERR_CAPACITY with *proof_words = the exact size when the buffer is too small.  A trace that breaks its AIR still
+ * yields a proof (as in Plonky3's release builds); rk_p3_verify rejects it with reason 3. */
+int rk_p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
+                uint32_t* h_proof, size_t capacity_words, size_t* proof_words);
+/* p3-uni-stark `verify` on the host (no GPU): params NULL = the SP1 preset; trace / log_height / on_device of the tables
+ * are ignored.  0 = accepted, RK_ERR_INVALID for malformed arguments, otherwise a reason: 1 malformed proof (short,
+ * trailing or non-canonical words), 2 shape mismatch, 3 constraint identity (OodEvaluationMismatch), 4 proof of work,
+ * 5 input opening, 6 commit-phase opening, 7 final polynomial. */
+int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
+                 const uint32_t* proof, size_t proof_words);
+/* exact proof size for the tables' shapes (log_height, width, air); 0 for shapes rk_p3_prove rejects */
+size_t rk_p3_proof_bound_words(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables);
+/* wall-clock per stage of the last rk_p3_prove on this ctx, milliseconds (the stream is drained at every boundary) */
+typedef struct { float lde, commit, quotient, open, fri, query, total; } rk_p3_timing;
+int rk_p3_last_timing(rk_ctx* ctx, rk_p3_timing* out);
+
 /* per-stage device time of the last rk_prove_segment on this ctx, milliseconds (hipEvent) */
 typedef struct { float ntt, hash, deep, fri, query, total, circuit /* time inside rk_circuit_hooks */; } rk_timing;
 int rk_last_timing(rk_ctx* ctx, rk_timing* out);

@@ -210,6 +210,24 @@ typedef struct { const fp* values; uint32_t height, width, row_major; } or_matri
 void or_mmcs_commit(const or_matrix* mats, uint32_t n, uint32_t* nodes /* 2 * H digests, heap order */);
 int or_mmcs_verify(const uint32_t* heights, const uint32_t* widths, uint32_t n, uint32_t index, const fp* rows, const uint32_t* path,
                    const uint32_t* root);
+/* ---- Plonky3 uni-stark over the two-adic FRI PCS, one or several tables (oracle/or_p3.c): the checker of
+ * rk_p3_prove / rk_p3_verify.  An AIR is a step list: every step but ASSERT_ZERO pushes one value; a, b name
+ * earlier values (CONST: a = canonical integer; LOCAL / NEXT: a = column; PUBLIC: a = index). ---- */
+enum { OR_AIR_CONST = 0, OR_AIR_LOCAL = 1, OR_AIR_NEXT = 2, OR_AIR_PUBLIC = 3, OR_AIR_IS_FIRST_ROW = 4, OR_AIR_IS_LAST_ROW = 5,
+       OR_AIR_IS_TRANSITION = 6, OR_AIR_ADD = 7, OR_AIR_SUB = 8, OR_AIR_MUL = 9, OR_AIR_NEG = 10, OR_AIR_ASSERT_ZERO = 11 };
+typedef struct { uint32_t op, a, b; } or_air_step;
+typedef struct { const or_air_step* steps; size_t n_steps; } or_air;
+typedef struct {
+    const fp* trace;               /* row-major 2^log_height x width (prover only) */
+    uint32_t log_height, width;    /* the verifier takes log_height from the proof */
+    const or_air* air;
+    const fp* public_values; uint32_t n_public;
+} or_p3_table;
+int or_air_log_quotient_degree(const or_air* air);
+/* 0 and a malloc'd proof (or_free), or < 0: -1 malformed input, -2 quotient degree above the blow-up,
+ * -3 the witness does not satisfy the AIR (the folded quotient is not low-degree), -4 proof of work */
+int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, size_t n_init, uint32_t** proof, size_t* words);
+int or_p3_verify(const or_p3_table* tables, uint32_t n_tables, const fp* init, size_t n_init, const uint32_t* proof, size_t words);
 void or_free(void* p);
 int or_max_threads(void);
 void or_set_threads(int n);

@@ -42,6 +42,20 @@ pub const RK_STEP_TRUE: rk_step_op = 6;
 pub const RK_STEP_AND_EQZ: rk_step_op = 7;
 pub const RK_STEP_AND_COND: rk_step_op = 8;
 
+pub type rk_air_op = c_int;
+pub const RK_AIR_CONST: rk_air_op = 0;
+pub const RK_AIR_LOCAL: rk_air_op = 1;
+pub const RK_AIR_NEXT: rk_air_op = 2;
+pub const RK_AIR_PUBLIC: rk_air_op = 3;
+pub const RK_AIR_IS_FIRST_ROW: rk_air_op = 4;
+pub const RK_AIR_IS_LAST_ROW: rk_air_op = 5;
+pub const RK_AIR_IS_TRANSITION: rk_air_op = 6;
+pub const RK_AIR_ADD: rk_air_op = 7;
+pub const RK_AIR_SUB: rk_air_op = 8;
+pub const RK_AIR_MUL: rk_air_op = 9;
+pub const RK_AIR_NEG: rk_air_op = 10;
+pub const RK_AIR_ASSERT_ZERO: rk_air_op = 11;
+
 pub type rk_kclass = c_int;
 pub const RK_KCLASS_HASH_ROWS: rk_kclass = 0;
 pub const RK_KCLASS_HASH_FOLD: rk_kclass = 1;
@@ -53,6 +67,11 @@ pub const RK_KCLASS_COUNT: rk_kclass = 5;
 pub const RK_MAX_QUERIES: u32 = 256;
 pub const RK_TRACE_CODE_COLS: u32 = 2;
 pub const RK_TRACE_DATA_COLS: u32 = 16;
+
+#[repr(C)]
+pub struct rk_air {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 pub struct rk_ctx {
@@ -242,6 +261,49 @@ pub struct rk_exec_segment {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct rk_air_step {
+    pub op: u32,
+    pub a: u32,
+    pub b: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_air_info {
+    pub n_steps: u64,
+    pub n_ops: u64,
+    pub n_constraints: u32,
+    pub max_degree: u32,
+    pub log_quotient_degree: u32,
+    pub n_fp_slots: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_p3_table {
+    pub trace: *const u32,
+    pub log_height: u32,
+    pub width: u32,
+    pub air: *const rk_air,
+    pub public_values: *const u32,
+    pub n_public: u32,
+    pub on_device: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_p3_timing {
+    pub lde: f32,
+    pub commit: f32,
+    pub quotient: f32,
+    pub open: f32,
+    pub fri: f32,
+    pub query: f32,
+    pub total: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct rk_timing {
     pub ntt: f32,
     pub hash: f32,
@@ -335,6 +397,14 @@ extern "C" {
     pub fn rk_exec_witness_device(ctx: *mut rk_ctx, ex: *const rk_exec, index: u32, d_code: *mut u32, d_data: *mut u32) -> c_int;
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
+    pub fn rk_air_create(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, out: *mut *mut rk_air) -> c_int;
+    pub fn rk_air_destroy(air: *mut rk_air) -> c_int;
+    pub fn rk_air_get_info(air: *const rk_air, out: *mut rk_air_info) -> c_int;
+    pub fn rk_air_compile(air: *mut rk_air, ctx: *mut rk_ctx) -> c_int;
+    pub fn rk_p3_prove(ctx: *mut rk_ctx, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, h_proof: *mut u32, capacity_words: usize, proof_words: *mut usize) -> c_int;
+    pub fn rk_p3_verify(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, proof: *const u32, proof_words: usize) -> c_int;
+    pub fn rk_p3_proof_bound_words(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32) -> usize;
+    pub fn rk_p3_last_timing(ctx: *mut rk_ctx, out: *mut rk_p3_timing) -> c_int;
     pub fn rk_last_timing(ctx: *mut rk_ctx, out: *mut rk_timing) -> c_int;
     pub fn rk_set_kernel_timing(ctx: *mut rk_ctx, enabled: c_int) -> c_int;
     pub fn rk_kernel_stats(ctx: *mut rk_ctx, kclass: c_int, out: *mut rk_kernel_stat) -> c_int;

@@ -627,7 +627,7 @@ mod test {
     /// The reference's own smoke test shape (provers/risc0/driver/src/lib.rs:131-137): prove, then verify.
     #[test]
     fn abi_matches_and_a_gpu_is_visible() {
-        assert_eq!(unsafe { rk_abi_version() }, 3);
+        assert_eq!(unsafe { rk_abi_version() }, 4);
         let mut n = 0;
         assert_eq!(unsafe { rk_device_count(&mut n) }, RK_OK);
         assert!(n > 0, "no MI355X visible: the hip backend has no CPU fallback");

@@ -119,6 +119,20 @@ class RkTiming(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ntt", "hash", "deep", "fri", "query", "total", "circuit")]
 
 
+class RkAirInfo(C.Structure):
+    _fields_ = [("n_steps", C.c_uint64), ("n_ops", C.c_uint64), ("n_constraints", C.c_uint32), ("max_degree", C.c_uint32),
+                ("log_quotient_degree", C.c_uint32), ("n_fp_slots", C.c_uint32)]
+
+
+class RkP3Table(C.Structure):
+    _fields_ = [("trace", C.c_void_p), ("log_height", C.c_uint32), ("width", C.c_uint32), ("air", C.c_void_p),
+                ("public_values", u32p), ("n_public", C.c_uint32), ("on_device", C.c_uint32)]
+
+
+class RkP3Timing(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("lde", "commit", "quotient", "open", "fri", "query", "total")]
+
+
 class RkExecOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("segment_limit_po2", C.c_uint32), ("session_limit", C.c_uint64),
                 ("input_words", u32p), ("n_input_words", C.c_size_t), ("record_trace", C.c_uint32)]
@@ -215,6 +229,14 @@ SYMBOLS = {
     "rk_program_compile": (C.c_int, [_vp, _vp]),
     "rk_program_source": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "rk_program_poly_ext": (C.c_int, [_vp, _u32, u32p, u32p, _sz, u32p, _u32, u32p, _u32, u32p]),
+    "rk_air_create": (C.c_int, [_vp, _sz, _u32, _u32, C.POINTER(_vp)]),
+    "rk_air_destroy": (C.c_int, [_vp]),
+    "rk_air_get_info": (C.c_int, [_vp, C.POINTER(RkAirInfo)]),
+    "rk_air_compile": (C.c_int, [_vp, _vp]),
+    "rk_p3_prove": (C.c_int, [_vp, C.POINTER(RkP3Table), _u32, u32p, _sz, u32p, _sz, C.POINTER(_sz)]),
+    "rk_p3_verify": (C.c_int, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32, u32p, _sz, u32p, _sz]),
+    "rk_p3_proof_bound_words": (_sz, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32]),
+    "rk_p3_last_timing": (C.c_int, [_vp, C.POINTER(RkP3Timing)]),
     "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
     "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),
 }

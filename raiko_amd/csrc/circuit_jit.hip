@@ -33,11 +33,13 @@ constexpr uint32_t NONE = rk::PROGRAM_NONE;
 // what the generated kernel receives (same layout as `struct Args` in the source below)
 struct JitArgs {
     const uint32_t* lde[3];
+    uint64_t len[3];     // words per column of each group
     uint64_t tab;        // globals | accum mix | powers (4 words each)
     uint32_t* check;
     uint64_t d;
     uint32_t glob_base, mix_base, pw_base, wm;
-    uint32_t blow, pad;
+    uint32_t blow, split;   // log2 (domain / trace rows); the result leaves in 2^split chunks (rk::EvalDomain)
+    uint32_t str[3], pad;   // point i of the domain is element i << str[g] of a column of group g
     uint32_t inv_den[16];
 };
 
@@ -78,11 +80,13 @@ RK_FI Ext mul(const Ext& a, const Ext& b, u32 wm) {
 using bb::Ext;
 struct Args {
     const u32* lde[3];
+    u64 len[3];
     u64 tab;
     u32* check;
     u64 d;
     u32 glob_base, mix_base, pw_base, wm;
-    u32 blow, pad;
+    u32 blow, split;
+    u32 str[3], pad;
     u32 inv_den[16];
 };
 RK_FI Ext load_pw(const_u32 tab, u32 base, u32 j) {
@@ -221,9 +225,10 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
                 body << "    const u32 " << nm << " = " << bb::encode(v.a) << "u;\n";
             } else if (v.op == RK_STEP_GET) {
                 const rk::Tap& t = pg.taps[v.a];
-                body << "    const u32 " << nm << " = a.lde[" << t.group << "][(u64)" << t.offset << "u * a.d + ";
-                if (t.back == 0) body << "i];\n";
-                else body << "((i + a.d - ((u64)" << t.back << "u << a.blow)) & (a.d - 1))];\n";
+                body << "    const u32 " << nm << " = a.lde[" << t.group << "][(u64)" << t.offset << "u * a.len[" << t.group << "] + (";
+                if (t.back == 0) body << "i";
+                else body << "((i + a.d - ((u64)" << t.back << "u << a.blow)) & (a.d - 1))";
+                body << " << a.str[" << t.group << "])];\n";
             } else if (v.op == RK_STEP_GET_GLOBAL) {
                 body << "    const u32 " << nm << " = tab[a." << (v.a == 0 ? "glob_base" : "mix_base") << " + " << v.b << "u];\n";
             } else {
@@ -294,7 +299,8 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
     for (const std::string& call : calls) src << call;
     src << "    const Ext tot = bb::scale(" << (ret_zero ? std::string("bb::ext_zero()") : "cx[" + std::to_string(mx_slot[ret_name]) + "]")
         << ", a.inv_den[i & ((1u << a.blow) - 1)]);\n"
-        << "    for (int e = 0; e < 4; e++) a.check[(u64)e * a.d + i] = tot.c[e];\n"
+        << "    const u64 rows = a.d >> a.split, at = (i & ((1u << a.split) - 1)) * 4 * rows + (i >> a.split);\n"
+        << "    for (int e = 0; e < 4; e++) a.check[at + (u64)e * rows] = tot.c[e];\n"
         << "}\n";
     return src.str();
 }
@@ -310,14 +316,19 @@ const JitEntry* program_jit(rk_program* pg, int device) {
     return it == pg->jit.end() ? nullptr : &it->second;
 }
 
-int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const rk_circuit_view* v, const uint32_t* d_tab, uint32_t glob_base,
+int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const EvalDomain& v, const uint32_t* d_tab, uint32_t glob_base,
                        uint32_t mix_base, uint32_t pw_base, uint32_t* d_check, const uint32_t inv_den[16]) {
-    const unsigned blow = ctx->sys.blowup_log2;
+    const unsigned blow = v.ratio_log2;
     JitArgs a{};
-    for (int g = 0; g < 3; g++) a.lde[g] = v->d_lde[g];
+    for (int g = 0; g < 3; g++) {
+        a.lde[g] = v.d_cols[g];
+        a.len[g] = v.col_len[g];
+        a.str[g] = v.stride_log2[g];
+    }
+    a.split = v.split_log2;
     a.tab = (uint64_t)(uintptr_t)d_tab;
     a.check = d_check;
-    a.d = (uint64_t)1 << (v->po2 + blow);
+    a.d = (uint64_t)1 << (v.po2 + blow);
     a.glob_base = glob_base;
     a.mix_base = mix_base;
     a.pw_base = pw_base;

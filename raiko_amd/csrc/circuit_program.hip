@@ -333,14 +333,15 @@ struct EvalArgs {
     uint64_t code;       // uint4 per op
     uint64_t consts;     // program constants | globals | accum mix
     uint64_t powers;     // 4 words per distinct power of poly_mix
-    uint64_t taps;       // uint4 per tap: column base (64-bit), shift in points, 0
+    uint64_t taps;       // uint4 per tap: column base (64-bit), shift in points, log2 of the column's stride per point
     uint32_t* spill;
     uint32_t* check;
     size_t d;
     uint32_t n_ops, glob_base, mix_base;
     uint32_t lds_fp, lds_mix, n_fp_slots;
     uint32_t ret_slot, wm;
-    uint32_t blow;       // log2 of the blow-up
+    uint32_t blow;       // log2 of (domain size / trace rows)
+    uint32_t split;      // the result leaves in 2^split chunks (EvalDomain::split_log2)
     uint32_t inv_den[16];
 };
 
@@ -366,8 +367,8 @@ struct Lane {
             const char* col = reinterpret_cast<const char*>(((uint64_t)t.y << 32) | t.x);
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const uint32_t off = ((uint32_t)i + p * NL + (uint32_t)a.d - t.z) & ((uint32_t)a.d - 1);
-                out[p] = *reinterpret_cast<const uint32_t*>(col + (off << 2));
+                const uint32_t off = (((uint32_t)i + p * NL + (uint32_t)a.d - t.z) & ((uint32_t)a.d - 1)) << t.w;
+                out[p] = *reinterpret_cast<const uint32_t*>(col + ((size_t)off << 2));
             }
         } else if (kind == K_SPILL) {
 #pragma unroll
@@ -473,8 +474,9 @@ __global__ __launch_bounds__(WG / P) void program_kernel(EvalArgs a) {
     for (int p = 0; p < P; p++) {
         const size_t pt = i + p * NL;
         const Ext r = bb::scale(tot[p], a.inv_den[pt & ((1u << a.blow) - 1)]);
+        const size_t rows = a.d >> a.split, at = (pt & ((1u << a.split) - 1)) * 4 * rows + (pt >> a.split);
 #pragma unroll
-        for (int e = 0; e < 4; e++) a.check[(size_t)e * a.d + pt] = r.c[e];
+        for (int e = 0; e < 4; e++) a.check[at + (size_t)e * rows] = r.c[e];
     }
 }
 
@@ -502,37 +504,70 @@ int device_code(rk_program* pg, rk_ctx* ctx, const uint4** out) {
 
 namespace rk {
 
+void program_power_table(const rk_program* pg, const std::vector<uint32_t>& powers, const uint32_t poly_mix[4], uint32_t wm, uint32_t* out) {
+    Ext pm, cur = bb::ext_one();
+    std::memcpy(pm.c, poly_mix, 16);
+    const size_t npw = powers.size();
+    const uint32_t top = pg->horner ? pg->info.max_power - 1 : 0;   // Horner: exponent e stands for top - e
+    uint32_t at = 0;
+    for (size_t t = 0; t < npw; t++) {  // ascending effective exponents: one running power
+        const size_t j = pg->horner ? npw - 1 - t : t;
+        const uint32_t e = pg->horner ? top - powers[j] : powers[j];
+        cur = bb::mul(cur, bb::pow(pm, e - at, wm), wm);
+        at = e;
+        std::memcpy(out + 4 * j, cur.c, 16);
+    }
+}
+
 int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const uint32_t poly_mix[4], uint32_t* d_check) {
-    rk_program* pg = const_cast<rk_program*>(cprog);  // the device copy of the op list is cached inside
-    if (!pg || !v || !v->ctx || !poly_mix || !d_check) return RK_ERR_INVALID;
-    rk_ctx* ctx = v->ctx;
-    const unsigned blow = ctx->sys.blowup_log2;
+    if (!cprog || !v || !v->ctx || !poly_mix || !d_check) return RK_ERR_INVALID;
+    const unsigned blow = v->ctx->sys.blowup_log2;
     if (v->po2 < 1 || v->po2 + blow > ntt::LAMBDA) return RK_ERR_INVALID;
-    if (v->n_globals < pg->need_globals || v->n_mix < pg->need_mix) return RK_ERR_INVALID;
-    if ((v->n_globals && !v->globals) || (v->n_mix && !v->mix)) return RK_ERR_INVALID;
+    EvalDomain dom;
+    dom.ctx = v->ctx;
+    dom.po2 = v->po2;
+    dom.ratio_log2 = blow;
+    for (int g = 0; g < 3; g++) {
+        dom.d_cols[g] = v->d_lde[g];
+        dom.group_size[g] = v->group_size[g];
+        dom.col_len[g] = (uint64_t)1 << (v->po2 + blow);
+    }
+    dom.globals = v->globals;
+    dom.n_globals = v->n_globals;
+    dom.mix = v->mix;
+    dom.n_mix = v->n_mix;
+    return program_eval_domain(cprog, dom, poly_mix, d_check);
+}
+
+int program_eval_domain(const rk_program* cprog, const EvalDomain& v, const uint32_t poly_mix[4], uint32_t* d_check) {
+    rk_program* pg = const_cast<rk_program*>(cprog);  // the device copy of the op list is cached inside
+    if (!pg || !v.ctx || !poly_mix || !d_check) return RK_ERR_INVALID;
+    rk_ctx* ctx = v.ctx;
+    const unsigned blow = v.ratio_log2;
+    if (v.po2 < 1 || blow > 4 || v.po2 + blow > ntt::LAMBDA || v.split_log2 > blow) return RK_ERR_INVALID;
+    if (v.n_globals < pg->need_globals || v.n_mix < pg->need_mix) return RK_ERR_INVALID;
+    if ((v.n_globals && !v.globals) || (v.n_mix && !v.mix)) return RK_ERR_INVALID;
+    const size_t n = (size_t)1 << v.po2, d = n << blow;
     for (int g = 0; g < 3; g++)
-        if (pg->group_min[g] && (!v->d_lde[g] || v->group_size[g] < pg->group_min[g])) return RK_ERR_INVALID;
+        if (pg->group_min[g] && (!v.d_cols[g] || v.group_size[g] < pg->group_min[g] || v.stride_log2[g] > 8 ||
+                                 v.col_len[g] < (d << v.stride_log2[g])))
+            return RK_ERR_INVALID;
     RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n = (size_t)1 << v->po2, d = n << blow;
     const uint32_t wm = ctx->sys.wm;
+    // x_i^N for x_i = shift * w_d^i takes d/N values: shift^N * w_(d/N)^(i mod d/N)
+    uint32_t inv_den[16] = {0};
+    {
+        const uint32_t sn = bb::pow(ctx->sys.shiftm, n), wb = bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - blow));
+        for (unsigned r = 0; r < (1u << blow); r++) inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(wb, r)), bb::ONE));
+    }
 
     if (const JitEntry* je = program_jit(pg, ctx->device)) {
         // the generated kernel (rk_program_compile): table = globals | mix | the powers its code indexes
-        const size_t o_mix = v->n_globals, o_pw = (o_mix + v->n_mix + 3) & ~(size_t)3, words = o_pw + 4 * (size_t)je->n_powers;
+        const size_t o_mix = v.n_globals, o_pw = (o_mix + v.n_mix + 3) & ~(size_t)3, words = o_pw + 4 * (size_t)je->n_powers;
         std::vector<uint32_t> tab(words + 4, 0);
-        if (v->n_globals) std::memcpy(tab.data(), v->globals, (size_t)v->n_globals * 4);
-        if (v->n_mix) std::memcpy(&tab[o_mix], v->mix, (size_t)v->n_mix * 4);
-        Ext pm, cur = bb::ext_one();
-        std::memcpy(pm.c, poly_mix, 16);
-        uint32_t at = 0;
-        for (uint32_t j = 0; j < je->n_powers; j++) {
-            cur = bb::mul(cur, bb::pow(pm, je->powers[j] - at, wm), wm);
-            at = je->powers[j];
-            std::memcpy(&tab[o_pw + 4 * j], cur.c, 16);
-        }
-        uint32_t inv_den[16] = {0};
-        const uint32_t sn = bb::pow(ctx->sys.shiftm, n), wb = bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - blow));
-        for (unsigned r = 0; r < (1u << blow); r++) inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(wb, r)), bb::ONE));
+        if (v.n_globals) std::memcpy(tab.data(), v.globals, (size_t)v.n_globals * 4);
+        if (v.n_mix) std::memcpy(&tab[o_mix], v.mix, (size_t)v.n_mix * 4);
+        program_power_table(pg, je->powers, poly_mix, wm, &tab[o_pw]);
         void* d_tab = nullptr;
         RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
         RK_HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -545,30 +580,22 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     a.code = (uint64_t)(uintptr_t)d_ops;
     // per-proof tables in one upload: constants | globals | mix | powers | taps
     const size_t nc = pg->consts.size(), npw = pg->powers.size(), ntap = pg->taps.size();
-    const size_t o_glob = nc, o_mix = o_glob + v->n_globals, o_pw = (o_mix + v->n_mix + 3) & ~(size_t)3;
+    const size_t o_glob = nc, o_mix = o_glob + v.n_globals, o_pw = (o_mix + v.n_mix + 3) & ~(size_t)3;
     const size_t o_tap = o_pw + 4 * npw, words = o_tap + 4 * ntap;
     std::vector<uint32_t> pack(words + 4, 0);
     std::memcpy(pack.data(), pg->consts.data(), nc * 4);
-    if (v->n_globals) std::memcpy(&pack[o_glob], v->globals, (size_t)v->n_globals * 4);
-    if (v->n_mix) std::memcpy(&pack[o_mix], v->mix, (size_t)v->n_mix * 4);
-    {
-        Ext pm, cur = bb::ext_one();
-        std::memcpy(pm.c, poly_mix, 16);
-        uint32_t at = 0;
-        for (size_t j = 0; j < npw; j++) {  // ascending exponents: one running power
-            cur = bb::mul(cur, bb::pow(pm, pg->powers[j] - at, wm), wm);
-            at = pg->powers[j];
-            std::memcpy(&pack[o_pw + 4 * j], cur.c, 16);
-        }
-    }
+    if (v.n_globals) std::memcpy(&pack[o_glob], v.globals, (size_t)v.n_globals * 4);
+    if (v.n_mix) std::memcpy(&pack[o_mix], v.mix, (size_t)v.n_mix * 4);
+    program_power_table(pg, pg->powers, poly_mix, wm, &pack[o_pw]);
     for (size_t t = 0; t < ntap; t++) {  // a tap `back` rows behind is back << blow points behind
         const Tap& tp = pg->taps[t];
         uint64_t col = 0;
-        if (tp.group < 3 && v->d_lde[tp.group] && tp.offset < v->group_size[tp.group])
-            col = (uint64_t)(uintptr_t)(v->d_lde[tp.group] + (size_t)tp.offset * d);
+        if (tp.group < 3 && v.d_cols[tp.group] && tp.offset < v.group_size[tp.group])
+            col = (uint64_t)(uintptr_t)(v.d_cols[tp.group] + (size_t)tp.offset * v.col_len[tp.group]);
         pack[o_tap + 4 * t] = (uint32_t)col;
         pack[o_tap + 4 * t + 1] = (uint32_t)(col >> 32);
         pack[o_tap + 4 * t + 2] = (uint32_t)((((size_t)tp.back) << blow) & (d - 1));
+        pack[o_tap + 4 * t + 3] = tp.group < 3 ? v.stride_log2[tp.group] : 0u;
     }
     void* d_pack = nullptr;
     RK_TRY(scratch(ctx, words * 4 + 16, &d_pack));
@@ -588,10 +615,9 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
     a.n_fp_slots = pg->n_fp_slots;
     a.ret_slot = pg->ret_slot;
     a.wm = wm;
-    // x_i^N for x_i = shift * w_D^i takes D/N values: shift^N * w_(D/N)^(i mod D/N)
     a.blow = blow;
-    const uint32_t sn = bb::pow(ctx->sys.shiftm, n), wb = bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - blow));
-    for (unsigned r = 0; r < (1u << blow); r++) a.inv_den[r] = bb::inv(bb::sub(bb::mul(sn, bb::pow(wb, r)), bb::ONE));
+    a.split = v.split_log2;
+    std::memcpy(a.inv_den, inv_den, sizeof a.inv_den);
     const size_t spill_words = ((size_t)(pg->n_fp_slots - a.lds_fp) + 4 * (size_t)(pg->n_mix_slots - a.lds_mix)) * d;
     void* d_spill = nullptr;
     if (spill_words) RK_TRY(dev_alloc(ctx, spill_words * 4, &d_spill));
@@ -603,7 +629,7 @@ int program_eval_check(const rk_program* cprog, const rk_circuit_view* v, const 
         hipLaunchKernelGGL(program_kernel<1>, dim3((unsigned)((d + WG - 1) / WG)), dim3(WG), lds_bytes, ctx->stream, a);
     int rc = post_launch(ctx, "program_kernel");
     if (d_spill) {
-        int fr = dev_free(ctx, d_spill);  // drains the stream first
+        int fr = dev_free(ctx, d_spill);  // stream-ordered: the block is reused only by later work of this stream
         if (rc == RK_OK) rc = fr;
     }
     return rc;
@@ -618,6 +644,7 @@ int program_poly_ext(const rk_program* pg, uint32_t wm, const uint32_t poly_mix[
     const Ext* u = reinterpret_cast<const Ext*>(eval_u_ext);
     Ext pm;
     std::memcpy(pm.c, poly_mix, 16);
+    const Ext pm_inv = pg->horner ? bb::inv(pm, wm) : bb::ext_one();
     struct Mix {
         Ext tot, mul;
     };
@@ -647,12 +674,12 @@ int program_poly_ext(const rk_program* pg, uint32_t wm, const uint32_t poly_mix[
             case RK_STEP_MUL:
                 fp.push_back(bb::mul(fp[st.a], fp[st.b], wm));
                 break;
-            case RK_STEP_TRUE:
-                mx.push_back(Mix{bb::ext_zero(), bb::ext_one()});
+            case RK_STEP_TRUE:  // Horner-ordered chain: mul starts at mix^(K-1) and goes down
+                mx.push_back(Mix{bb::ext_zero(), pg->horner ? bb::pow(pm, pg->info.max_power - 1, wm) : bb::ext_one()});
                 break;
             case RK_STEP_AND_EQZ: {
                 const Mix x = mx[st.a];
-                mx.push_back(Mix{bb::add(x.tot, bb::mul(x.mul, fp[st.b], wm)), bb::mul(x.mul, pm, wm)});
+                mx.push_back(Mix{bb::add(x.tot, bb::mul(x.mul, fp[st.b], wm)), bb::mul(x.mul, pg->horner ? pm_inv : pm, wm)});
                 break;
             }
             case RK_STEP_AND_COND: {
@@ -668,6 +695,26 @@ int program_poly_ext(const rk_program* pg, uint32_t wm, const uint32_t poly_mix[
     return RK_OK;
 }
 
+}  // namespace rk
+
+namespace rk {
+// a program over an explicit tap list (no rk_taps behind it): what the AIR front end of p3.hip builds.  A Horner-ordered
+// list must be a single AND_EQZ chain (no AND_COND): the exponent reversal is defined on that shape only.
+int program_create_raw(const rk_poly_step* steps, size_t n_steps, uint32_t ret, std::vector<Tap>&& taps, bool horner, rk_program** out) {
+    if (!out || !steps || n_steps == 0 || n_steps > ((size_t)1 << 28) || taps.size() > IDX_MASK) return RK_ERR_INVALID;
+    if (horner)
+        for (size_t s = 0; s < n_steps; s++)
+            if (steps[s].op == RK_STEP_AND_COND) return RK_ERR_INVALID;
+    std::unique_ptr<rk_program> pg(new rk_program);
+    pg->steps.assign(steps, steps + n_steps);
+    pg->ret = ret;
+    pg->horner = horner;
+    pg->taps = std::move(taps);
+    RK_TRY(compile(pg.get()));
+    if (horner && pg->info.max_power == 0) pg->horner = false;  // no constraint at all: nothing to reverse
+    *out = pg.release();
+    return RK_OK;
+}
 }  // namespace rk
 
 extern "C" {

@@ -195,7 +195,7 @@ static int upload_p2(rk_ctx* ctx) {
 
 extern "C" {
 
-int rk_abi_version(void) { return 3; }
+int rk_abi_version(void) { return 4; }
 
 const char* rk_strerror(int s) {
     switch (s) {

@@ -46,6 +46,7 @@ struct rk_ctx {
     bool h_ring_failed = false;
 
     rk_timing timing{};
+    rk_p3_timing p3_timing{};
     std::vector<hipEvent_t> stage_events;            // pool behind the per-stage brackets of prove_segment
 
     // optional per-kernel-class timing (hipEvent pairs on the ctx stream, resolved lazily)
@@ -176,7 +177,11 @@ int program_poly_ext(const rk_program* prog, uint32_t wm, const uint32_t poly_mi
                      const uint32_t* globals, uint32_t n_globals, const uint32_t* mix, uint32_t n_mix, uint32_t out_ext[4]);
 // d_ext[idx[i]] -= delta[i]
 // Plonky3 two-adic PCS steps on row-major matrices (kernels_pcs.hip)
-int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t h, size_t w);
+// keep_cols != nullptr: *keep_cols receives the column-major natural-order evaluations (w columns of h << blow-up
+// words, a dev_alloc'd block the caller frees) the rows were transposed from
+int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t h, size_t w, uint32_t** keep_cols = nullptr);
+// column-major w columns of H words (natural order) -> row-major H x w with row bitrev(j) = index j
+int pcs_cols_to_rows_bitrev(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_cols, size_t H, size_t w);
 int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const uint32_t* h_points, size_t n_points);
 int pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t H, size_t w, size_t n_points,
                         const uint32_t* h_points, const uint32_t* h_ys, const bb::Ext& alpha, uint64_t alpha_offset);

@@ -193,7 +193,15 @@ __global__ __launch_bounds__(RO_ROWS) void reduce_openings_kernel(uint32_t* __re
 
 namespace rk {
 
-int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t h, size_t w) {
+int pcs_cols_to_rows_bitrev(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_cols, size_t H, size_t w) {
+    if (!is_pow2(H) || w == 0 || log2u(H) > ntt::LAMBDA) return RK_ERR_INVALID;
+    KTimer kt(ctx, RK_KCLASS_BIT_REVERSE, (double)H * w * 8);
+    hipLaunchKernelGGL(cols_to_rows_bitrev_kernel, dim3((unsigned)((H + TT - 1) / TT), (unsigned)((w + TT - 1) / TT)), dim3(TT, 8), 0,
+                       ctx->stream, d_out, d_cols, H, w, log2u(H));
+    return post_launch(ctx, "cols_to_rows_bitrev_kernel");
+}
+
+int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t h, size_t w, uint32_t** keep_cols) {
     const unsigned blow = ctx->sys.blowup_log2;
     if (!is_pow2(h) || h < 2 || w == 0 || log2u(h) + blow > 24) return RK_ERR_INVALID;
     const size_t H = h << blow;
@@ -210,13 +218,9 @@ int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_
     // coset of the larger subgroup -- the same two calls a risc0 trace group goes through
     if (st == RK_OK) st = ntt_reverse(ctx, (uint32_t*)a, h, w, /*fuse_zk_shift=*/true);
     if (st == RK_OK) st = ntt_forward(ctx, (uint32_t*)b, (const uint32_t*)a, h, w, blow);
-    if (st == RK_OK) {
-        KTimer kt(ctx, RK_KCLASS_BIT_REVERSE, (double)H * w * 8);
-        hipLaunchKernelGGL(cols_to_rows_bitrev_kernel, dim3((unsigned)((H + TT - 1) / TT), (unsigned)((w + TT - 1) / TT)), dim3(TT, 8), 0,
-                           ctx->stream, d_out, (const uint32_t*)b, H, w, log2u(H));
-        st = post_launch(ctx, "cols_to_rows_bitrev_kernel");
-    }
-    if (b) dev_free(ctx, b);
+    if (st == RK_OK) st = pcs_cols_to_rows_bitrev(ctx, d_out, (const uint32_t*)b, H, w);
+    if (b && (st != RK_OK || !keep_cols)) dev_free(ctx, b);
+    if (st == RK_OK && keep_cols) *keep_cols = (uint32_t*)b;
     dev_free(ctx, a);
     return st;
 }

@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int HASH_BLOCK = 256;
-constexpr uint32_t MAX_MATS = 64;
+constexpr uint32_t MAX_MATS = 512;
 
 struct MatDesc {
     const uint32_t* base;

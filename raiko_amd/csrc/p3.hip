@@ -1,0 +1,861 @@
+// rk_air_* / rk_p3_prove / rk_p3_verify (include/raiko_hip.h): a univariate STARK over the two-adic FRI PCS for AIRs
+// handed over as data -- the proof system behind SP1's `client.setup(ELF)` / `client.prove(&pk, stdin)` (reference
+// provers/sp1/driver/src/lib.rs:44-57, shard knobs docs/README_Sp1.md:19-32) as far as it exists without SP1's chips:
+// Plonky3's p3-uni-stark prover.rs / verifier.rs on p3-fri's TwoAdicFriPcs with a DuplexChallenger, several tables
+// under shared challenges the way sp1-core proves the chips of a shard (Plonky3@88ea2b8, reference
+// Cargo.lock:4889-5127; the crates are outside the reference tree: RECALLED).  SP1's chips, its permutation argument
+// and its recursion VM are NOT here.
+//
+// Device side of one proof:
+//   trace LDE      rows -> columns, iNTT (coset shift fused), expanding NTT, columns -> bit-reversed rows
+//                  (kernels_pcs.hip); the column-major evaluations are kept until the quotient is done
+//   commitments    rk_mmcs_commit (mmcs.hip)
+//   quotient       the AIR is translated once into an rk_program (circuit_program.hip): LOCAL / NEXT are taps of the
+//                  column-major LDE (NEXT = one trace row ahead, cyclic), the three selectors are taps of three
+//                  columns written by selector_kernel, the asserts one AND_EQZ chain with Horner-ordered powers of
+//                  alpha; rk::program_eval_domain runs the interpreter or the hiprtc-generated kernel over the
+//                  quotient domain (a sub-coset of the LDE: stride 2^(blow-up - log quotient degree)) and leaves the
+//                  result split into chunks, column-major, ready for the chunks' own LDE
+//   chunk LDE      iNTT, coefficient i of chunk j times w_(N qd)^(-j i) (chunk_shift_kernel), expanding NTT, to rows
+//   openings       rk_pcs_eval_at_many / rk_pcs_reduce_openings, FRI commit phase rk_fri_fold_evals + rk_mmcs_commit
+//   queries        every opened row and sibling digest of the proof in ONE gather launch and one download
+// The transcript (DuplexChallenger) runs on the host between those steps; the proof of work on the GPU.
+#include "internal.hpp"
+#include "circuit_program.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+
+struct rk_air {
+    std::vector<rk_air_step> steps;
+    uint32_t width = 0, n_public = 0;
+    rk_air_info info{};
+    uint32_t sel_mask = 0;   // bit c: selector column c (is_first_row, is_last_row, is_transition) is named by the list
+    rk_program* prog = nullptr;
+};
+
+namespace {
+
+using bb::Ext;
+constexpr uint32_t MAX_TABLES = 32, MAX_QD_LOG = 4;
+constexpr uint32_t NEXT_BACK = 0xffffffffu;  // a tap "one row ahead": back = -1 modulo any power-of-two domain
+
+// ---------------------------------------------------------------- p3-challenger DuplexChallenger (host)
+struct Challenger {
+    const p2::Any* k;
+    uint32_t state[p2::MAX_CELLS], in[p2::MAX_CELLS], out[p2::MAX_CELLS];
+    unsigned n_in = 0, n_out = 0;
+    explicit Challenger(const p2::Any* kk) : k(kk) { std::memset(state, 0, sizeof state); }
+    unsigned rate() const { return (unsigned)k->rate(); }
+    void duplex() {
+        for (unsigned i = 0; i < n_in; i++) state[i] = in[i];
+        n_in = 0;
+        k->permute(state);
+        for (unsigned i = 0; i < rate(); i++) out[i] = state[i];
+        n_out = rate();
+    }
+    void observe(uint32_t v) {
+        n_out = 0;
+        in[n_in++] = v;
+        if (n_in == rate()) duplex();
+    }
+    void observe(const uint32_t* v, size_t n) {
+        for (size_t i = 0; i < n; i++) observe(v[i]);
+    }
+    uint32_t sample() {
+        if (n_in != 0 || n_out == 0) duplex();
+        return out[--n_out];
+    }
+    Ext sample_ext() {
+        Ext r;
+        for (int i = 0; i < 4; i++) r.c[i] = sample();
+        return r;
+    }
+    uint32_t sample_bits(unsigned bits) { return bb::decode(sample()) & (uint32_t)(((uint64_t)1 << bits) - 1); }
+    bool check_witness(unsigned bits, uint32_t w) {
+        observe(bb::encode(w));
+        return sample_bits(bits) == 0;
+    }
+};
+
+// ---------------------------------------------------------------- AIR: checks, symbolic degree, host evaluation
+int air_scan(const rk_air_step* steps, size_t n, uint32_t width, uint32_t n_public, rk_air_info* info) {
+    std::vector<uint32_t> deg;
+    deg.reserve(n);
+    uint32_t max_deg = 0, n_con = 0;
+    for (size_t s = 0; s < n; s++) {
+        const rk_air_step& st = steps[s];
+        const size_t nv = deg.size();
+        switch (st.op) {
+            case RK_AIR_CONST: if (st.a >= bb::P) return RK_ERR_INVALID; deg.push_back(0); break;
+            case RK_AIR_LOCAL: case RK_AIR_NEXT: if (st.a >= width) return RK_ERR_INVALID; deg.push_back(1); break;
+            case RK_AIR_PUBLIC: if (st.a >= n_public) return RK_ERR_INVALID; deg.push_back(0); break;
+            case RK_AIR_IS_FIRST_ROW: case RK_AIR_IS_LAST_ROW: deg.push_back(1); break;
+            case RK_AIR_IS_TRANSITION: deg.push_back(0); break;
+            case RK_AIR_ADD: case RK_AIR_SUB:
+                if (st.a >= nv || st.b >= nv) return RK_ERR_INVALID;
+                deg.push_back(std::max(deg[st.a], deg[st.b]));
+                break;
+            case RK_AIR_MUL:
+                if (st.a >= nv || st.b >= nv) return RK_ERR_INVALID;
+                deg.push_back(std::min<uint32_t>(deg[st.a] + deg[st.b], 1u << 20));
+                break;
+            case RK_AIR_NEG: if (st.a >= nv) return RK_ERR_INVALID; deg.push_back(deg[st.a]); break;
+            case RK_AIR_ASSERT_ZERO:
+                if (st.a >= nv) return RK_ERR_INVALID;
+                max_deg = std::max(max_deg, deg[st.a]);
+                n_con++;
+                break;
+            default: return RK_ERR_INVALID;
+        }
+    }
+    // p3-uni-stark get_log_quotient_degree: log2_ceil(max(constraint degree, 2) - 1)
+    info->n_steps = n;
+    info->n_constraints = n_con;
+    info->max_degree = max_deg;
+    info->log_quotient_degree = log2u(std::max(max_deg, 2u) - 1);
+    return RK_OK;
+}
+
+// folder.rs on extension elements (the verifier's side): accumulator = accumulator * alpha + x per assert, in order
+Ext air_fold(const rk_air& air, const Ext* local, const Ext* next, const uint32_t* pub, const Ext& is_first, const Ext& is_last,
+             const Ext& is_trans, const Ext& alpha, uint32_t wm) {
+    std::vector<Ext> v;
+    v.reserve(air.steps.size());
+    Ext acc = bb::ext_zero();
+    for (const rk_air_step& st : air.steps) {
+        switch (st.op) {
+            case RK_AIR_CONST: v.push_back(bb::ext_from(bb::encode(st.a))); break;
+            case RK_AIR_LOCAL: v.push_back(local[st.a]); break;
+            case RK_AIR_NEXT: v.push_back(next[st.a]); break;
+            case RK_AIR_PUBLIC: v.push_back(bb::ext_from(pub[st.a])); break;
+            case RK_AIR_IS_FIRST_ROW: v.push_back(is_first); break;
+            case RK_AIR_IS_LAST_ROW: v.push_back(is_last); break;
+            case RK_AIR_IS_TRANSITION: v.push_back(is_trans); break;
+            case RK_AIR_ADD: v.push_back(bb::add(v[st.a], v[st.b])); break;
+            case RK_AIR_SUB: v.push_back(bb::sub(v[st.a], v[st.b])); break;
+            case RK_AIR_MUL: v.push_back(bb::mul(v[st.a], v[st.b], wm)); break;
+            case RK_AIR_NEG: v.push_back(bb::sub(bb::ext_zero(), v[st.a])); break;
+            default: acc = bb::add(bb::mul(acc, alpha, wm), v[st.a]); break;
+        }
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------- kernels
+// LagrangeSelectors on the quotient coset (p3-commit domain.rs selectors_on_coset): point i is x = shift * w_d^i;
+// Z_H(x) = x^n - 1 takes d / n values.  Columns: 0 is_first_row = Z_H / (x - 1), 1 is_last_row = Z_H / (x - g^-1),
+// 2 is_transition = x - g^-1.  One lane per point; the two inversions are Fermat powers (a few hundred products per
+// point against the hundreds of thousands a wide AIR costs).
+struct SelArgs {
+    uint32_t* out;       // 3 columns of d words
+    size_t d;
+    unsigned log_d;
+    uint32_t shiftm, g_inv;
+    uint32_t zh[16];     // shift^n * w_(d/n)^r - 1
+    uint32_t ratio_mask, want;   // want: bit c set = column c is read by the AIR
+};
+__global__ void selector_kernel(SelArgs a, ntt::Tables tb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.d) return;
+    const uint32_t x = bb::mul(a.shiftm, ntt::root_pow(tb, 0, (uint32_t)(i << (ntt::LAMBDA - a.log_d))));
+    const uint32_t zh = a.zh[i & a.ratio_mask];
+    if (a.want & 1u) a.out[i] = bb::mul(zh, bb::inv(bb::sub(x, bb::ONE)));
+    if (a.want & 2u) a.out[a.d + i] = bb::mul(zh, bb::inv(bb::sub(x, a.g_inv)));
+    if (a.want & 4u) a.out[2 * a.d + i] = bb::sub(x, a.g_inv);
+}
+
+// bit-reversed coefficients of the chunk columns (4 per chunk, n words each): coefficient i of chunk j times
+// w_(n qd)^(-j i) -- Pcs::commit's `shift = generator / domain.shift` for the chunk domain shift * w^j * H_n
+__global__ void chunk_shift_kernel(uint32_t* __restrict__ q, size_t n, unsigned log_n, unsigned log_nq, unsigned n_cols, ntt::Tables tb) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_cols) return;
+    const uint32_t col = (uint32_t)(t >> log_n), p = (uint32_t)(t & (n - 1)), j = col >> 2;
+    if (j == 0) return;
+    const uint32_t i = bb::bitrev(p, log_n);
+    const uint32_t e = (uint32_t)(((uint64_t)j * i) & (((uint64_t)1 << log_nq) - 1));
+    q[t] = bb::mul(q[t], ntt::root_pow(tb, 1, e << (ntt::LAMBDA - log_nq)));
+}
+
+// out[i] += in[i] (extension elements as 4 words): the shorter reduced opening joining the folded vector
+__global__ void add_words_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ in, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) io[i] = bb::add(io[i], in[i]);
+}
+
+// every opened row / digest of a proof's query phase: job = (source address, words, destination offset); one
+// 64-lane group per job
+struct GatherJob {
+    uint64_t src;
+    uint32_t words, dst;
+};
+__global__ void gather_jobs_kernel(uint32_t* __restrict__ dst, const GatherJob* __restrict__ jobs, size_t n_jobs) {
+    const size_t j = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (j >= n_jobs) return;
+    const GatherJob jb = jobs[j];
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(jb.src);
+    for (uint32_t w = threadIdx.x & 63; w < jb.words; w += 64) dst[jb.dst + w] = s[w];
+}
+
+// ---------------------------------------------------------------- prover state
+struct DevBuf {  // dev_alloc'd block released with the scope
+    rk_ctx* ctx = nullptr;
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), p(o.p) { o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        reset();
+        ctx = o.ctx;
+        p = o.p;
+        o.p = nullptr;
+        return *this;
+    }
+    ~DevBuf() { reset(); }
+    int alloc(rk_ctx* c, size_t bytes) {
+        reset();
+        ctx = c;
+        return rk::dev_alloc(c, bytes, &p);
+    }
+    void reset() {
+        if (p) (void)rk::dev_free(ctx, p);
+        p = nullptr;
+    }
+    uint32_t* u32() const { return (uint32_t*)p; }
+};
+
+struct TableState {
+    unsigned k = 0, lqd = 0;      // log2 rows, log2 quotient degree
+    size_t n = 0, H = 0, w = 0;
+    DevBuf lde;                   // H x w row-major, bit-reversed rows (committed)
+    DevBuf cols;                  // w columns of H natural-order evaluations (until the quotient is done)
+    std::vector<DevBuf> chunk;    // qd matrices H x 4
+    std::vector<uint32_t> y;      // opened values: local 4w | next 4w | chunks 16 each
+};
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+size_t proof_bound(const rk_params& p, const rk_p3_table* t, uint32_t n, const uint32_t* lqd) {
+    size_t words = 1 + n + 16, log_max = 0, row_t = 0, row_q = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        words += 8 * (size_t)t[i].width + ((size_t)16 << lqd[i]);
+        log_max = std::max<size_t>(log_max, t[i].log_height + p.blowup_log2);
+        row_t += t[i].width;
+        row_q += (size_t)4 << lqd[i];
+    }
+    const size_t rounds = log_max - p.blowup_log2;
+    words += 1 + 8 * rounds + 4 + 1;
+    size_t per_query = row_t + row_q + 2 * 8 * log_max;
+    for (size_t r = 0; r < rounds; r++) per_query += 4 + 8 * (log_max - 1 - r);
+    return words + per_query * p.queries;
+}
+
+int check_tables(const rk_params& par, const rk_p3_table* tables, uint32_t n_tables, bool prover, uint32_t* lqd) {
+    if (!tables || n_tables == 0 || n_tables > MAX_TABLES) return RK_ERR_INVALID;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        const rk_p3_table& tb = tables[t];
+        if (!tb.air || tb.width != tb.air->width || tb.n_public != tb.air->n_public || (tb.n_public && !tb.public_values)) return RK_ERR_INVALID;
+        for (uint32_t i = 0; i < tb.n_public; i++)
+            if (tb.public_values[i] >= bb::P) return RK_ERR_INVALID;
+        lqd[t] = tb.air->info.log_quotient_degree;
+        if (lqd[t] > par.blowup_log2 || lqd[t] > MAX_QD_LOG) return RK_ERR_INVALID;  // the LDE must cover the quotient domain
+        if (prover && (!tb.trace || tb.log_height < 1 || tb.log_height + par.blowup_log2 > ntt::LAMBDA || tb.on_device > 1)) return RK_ERR_INVALID;
+    }
+    return RK_OK;
+}
+
+int d2h(rk_ctx* ctx, void* h, const void* d, size_t bytes) {
+    RK_HIP_TRY(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+
+int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init, size_t n_init, uint32_t* h_proof,
+             size_t capacity, size_t* proof_words) {
+    rk_params par;
+    RK_TRY(rk_get_params(ctx, &par));
+    uint32_t lqd[MAX_TABLES];
+    RK_TRY(check_tables(par, tables, n_tables, true, lqd));
+    for (size_t i = 0; i < n_init; i++)
+        if (init[i] >= bb::P) return RK_ERR_INVALID;
+    const size_t bound = proof_bound(par, tables, n_tables, lqd);
+    if (capacity < bound) {
+        *proof_words = bound;
+        return RK_ERR_CAPACITY;
+    }
+    const unsigned blow = par.blowup_log2;
+    rk_p3_timing& tm = ctx->p3_timing;
+    tm = rk_p3_timing{};
+    const double t_start = now_ms();
+    double t_mark = t_start;
+    auto lap = [&](float& slot) {
+        (void)hipStreamSynchronize(ctx->stream);
+        const double t = now_ms();
+        slot += (float)(t - t_mark);
+        t_mark = t;
+    };
+    std::vector<uint32_t> pf;
+    pf.reserve(bound);
+    auto push = [&](const uint32_t* w, size_t n) { pf.insert(pf.end(), w, w + n); };
+    Challenger ch(&ctx->h_p2);
+    ch.observe(init, n_init);
+
+    // ---- trace LDEs and their commitment
+    std::vector<TableState> ts(n_tables);
+    std::vector<rk_matrix> tmats(n_tables);
+    size_t Ht = 0;
+    unsigned log_max = 0;
+    pf.push_back(n_tables);
+    for (uint32_t t = 0; t < n_tables; t++) {
+        const rk_p3_table& tb = tables[t];
+        TableState& s = ts[t];
+        s.k = tb.log_height;
+        s.lqd = lqd[t];
+        s.n = (size_t)1 << s.k;
+        s.H = s.n << blow;
+        s.w = tb.width;
+        pf.push_back(tb.log_height);
+        DevBuf staged;
+        const uint32_t* d_trace = tb.trace;
+        if (!tb.on_device) {
+            RK_TRY(staged.alloc(ctx, s.n * s.w * 4));
+            RK_HIP_TRY(ctx, hipMemcpyAsync(staged.p, tb.trace, s.n * s.w * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_trace = staged.u32();
+        }
+        RK_TRY(s.lde.alloc(ctx, s.H * s.w * 4));
+        uint32_t* cols = nullptr;
+        RK_TRY(rk::pcs_coset_lde_rows(ctx, s.lde.u32(), d_trace, s.n, s.w, &cols));
+        s.cols.ctx = ctx;
+        s.cols.p = cols;
+        if (!tb.on_device) RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host buffer is free again
+        tmats[t] = rk_matrix{s.lde.u32(), (uint32_t)s.H, (uint32_t)s.w, 1};
+        Ht = std::max(Ht, s.H);
+        log_max = std::max(log_max, s.k + blow);
+    }
+    lap(tm.lde);
+    DevBuf tnodes;
+    RK_TRY(tnodes.alloc(ctx, 2 * Ht * p2::OUT * 4));
+    uint32_t root[8];
+    RK_TRY(rk_mmcs_commit(ctx, tmats.data(), n_tables, tnodes.u32(), root));
+    push(root, 8);
+    ch.observe(root, 8);
+    for (uint32_t t = 0; t < n_tables; t++) ch.observe(tables[t].public_values, tables[t].n_public);
+    const Ext alpha = ch.sample_ext();
+    lap(tm.commit);
+
+    // ---- quotients
+    std::vector<rk_matrix> qmats;
+    size_t Hq = 0;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        const rk_p3_table& tb = tables[t];
+        TableState& s = ts[t];
+        const unsigned kq = s.k + s.lqd;
+        const size_t qd = (size_t)1 << s.lqd, d = s.n << s.lqd, n_qcols = 4 * qd;
+        rk_program* pg = tb.air->prog;
+        DevBuf sel, q, qb;
+        if (pg->group_min[0]) {
+            RK_TRY(sel.alloc(ctx, 3 * d * 4));
+            SelArgs a{};
+            a.out = sel.u32();
+            a.d = d;
+            a.log_d = kq;
+            a.shiftm = ctx->sys.shiftm;
+            a.g_inv = bb::inv(bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
+            const uint32_t sn = bb::pow(ctx->sys.shiftm, s.n), wr = bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.lqd));
+            for (unsigned r = 0; r < qd; r++) a.zh[r] = bb::sub(bb::mul(sn, bb::pow(wr, r)), bb::ONE);
+            a.ratio_mask = (uint32_t)qd - 1;
+            a.want = tb.air->sel_mask;
+            hipLaunchKernelGGL(selector_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, ctx->stream, a, ctx->tb);
+            RK_TRY(rk::post_launch(ctx, "selector_kernel"));
+        }
+        RK_TRY(q.alloc(ctx, n_qcols * s.n * 4));
+        rk::EvalDomain dom;
+        dom.ctx = ctx;
+        dom.po2 = s.k;
+        dom.ratio_log2 = dom.split_log2 = s.lqd;
+        dom.d_cols[0] = sel.u32();
+        dom.group_size[0] = 3;
+        dom.col_len[0] = d;
+        dom.d_cols[2] = s.cols.u32();
+        dom.group_size[2] = (uint32_t)s.w;
+        dom.col_len[2] = s.H;
+        dom.stride_log2[2] = blow - s.lqd;
+        dom.globals = tb.public_values;
+        dom.n_globals = tb.n_public;
+        RK_TRY(rk::program_eval_domain(pg, dom, alpha.c, q.u32()));
+        s.cols.reset();
+        sel.reset();
+        // the chunks' own LDE: interpolate over H_n, move to the chunk's coset, evaluate on the LDE coset
+        RK_TRY(rk::ntt_reverse(ctx, q.u32(), s.n, n_qcols, /*fuse_zk_shift=*/false));
+        if (qd > 1) {
+            const size_t tot = s.n * n_qcols;
+            hipLaunchKernelGGL(chunk_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, q.u32(), s.n, s.k, kq,
+                               (unsigned)n_qcols, ctx->tb);
+            RK_TRY(rk::post_launch(ctx, "chunk_shift_kernel"));
+        }
+        RK_TRY(qb.alloc(ctx, n_qcols * s.H * 4));
+        RK_TRY(rk::ntt_forward(ctx, qb.u32(), q.u32(), s.n, n_qcols, blow));
+        s.chunk.resize(qd);
+        for (size_t j = 0; j < qd; j++) {
+            RK_TRY(s.chunk[j].alloc(ctx, s.H * 4 * 4));
+            RK_TRY(rk::pcs_cols_to_rows_bitrev(ctx, s.chunk[j].u32(), qb.u32() + 4 * j * s.H, s.H, 4));
+            qmats.push_back(rk_matrix{s.chunk[j].u32(), (uint32_t)s.H, 4, 1});
+        }
+        Hq = std::max(Hq, s.H);
+    }
+    lap(tm.quotient);
+    DevBuf qnodes;
+    RK_TRY(qnodes.alloc(ctx, 2 * Hq * p2::OUT * 4));
+    RK_TRY(rk_mmcs_commit(ctx, qmats.data(), (uint32_t)qmats.size(), qnodes.u32(), root));
+    push(root, 8);
+    ch.observe(root, 8);
+    const Ext zeta = ch.sample_ext();
+    lap(tm.commit);
+
+    // ---- PCS open: opened values and reduced openings
+    const Ext alpha2 = ch.sample_ext();
+    DevBuf ro[ntt::LAMBDA + 1];
+    uint64_t num_reduced[ntt::LAMBDA + 1] = {0};
+    DevBuf d_ys;
+    {
+        size_t wmax = 4;
+        for (const TableState& s : ts) wmax = std::max(wmax, s.w);
+        RK_TRY(d_ys.alloc(ctx, 2 * wmax * 16));
+    }
+    for (uint32_t t = 0; t < n_tables; t++) {  // round 0: every trace at zeta and zeta * g
+        TableState& s = ts[t];
+        const unsigned lh = s.k + blow;
+        if (!ro[lh].p) {
+            RK_TRY(ro[lh].alloc(ctx, s.H * 16));
+            RK_HIP_TRY(ctx, hipMemsetAsync(ro[lh].p, 0, s.H * 16, ctx->stream));
+        }
+        uint32_t pts[8];
+        std::memcpy(pts, zeta.c, 16);
+        const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
+        std::memcpy(pts + 4, zn.c, 16);
+        s.y.resize(8 * s.w + ((size_t)16 << s.lqd));
+        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.lde.u32(), s.H, s.w, pts, 2));
+        RK_TRY(d2h(ctx, s.y.data(), d_ys.p, 8 * s.w * 4));
+        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.lde.u32(), s.H, s.w, 2, pts, s.y.data(), alpha2, num_reduced[lh]));
+        num_reduced[lh] += 2 * s.w;
+    }
+    for (uint32_t t = 0; t < n_tables; t++) {  // round 1: every quotient chunk at zeta
+        TableState& s = ts[t];
+        const unsigned lh = s.k + blow;
+        for (size_t j = 0; j < s.chunk.size(); j++) {
+            uint32_t* y = s.y.data() + 8 * s.w + 16 * j;
+            RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunk[j].u32(), s.H, 4, zeta.c, 1));
+            RK_TRY(d2h(ctx, y, d_ys.p, 64));
+            RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunk[j].u32(), s.H, 4, 1, zeta.c, y, alpha2, num_reduced[lh]));
+            num_reduced[lh] += 4;
+        }
+    }
+    for (const TableState& s : ts) push(s.y.data(), s.y.size());
+    lap(tm.open);
+
+    // ---- FRI commit phase
+    const unsigned n_rounds = log_max - blow;
+    struct Layer {
+        DevBuf values, nodes;   // 2^(log_max - round) extension elements; the tree over their pairs
+    };
+    std::vector<Layer> layers(n_rounds);
+    DevBuf folded = std::move(ro[log_max]);
+    size_t len = (size_t)1 << log_max;
+    pf.push_back(n_rounds);
+    for (unsigned rd = 0; rd < n_rounds; rd++) {
+        Layer& L = layers[rd];
+        RK_TRY(L.nodes.alloc(ctx, len * p2::OUT * 4));   // 2 * (len / 2) digests
+        const rk_matrix lm{folded.u32(), (uint32_t)(len / 2), 8, 1};
+        RK_TRY(rk_mmcs_commit(ctx, &lm, 1, L.nodes.u32(), root));
+        push(root, 8);
+        ch.observe(root, 8);
+        const Ext beta = ch.sample_ext();
+        DevBuf nxt;
+        RK_TRY(nxt.alloc(ctx, len / 2 * 16));
+        RK_TRY(rk::fri_fold_evals(ctx, nxt.u32(), folded.u32(), len / 2, beta));
+        L.values = std::move(folded);
+        folded = std::move(nxt);
+        len /= 2;
+        const unsigned lg = log2u(len);
+        if (lg != log_max && ro[lg].p) {
+            hipLaunchKernelGGL(add_words_kernel, dim3((unsigned)((len * 4 + 255) / 256)), dim3(256), 0, ctx->stream, folded.u32(),
+                               (const uint32_t*)ro[lg].u32(), len * 4);
+            RK_TRY(rk::post_launch(ctx, "add_words_kernel"));
+        }
+    }
+    std::vector<uint32_t> fin(len * 4);
+    RK_TRY(d2h(ctx, fin.data(), folded.p, len * 16));
+    for (size_t i = 1; i < len; i++)
+        if (std::memcmp(&fin[4 * i], &fin[0], 16) != 0) return RK_ERR_INTERNAL;   // `blowup` values of a constant
+    push(fin.data(), 4);
+    ch.observe(fin.data(), 4);
+    uint32_t witness = 0;
+    if (par.pow_bits) RK_TRY(rk::duplex_grind(ctx, ch.state, ch.in, ch.n_in, par.pow_bits, &witness));
+    if (!ch.check_witness(par.pow_bits, witness)) return RK_ERR_INTERNAL;
+    pf.push_back(witness);
+    lap(tm.fri);
+
+    // ---- queries: all indices first (they depend on the transcript only), then one gather
+    std::vector<GatherJob> jobs;
+    uint32_t at = 0;
+    auto job = [&](const uint32_t* src, uint32_t words) {
+        jobs.push_back(GatherJob{(uint64_t)(uintptr_t)src, words, at});
+        at += words;
+    };
+    auto open_batch = [&](const std::vector<rk_matrix>& mats, const uint32_t* nodes, size_t H, uint32_t index) {
+        for (const rk_matrix& m : mats) job(m.d_values + (size_t)(index / (H / m.height)) * m.width, m.width);
+        for (size_t idx = H + index; idx > 1; idx >>= 1) job(nodes + (idx ^ 1) * p2::OUT, p2::OUT);
+    };
+    for (uint32_t qi = 0; qi < par.queries; qi++) {
+        const uint32_t index = ch.sample_bits(log_max);
+        open_batch(tmats, tnodes.u32(), Ht, index >> (log_max - log2u(Ht)));
+        open_batch(qmats, qnodes.u32(), Hq, index >> (log_max - log2u(Hq)));
+        for (unsigned rd = 0; rd < n_rounds; rd++) {
+            const uint32_t idx = index >> rd, pair = idx >> 1;
+            const size_t height = ((size_t)1 << (log_max - rd)) / 2;
+            job(layers[rd].values.u32() + (2 * (size_t)pair + ((idx ^ 1) & 1)) * 4, 4);
+            for (size_t a = height + pair; a > 1; a >>= 1) job(layers[rd].nodes.u32() + (a ^ 1) * p2::OUT, p2::OUT);
+        }
+    }
+    if (pf.size() + at > capacity) return RK_ERR_INTERNAL;  // the bound is exact: cannot happen
+    {
+        DevBuf d_jobs, d_out;
+        RK_TRY(d_jobs.alloc(ctx, jobs.size() * sizeof(GatherJob)));
+        RK_TRY(d_out.alloc(ctx, (size_t)at * 4 + 16));
+        RK_HIP_TRY(ctx, hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(gather_jobs_kernel, dim3((unsigned)((jobs.size() + 3) / 4)), dim3(256), 0, ctx->stream, d_out.u32(),
+                           (const GatherJob*)d_jobs.p, jobs.size());
+        RK_TRY(rk::post_launch(ctx, "gather_jobs_kernel"));
+        std::memcpy(h_proof, pf.data(), pf.size() * 4);
+        RK_TRY(d2h(ctx, h_proof + pf.size(), d_out.p, (size_t)at * 4));
+    }
+    *proof_words = pf.size() + at;
+    lap(tm.query);
+    tm.total = (float)(now_ms() - t_start);
+    return RK_OK;
+}
+
+// ---------------------------------------------------------------- verifier (host)
+struct Reader {
+    const uint32_t* p;
+    size_t n, pos = 0;
+    bool bad = false;
+    const uint32_t* take(size_t k) {
+        if (pos + k > n) {
+            bad = true;
+            return nullptr;
+        }
+        const uint32_t* q = p + pos;
+        pos += k;
+        return q;
+    }
+};
+struct Selectors {
+    Ext is_first, is_last, is_trans, inv_zeroifier;
+};
+Selectors selectors_at(const Ext& x, unsigned log_n, uint32_t root27m, uint32_t wm) {
+    const Ext z_h = bb::sub(bb::pow(x, (uint64_t)1 << log_n, wm), bb::ext_one());
+    const uint32_t g_inv = bb::inv(bb::pow(root27m, (uint64_t)1 << (27 - log_n)));
+    Selectors s;
+    s.is_first = bb::mul(z_h, bb::inv(bb::sub(x, bb::ext_one()), wm), wm);
+    s.is_last = bb::mul(z_h, bb::inv(bb::sub(x, bb::ext_from(g_inv)), wm), wm);
+    s.is_trans = bb::sub(x, bb::ext_from(g_inv));
+    s.inv_zeroifier = bb::inv(z_h, wm);
+    return s;
+}
+Ext load_ext(const uint32_t* p) { return Ext{{p[0], p[1], p[2], p[3]}}; }
+
+// 0 accept; 1 malformed / short / trailing / non-canonical word, 2 shape mismatch, 3 constraint identity
+// (OodEvaluationMismatch), 4 proof of work, 5 input opening, 6 commit-phase opening, 7 final polynomial
+int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init, size_t n_init,
+              const uint32_t* proof, size_t words) {
+    rk_params def;
+    rk::params_preset(&def, RK_PRESET_SP1);
+    const rk_params& par = params ? *params : def;
+    rk::Sys sys;
+    auto k = std::make_unique<p2::Any>();
+    RK_TRY(rk::resolve_params(&par, &sys, k.get()));
+    uint32_t lqd[MAX_TABLES];
+    RK_TRY(check_tables(par, tables, n_tables, false, lqd));
+    if (!proof || (n_init && !init)) return RK_ERR_INVALID;
+    for (size_t i = 0; i < n_init; i++)
+        if (init[i] >= bb::P) return RK_ERR_INVALID;
+    for (size_t i = 0; i < words; i++)
+        if (proof[i] >= bb::P) return 1;
+    const unsigned blow = sys.blowup_log2;
+    const uint32_t wm = sys.wm, shiftm = sys.shiftm;
+    auto gen = [&](unsigned bits) { return bb::pow(sys.root27m, (uint64_t)1 << (27 - bits)); };
+    Reader r{proof, words};
+    const uint32_t* hdr = r.take(1 + (size_t)n_tables);
+    if (!hdr || hdr[0] != n_tables) return 2;
+    unsigned log_n[MAX_TABLES], log_max = 0;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        log_n[t] = hdr[1 + t];
+        if (log_n[t] < 1 || log_n[t] + blow > ntt::LAMBDA) return 2;
+        log_max = std::max(log_max, log_n[t] + blow);
+    }
+    Challenger ch(k.get());
+    ch.observe(init, n_init);
+    const uint32_t* troot = r.take(8);
+    if (!troot) return 1;
+    ch.observe(troot, 8);
+    for (uint32_t t = 0; t < n_tables; t++) ch.observe(tables[t].public_values, tables[t].n_public);
+    const Ext alpha = ch.sample_ext();
+    const uint32_t* qroot = r.take(8);
+    if (!qroot) return 1;
+    ch.observe(qroot, 8);
+    const Ext zeta = ch.sample_ext();
+    const uint32_t *y_local[MAX_TABLES], *y_next[MAX_TABLES], *y_chunk[MAX_TABLES];
+    for (uint32_t t = 0; t < n_tables; t++) {
+        y_local[t] = r.take(4 * (size_t)tables[t].width);
+        y_next[t] = r.take(4 * (size_t)tables[t].width);
+        y_chunk[t] = r.take((size_t)16 << lqd[t]);
+        if (r.bad) return 1;
+    }
+    for (uint32_t t = 0; t < n_tables; t++) {
+        const unsigned kq = log_n[t] + lqd[t];
+        const size_t qd = (size_t)1 << lqd[t], n = (size_t)1 << log_n[t];
+        // quotient(zeta) = sum_i zps_i * sum_e x^e * chunk_i[e], zps_i = prod_{j != i} Z_j(zeta) / Z_j(first point of domain i)
+        Ext quotient = bb::ext_zero();
+        for (size_t i = 0; i < qd; i++) {
+            Ext zp = bb::ext_one();
+            const uint32_t first_i = bb::mul(shiftm, bb::pow(gen(kq), i));
+            for (size_t j = 0; j < qd; j++) {
+                if (j == i) continue;
+                const uint32_t sj_inv = bb::inv(bb::mul(shiftm, bb::pow(gen(kq), j)));
+                const Ext a = bb::sub(bb::pow(bb::scale(zeta, sj_inv), n, wm), bb::ext_one());
+                const uint32_t b = bb::sub(bb::pow(bb::mul(first_i, sj_inv), n), bb::ONE);
+                zp = bb::mul(zp, bb::scale(a, bb::inv(b)), wm);
+            }
+            for (int e = 0; e < 4; e++) {
+                Ext mono = bb::ext_zero();
+                mono.c[e] = bb::ONE;
+                quotient = bb::add(quotient, bb::mul(bb::mul(zp, mono, wm), load_ext(y_chunk[t] + (i * 4 + e) * 4), wm));
+            }
+        }
+        const Selectors s = selectors_at(zeta, log_n[t], sys.root27m, wm);
+        const Ext folded = air_fold(*tables[t].air, (const Ext*)y_local[t], (const Ext*)y_next[t], tables[t].public_values, s.is_first,
+                                    s.is_last, s.is_trans, alpha, wm);
+        if (!bb::eq(bb::mul(folded, s.inv_zeroifier, wm), quotient)) return 3;
+    }
+    const Ext alpha2 = ch.sample_ext();
+    const uint32_t* nr = r.take(1);
+    if (!nr) return 1;
+    const uint32_t n_rounds = *nr;
+    if (n_rounds != log_max - blow) return 2;
+    const uint32_t* commits = r.take(8 * (size_t)n_rounds);
+    if (r.bad) return 1;
+    std::vector<Ext> betas(n_rounds);
+    for (uint32_t rd = 0; rd < n_rounds; rd++) {
+        ch.observe(commits + 8 * rd, 8);
+        betas[rd] = ch.sample_ext();
+    }
+    const uint32_t* fp = r.take(4);
+    const uint32_t* wit = r.take(1);
+    if (r.bad) return 1;
+    const Ext final_poly = load_ext(fp);
+    ch.observe(fp, 4);
+    if (!ch.check_witness(sys.pow_bits, *wit)) return 4;
+
+    std::vector<uint32_t> th(n_tables), tw(n_tables), qh, qw;
+    size_t trow = 0;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        th[t] = 1u << (log_n[t] + blow);
+        tw[t] = tables[t].width;
+        trow += tables[t].width;
+        for (uint32_t j = 0; j < (1u << lqd[t]); j++) {
+            qh.push_back(th[t]);
+            qw.push_back(4);
+        }
+    }
+    const size_t qrow = 4 * qh.size();
+    for (uint32_t qi = 0; qi < sys.queries; qi++) {
+        const uint32_t index = ch.sample_bits(log_max);
+        // every table is in both batches: both trees have the global maximum height
+        const uint32_t* trows = r.take(trow);
+        const uint32_t* tpath = r.take(8 * (size_t)log_max);
+        const uint32_t* qrows = r.take(qrow);
+        const uint32_t* qpath = r.take(8 * (size_t)log_max);
+        if (r.bad) return 1;
+        if (rk_mmcs_verify(&par, th.data(), tw.data(), n_tables, index, trows, tpath, troot) != 0) return 5;
+        if (rk_mmcs_verify(&par, qh.data(), qw.data(), (uint32_t)qh.size(), index, qrows, qpath, qroot) != 0) return 5;
+        Ext rop[ntt::LAMBDA + 1], apow[ntt::LAMBDA + 1];
+        bool used[ntt::LAMBDA + 1] = {false};
+        for (unsigned i = 0; i <= ntt::LAMBDA; i++) rop[i] = bb::ext_zero(), apow[i] = bb::ext_one();
+        auto reduce = [&](unsigned lh, uint32_t x, const Ext& z, const Ext& p_at_z, uint32_t p_at_x) {
+            const Ext den = bb::sub(bb::ext_from(x), z);
+            const Ext quot = bb::mul(bb::sub(bb::ext_from(p_at_x), p_at_z), bb::inv(den, wm), wm);
+            rop[lh] = bb::add(rop[lh], bb::mul(apow[lh], quot, wm));
+            apow[lh] = bb::mul(apow[lh], alpha2, wm);
+        };
+        size_t at = 0;
+        for (uint32_t t = 0; t < n_tables; t++) {
+            const unsigned lh = log_n[t] + blow;
+            const uint32_t x = bb::mul(shiftm, bb::pow(gen(lh), bb::bitrev(index >> (log_max - lh), lh)));
+            used[lh] = true;
+            const Ext zn = bb::scale(zeta, gen(log_n[t]));
+            for (uint32_t c = 0; c < tables[t].width; c++) reduce(lh, x, zeta, load_ext(y_local[t] + 4 * c), trows[at + c]);
+            for (uint32_t c = 0; c < tables[t].width; c++) reduce(lh, x, zn, load_ext(y_next[t] + 4 * c), trows[at + c]);
+            at += tables[t].width;
+        }
+        at = 0;
+        for (uint32_t t = 0; t < n_tables; t++) {
+            const unsigned lh = log_n[t] + blow;
+            const uint32_t x = bb::mul(shiftm, bb::pow(gen(lh), bb::bitrev(index >> (log_max - lh), lh)));
+            for (uint32_t j = 0; j < (1u << lqd[t]); j++, at += 4)
+                for (int c = 0; c < 4; c++) reduce(lh, x, zeta, load_ext(y_chunk[t] + (j * 4 + c) * 4), qrows[at + c]);
+        }
+        Ext folded = bb::ext_zero();
+        uint32_t idx = index;
+        for (uint32_t rd = 0; rd < n_rounds; rd++) {
+            const unsigned lfh = log_max - 1 - rd;
+            if (used[lfh + 1]) folded = bb::add(folded, rop[lfh + 1]);
+            const uint32_t* sib = r.take(4);
+            const uint32_t* path = r.take(8 * (size_t)lfh);
+            if (r.bad) return 1;
+            uint32_t pair[8];
+            std::memcpy(pair + 4 * (idx & 1), folded.c, 16);
+            std::memcpy(pair + 4 * ((idx ^ 1) & 1), sib, 16);
+            const uint32_t dh = 1u << lfh, dw = 8;
+            static const uint32_t no_path[8] = {0};
+            if (rk_mmcs_verify(&par, &dh, &dw, 1, idx >> 1, pair, lfh ? path : no_path, commits + 8 * rd) != 0) return 6;
+            idx >>= 1;
+            // fold_row: the line through (x0, e0) and (-x0, e1) at beta; x0 = g^bitrev(idx) in the subgroup of order 2^(lfh+1)
+            const uint32_t x0 = bb::pow(gen(lfh + 1), bb::bitrev(idx, lfh));
+            const Ext e0 = load_ext(pair), e1 = load_ext(pair + 4);
+            const Ext slope = bb::scale(bb::sub(e1, e0), bb::inv(bb::sub(bb::neg(x0), x0)));
+            folded = bb::add(e0, bb::mul(bb::sub(betas[rd], bb::ext_from(x0)), slope, wm));
+        }
+        if (!bb::eq(folded, final_poly)) return 7;
+    }
+    return r.pos == r.n ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, rk_air** out) {
+    RK_GUARD_BEGIN
+    if (!out) return RK_ERR_INVALID;
+    *out = nullptr;
+    if (!steps || n_steps == 0 || n_steps > ((size_t)1 << 27) || width == 0 || width > (1u << 16) || n_public > (1u << 20)) return RK_ERR_INVALID;
+    std::unique_ptr<rk_air> air(new rk_air);
+    RK_TRY(air_scan(steps, n_steps, width, n_public, &air->info));
+    air->steps.assign(steps, steps + n_steps);
+    air->width = width;
+    air->n_public = n_public;
+    // the list as an rk_program: taps 0..2 = the selector columns (group 0), 3 + c = LOCAL c, 3 + width + c = NEXT c
+    // (group 2); PUBLIC = GET_GLOBAL of the proof's globals; NEG a = 0 - a; the asserts one AND_EQZ chain
+    std::vector<rk::Tap> taps;
+    for (uint32_t c = 0; c < 3; c++) taps.push_back(rk::Tap{0, c, 0});
+    for (uint32_t c = 0; c < width; c++) taps.push_back(rk::Tap{2, c, 0});
+    for (uint32_t c = 0; c < width; c++) taps.push_back(rk::Tap{2, c, NEXT_BACK});
+    std::vector<rk_poly_step> ps;
+    ps.reserve(n_steps + 2);
+    std::vector<uint32_t> fp_of;   // AIR value -> position in the program's field-value list
+    fp_of.reserve(n_steps);
+    uint32_t n_fp = 0, n_mx = 0, zero = rk::PROGRAM_NONE;
+    ps.push_back(rk_poly_step{RK_STEP_TRUE, 0, 0, 0});
+    uint32_t chain = n_mx++;
+    for (size_t s = 0; s < n_steps; s++) {
+        const rk_air_step& st = steps[s];
+        switch (st.op) {
+            case RK_AIR_CONST: ps.push_back(rk_poly_step{RK_STEP_CONST, st.a, 0, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_LOCAL: ps.push_back(rk_poly_step{RK_STEP_GET, 3 + st.a, 0, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_NEXT: ps.push_back(rk_poly_step{RK_STEP_GET, 3 + width + st.a, 0, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_PUBLIC: ps.push_back(rk_poly_step{RK_STEP_GET_GLOBAL, 0, st.a, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_IS_FIRST_ROW: case RK_AIR_IS_LAST_ROW: case RK_AIR_IS_TRANSITION:
+                air->sel_mask |= 1u << (st.op - RK_AIR_IS_FIRST_ROW);
+                ps.push_back(rk_poly_step{RK_STEP_GET, st.op - RK_AIR_IS_FIRST_ROW, 0, 0});
+                fp_of.push_back(n_fp++);
+                break;
+            case RK_AIR_ADD: ps.push_back(rk_poly_step{RK_STEP_ADD, fp_of[st.a], fp_of[st.b], 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_SUB: ps.push_back(rk_poly_step{RK_STEP_SUB, fp_of[st.a], fp_of[st.b], 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_MUL: ps.push_back(rk_poly_step{RK_STEP_MUL, fp_of[st.a], fp_of[st.b], 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_NEG:
+                if (zero == rk::PROGRAM_NONE) {
+                    ps.push_back(rk_poly_step{RK_STEP_CONST, 0, 0, 0});
+                    zero = n_fp++;
+                }
+                ps.push_back(rk_poly_step{RK_STEP_SUB, zero, fp_of[st.a], 0});
+                fp_of.push_back(n_fp++);
+                break;
+            default:  // ASSERT_ZERO
+                ps.push_back(rk_poly_step{RK_STEP_AND_EQZ, chain, fp_of[st.a], 0});
+                chain = n_mx++;
+                break;
+        }
+    }
+    RK_TRY(rk::program_create_raw(ps.data(), ps.size(), chain, std::move(taps), /*horner=*/true, &air->prog));
+    rk_program_info pi;
+    (void)rk_program_get_info(air->prog, &pi);
+    air->info.n_ops = pi.n_ops;
+    air->info.n_fp_slots = pi.n_fp_slots;
+    *out = air.release();
+    return RK_OK;
+    RK_GUARD_END
+}
+int rk_air_destroy(rk_air* air) {
+    RK_GUARD_BEGIN
+    if (!air) return RK_OK;
+    (void)rk_program_destroy(air->prog);
+    delete air;
+    return RK_OK;
+    RK_GUARD_END
+}
+int rk_air_get_info(const rk_air* air, rk_air_info* out) {
+    if (!air || !out) return RK_ERR_INVALID;
+    *out = air->info;
+    return RK_OK;
+}
+int rk_air_compile(rk_air* air, rk_ctx* ctx) {
+    RK_GUARD_BEGIN
+    if (!air || !ctx) return RK_ERR_INVALID;
+    return rk_program_compile(air->prog, ctx);
+    RK_GUARD_END
+}
+
+size_t rk_p3_proof_bound_words(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables) {
+    rk_params def;
+    rk::params_preset(&def, RK_PRESET_SP1);
+    const rk_params& par = params ? *params : def;
+    rk::Sys sys;
+    auto k = std::make_unique<p2::Any>();
+    if (rk::resolve_params(&par, &sys, k.get()) != RK_OK) return 0;
+    uint32_t lqd[MAX_TABLES];
+    if (check_tables(par, tables, n_tables, false, lqd) != RK_OK) return 0;
+    for (uint32_t t = 0; t < n_tables; t++)
+        if (tables[t].log_height < 1 || tables[t].log_height + par.blowup_log2 > ntt::LAMBDA) return 0;
+    return proof_bound(par, tables, n_tables, lqd);
+}
+
+int rk_p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init, uint32_t* h_proof,
+                size_t capacity_words, size_t* proof_words) {
+    RK_GUARD_BEGIN
+    if (!ctx || !h_proof || !proof_words || (n_init && !init_words)) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = p3_prove(ctx, tables, n_tables, init_words, n_init, h_proof, capacity_words, proof_words);
+    if (rc != RK_OK) (void)hipStreamSynchronize(ctx->stream);   // scoped buffers are back in the pool: nothing may still read them
+    return rc;
+    RK_GUARD_END
+}
+
+int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
+                 const uint32_t* proof, size_t proof_words) {
+    RK_GUARD_BEGIN
+    return p3_verify(params, tables, n_tables, init_words, n_init, proof, proof_words);
+    RK_GUARD_END
+}
+
+int rk_p3_last_timing(rk_ctx* ctx, rk_p3_timing* out) {
+    if (!ctx || !out) return RK_ERR_INVALID;
+    *out = ctx->p3_timing;
+    return RK_OK;
+}
+
+}  // extern "C"

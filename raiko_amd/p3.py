@@ -1,0 +1,391 @@
+"""Host side of the Plonky3-style STARK entry points (rk_air_* / rk_p3_prove / rk_p3_verify, include/raiko_hip.h):
+the path behind SP1's `client.prove(&pk, stdin)` (reference provers/sp1/driver/src/lib.rs:44-57) as far as it can be
+built without SP1's chips -- a univariate STARK over the two-adic FRI PCS for AIRs handed over as data.
+
+An AIR is a list of steps, the shape a `p3_air::Air::eval` call leaves in a symbolic builder (p3-uni-stark
+symbolic_builder.rs, RECALLED): every step but ASSERT_ZERO pushes one value, operands name earlier values.
+`AirBuilder` records such a list from ordinary Python expressions:
+
+    b = AirBuilder(width=2, n_public=3)
+    l, r, nl, nr = b.local(0), b.local(1), b.next(0), b.next(1)
+    b.when_first_row().assert_eq(l, b.public(0))
+    b.when_transition().assert_eq(nl, r)
+    air = b.build()
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+P = 2013265921
+
+CONST, LOCAL, NEXT, PUBLIC, IS_FIRST_ROW, IS_LAST_ROW, IS_TRANSITION, ADD, SUB, MUL, NEG, ASSERT_ZERO = range(12)
+
+
+class Expr:
+    __slots__ = ("b", "idx")
+
+    def __init__(self, b, idx):
+        self.b, self.idx = b, idx
+
+    def _lift(self, o):
+        return o if isinstance(o, Expr) else self.b.const(int(o))
+
+    def __add__(self, o):
+        return self.b._push(ADD, self.idx, self._lift(o).idx)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.b._push(SUB, self.idx, self._lift(o).idx)
+
+    def __rsub__(self, o):
+        return self.b._push(SUB, self._lift(o).idx, self.idx)
+
+    def __mul__(self, o):
+        return self.b._push(MUL, self.idx, self._lift(o).idx)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self.b._push(NEG, self.idx, 0)
+
+
+class _When:
+    def __init__(self, b, cond):
+        self.b, self.cond = b, cond
+
+    def assert_zero(self, x):
+        self.b.assert_zero(self.cond * x)
+
+    def assert_eq(self, x, y):
+        self.b.assert_zero(self.cond * (x - y))
+
+
+class Air:
+    """steps: (n, 3) uint32 array of (op, a, b)"""
+
+    def __init__(self, steps, width, n_public):
+        self.steps = np.ascontiguousarray(steps, dtype=np.uint32).reshape(-1, 3)
+        self.width, self.n_public = int(width), int(n_public)
+        self._handle = None
+
+    def handle(self):
+        """the rk_air behind this list (rk_air_create validates it and translates it for the GPU evaluator)"""
+        if self._handle is None:
+            lib = _lib.load()
+            h = C.c_void_p()
+            _lib.check(None, lib.rk_air_create(self.steps.ctypes.data, self.steps.shape[0], self.width, self.n_public, C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def info(self):
+        out = _lib.RkAirInfo()
+        _lib.check(None, _lib.load().rk_air_get_info(self.handle(), C.byref(out)))
+        return {n: int(getattr(out, n)) for n, _ in out._fields_}
+
+    def compile(self, hal):
+        """rk_air_compile: the straight-line quotient kernel for hal's GPU (hiprtc)"""
+        _lib.check(hal._ctx, _lib.load().rk_air_compile(self.handle(), hal._ctx))
+
+    def __del__(self):
+        if getattr(self, "_handle", None) is not None and _lib is not None:
+            try:
+                _lib.load().rk_air_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    @property
+    def n_constraints(self):
+        return int((self.steps[:, 0] == ASSERT_ZERO).sum())
+
+    def log_quotient_degree(self):
+        """p3-uni-stark get_log_quotient_degree on the symbolic degrees (trace cells, is_first_row, is_last_row: 1;
+        is_transition, constants, public values: 0)"""
+        deg, mx = [], 0
+        for op, a, b in self.steps.tolist():
+            if op in (CONST, PUBLIC, IS_TRANSITION):
+                deg.append(0)
+            elif op in (LOCAL, NEXT, IS_FIRST_ROW, IS_LAST_ROW):
+                deg.append(1)
+            elif op in (ADD, SUB):
+                deg.append(max(deg[a], deg[b]))
+            elif op == MUL:
+                deg.append(deg[a] + deg[b])
+            elif op == NEG:
+                deg.append(deg[a])
+            else:
+                mx = max(mx, deg[a])
+        d = max(mx, 2) - 1
+        return (d - 1).bit_length()
+
+    def check_trace(self, trace, public_values=()):
+        """every constraint on every row of a canonical-integer trace (rows wrap around); -> list of (row, constraint)"""
+        t = np.asarray(trace, dtype=object)
+        n = t.shape[0]
+        bad = []
+        for r in range(n):
+            vals, k = [], 0
+            for op, a, b in self.steps.tolist():
+                if op == CONST:
+                    vals.append(a)
+                elif op == LOCAL:
+                    vals.append(int(t[r][a]))
+                elif op == NEXT:
+                    vals.append(int(t[(r + 1) % n][a]))
+                elif op == PUBLIC:
+                    vals.append(int(public_values[a]))
+                elif op == IS_FIRST_ROW:
+                    vals.append(1 if r == 0 else 0)
+                elif op == IS_LAST_ROW:
+                    vals.append(1 if r == n - 1 else 0)
+                elif op == IS_TRANSITION:
+                    vals.append(0 if r == n - 1 else 1)
+                elif op == ADD:
+                    vals.append((vals[a] + vals[b]) % P)
+                elif op == SUB:
+                    vals.append((vals[a] - vals[b]) % P)
+                elif op == MUL:
+                    vals.append(vals[a] * vals[b] % P)
+                elif op == NEG:
+                    vals.append(-vals[a] % P)
+                else:
+                    if vals[a] % P:
+                        bad.append((r, k))
+                    k += 1
+        return bad
+
+
+class AirBuilder:
+    def __init__(self, width, n_public=0):
+        self.width, self.n_public = width, n_public
+        self.steps, self.nv = [], 0
+        self._memo = {}
+
+    def _push(self, op, a=0, b=0):
+        key = (op, a, b)
+        if op != ASSERT_ZERO and key in self._memo:     # the same leaf or expression twice is one value
+            return Expr(self, self._memo[key])
+        self.steps.append(key)
+        if op == ASSERT_ZERO:
+            return None
+        self._memo[key] = self.nv
+        self.nv += 1
+        return Expr(self, self.nv - 1)
+
+    def const(self, v):
+        return self._push(CONST, v % P)
+
+    def local(self, c):
+        assert 0 <= c < self.width
+        return self._push(LOCAL, c)
+
+    def next(self, c):
+        assert 0 <= c < self.width
+        return self._push(NEXT, c)
+
+    def public(self, i):
+        assert 0 <= i < self.n_public
+        return self._push(PUBLIC, i)
+
+    def is_first_row(self):
+        return self._push(IS_FIRST_ROW)
+
+    def is_last_row(self):
+        return self._push(IS_LAST_ROW)
+
+    def is_transition(self):
+        return self._push(IS_TRANSITION)
+
+    def when_first_row(self):
+        return _When(self, self.is_first_row())
+
+    def when_last_row(self):
+        return _When(self, self.is_last_row())
+
+    def when_transition(self):
+        return _When(self, self.is_transition())
+
+    def assert_zero(self, x):
+        self._push(ASSERT_ZERO, x.idx)
+
+    def assert_eq(self, x, y):
+        self.assert_zero(x - y)
+
+    def build(self):
+        return Air(np.array(self.steps, dtype=np.uint32), self.width, self.n_public)
+
+
+_R_MOD_P = (1 << 32) % P
+
+
+def to_mont(x):
+    return (np.asarray(x, dtype=np.uint64) % P * _R_MOD_P % P).astype(np.uint32)
+
+
+class Table:
+    """one table of a proof: a row-major trace (Montgomery words, as every buffer of the ABI), its AIR, its public values"""
+
+    def __init__(self, air, trace_mont, public_mont=()):
+        self.air = air
+        self.trace = None if trace_mont is None else np.ascontiguousarray(trace_mont, dtype=np.uint32)
+        self.public_values = np.ascontiguousarray(public_mont, dtype=np.uint32).reshape(-1)
+        if self.trace is not None:
+            n, w = self.trace.shape
+            assert w == air.width and n >= 2 and n & (n - 1) == 0
+            self.log_height = n.bit_length() - 1
+        assert self.public_values.size == air.n_public
+
+    @classmethod
+    def from_canonical(cls, air, trace, public_values=()):
+        return cls(air, to_mont(trace), to_mont(np.array(list(public_values), dtype=np.uint64)))
+
+
+def _c_tables(tables, device_traces=None):
+    arr = (_lib.RkP3Table * len(tables))()
+    keep = []
+    for i, t in enumerate(tables):
+        arr[i].width = t.air.width
+        arr[i].air = t.air.handle()
+        pv = np.ascontiguousarray(t.public_values, dtype=np.uint32)
+        keep.append(pv)
+        arr[i].public_values = pv.ctypes.data_as(_lib.u32p)
+        arr[i].n_public = pv.size
+        if device_traces is not None and device_traces[i] is not None:
+            d_ptr, log_height = device_traces[i]
+            arr[i].trace, arr[i].log_height, arr[i].on_device = int(d_ptr), int(log_height), 1
+        elif t.trace is not None:
+            arr[i].trace = t.trace.ctypes.data
+            arr[i].log_height = t.log_height
+    return arr, keep
+
+
+def prove(hal, tables, init=(), device_traces=None):
+    """rk_p3_prove on hal's context under its current parameter set -> proof words.  device_traces: optional list of
+    (device pointer, log_height) per table for traces already in HBM."""
+    lib = _lib.load()
+    arr, keep = _c_tables(tables, device_traces)
+    iw = np.ascontiguousarray(init, dtype=np.uint32)
+    par = _lib.RkParams()
+    _lib.check(hal._ctx, lib.rk_get_params(hal._ctx, C.byref(par)))
+    cap = lib.rk_p3_proof_bound_words(C.byref(par), arr, len(tables))
+    if cap == 0:
+        raise _lib.RkError(_lib.RK_ERR_INVALID, "rk_p3_proof_bound_words: shapes the prover rejects")
+    out = np.zeros(cap, dtype=np.uint32)
+    n = C.c_size_t(0)
+    _lib.check(hal._ctx, lib.rk_p3_prove(hal._ctx, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size,
+                                        out.ctypes.data_as(_lib.u32p), cap, C.byref(n)))
+    del keep
+    return out[: n.value].copy()
+
+
+def verify(tables, proof, init=(), params=None) -> int:
+    """rk_p3_verify (host only).  params: an RkParams blob (raiko_amd.hal.make_params) or None for the SP1 preset"""
+    lib = _lib.load()
+    arr, keep = _c_tables(tables)
+    iw = np.ascontiguousarray(init, dtype=np.uint32)
+    pf = np.ascontiguousarray(proof, dtype=np.uint32)
+    rc = lib.rk_p3_verify(C.byref(params) if params is not None else None, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size,
+                          pf.ctypes.data_as(_lib.u32p), pf.size)
+    del keep
+    return rc
+
+
+def last_timing(hal) -> dict:
+    t = _lib.RkP3Timing()
+    _lib.check(hal._ctx, _lib.load().rk_p3_last_timing(hal._ctx, C.byref(t)))
+    return {n: float(getattr(t, n)) for n, _ in t._fields_}
+
+
+# ---------------------------------------------------------------------------------------------- example AIRs
+def fibonacci_air():
+    """Plonky3's uni-stark test AIR (fib_air.rs, RECALLED): columns (left, right), public values (a, b, x):
+    first row = (a, b); next.left = right, next.right = left + right; last row's right = x.  Degree 2: one quotient chunk."""
+    b = AirBuilder(2, 3)
+    l, r, nl, nr = b.local(0), b.local(1), b.next(0), b.next(1)
+    f = b.when_first_row()
+    f.assert_eq(l, b.public(0))
+    f.assert_eq(r, b.public(1))
+    t = b.when_transition()
+    t.assert_eq(nl, r)
+    t.assert_eq(nr, l + r)
+    b.when_last_row().assert_eq(r, b.public(2))
+    return b.build()
+
+
+def fibonacci_trace(log_n, a=0, b=1):
+    n = 1 << log_n
+    t = np.zeros((n, 2), dtype=np.uint64)
+    t[0] = (a, b)
+    for i in range(1, n):
+        t[i] = (t[i - 1][1], (int(t[i - 1][0]) + int(t[i - 1][1])) % P)
+    return t.astype(np.uint32), [a, b, int(t[n - 1][1])]
+
+
+def cubic_air(width=6):
+    """A degree-3 AIR (two quotient chunks): column 0 is x -> x^3 + c row to row (c public), columns 2k+1, 2k+2 hold
+    y_k and y_k^2 * x for running pairs, a boolean flag column gates an accumulator.  Exercises MUL chains, NEG,
+    constants, public values, all three selectors and a constraint of degree 3."""
+    assert width >= 4
+    b = AirBuilder(width, 2)
+    x, nx = b.local(0), b.next(0)
+    flag, acc, nacc = b.local(1), b.local(2), b.next(2)
+    c = b.public(0)
+    b.when_first_row().assert_eq(x, b.public(1))
+    b.when_first_row().assert_zero(acc)
+    b.when_transition().assert_eq(nx, x * x * x + c)          # degree 3
+    b.assert_zero(flag * (flag - 1))                          # boolean, every row
+    b.when_transition().assert_eq(nacc, acc + flag * x)       # gated sum
+    for k in range(3, width):
+        y = b.local(k)
+        b.assert_eq(y, -(b.local(k - 1) * x) + 7)             # y_k = 7 - y_(k-1) x
+    return b.build()
+
+
+def cubic_trace(log_n, width=6, seed=1):
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    c, x0 = int(rng.integers(0, P)), int(rng.integers(0, P))
+    t = np.zeros((n, width), dtype=object)
+    x, acc = x0, 0
+    for i in range(n):
+        flag = int(rng.integers(0, 2))
+        row = [x, flag, acc]
+        for k in range(3, width):
+            row.append((7 - row[k - 1] * x) % P)
+        t[i] = row
+        acc = (acc + flag * x) % P
+        x = (x * x * x + c) % P
+    return t.astype(np.uint64).astype(np.uint32), [c, x0]
+
+
+def wide_air(width, n_terms=None, seed=3):
+    """A synthetic AIR of SP1-chip size for benchmarks: `width` columns; constraint k ties column k of the next row to a
+    degree-3 expression of three columns of this row -- next[k] = a * b * c + d -- so a valid trace is easy to fill row
+    by row and the list has ~6 ops per constraint."""
+    rng = np.random.default_rng(seed)
+    b = AirBuilder(width, 0)
+    picks = []
+    tr = b.when_transition()
+    for k in range(width):
+        i, j, l, m = (int(v) for v in rng.integers(0, width, size=4))
+        picks.append((i, j, l, m))
+        tr.assert_eq(b.next(k), b.local(i) * b.local(j) * b.local(l) + b.local(m))
+    air = b.build()
+    air.picks = picks
+    return air
+
+
+def wide_trace(air, log_n, seed=4):
+    n, w = 1 << log_n, air.width
+    rng = np.random.default_rng(seed)
+    t = np.zeros((n, w), dtype=np.uint64)
+    t[0] = rng.integers(0, P, size=w)
+    idx = np.array(air.picks, dtype=np.int64)
+    for r in range(1, n):
+        prev = t[r - 1]
+        a, b_, c, d = prev[idx[:, 0]], prev[idx[:, 1]], prev[idx[:, 2]], prev[idx[:, 3]]
+        t[r] = ((a * b_ % P) * c % P + d) % P
+    return t.astype(np.uint32), []

@@ -60,6 +60,15 @@ class OrMatrix(C.Structure):
     _fields_ = [("values", C.c_void_p), ("height", C.c_uint32), ("width", C.c_uint32), ("row_major", C.c_uint32)]
 
 
+class OrAir(C.Structure):
+    _fields_ = [("steps", C.c_void_p), ("n_steps", C.c_size_t)]
+
+
+class OrP3Table(C.Structure):
+    _fields_ = [("trace", C.c_void_p), ("log_height", C.c_uint32), ("width", C.c_uint32), ("air", C.POINTER(OrAir)),
+                ("public_values", C.c_void_p), ("n_public", C.c_uint32)]
+
+
 class OrIop(C.Structure):
     _fields_ = [("proof", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t), ("cells", C.c_uint32 * 24),
                 ("pool_used", C.c_size_t)]
@@ -138,6 +147,9 @@ def oracle():
             "or_duplex_grind": (u32, [vp, vp, sz, C.c_uint]),
             "or_pcs_coset_lde_rows": (None, [vp, vp, sz, sz]), "or_pcs_eval_at": (None, [vp, vp, sz, sz, vp]),
             "or_pcs_reduce_openings": (None, [vp, vp, sz, sz, sz, vp, vp, vp, C.c_uint64]),
+            "or_air_log_quotient_degree": (C.c_int, [C.POINTER(OrAir)]),
+            "or_p3_prove": (C.c_int, [C.POINTER(OrP3Table), u32, vp, sz, C.POINTER(u32p), C.POINTER(sz)]),
+            "or_p3_verify": (C.c_int, [C.POINTER(OrP3Table), u32, vp, sz, vp, sz]),
             "or_free": (None, [vp]), "or_max_threads": (C.c_int, []), "or_set_threads": (None, [C.c_int]),
             "or_last_timing": (None, [C.POINTER(OrTiming)]),
         }
@@ -298,6 +310,52 @@ def oracle_verify(seg, seal, toy_identity=False) -> int:
         rc = lib.or_verify_segment_circuit(C.byref(c), s.ctypes.data_as(u32p), s.size, fn, None)
     else:
         rc = lib.or_verify_segment(C.byref(c), s.ctypes.data_as(u32p), s.size)
+    del keep
+    return rc
+
+
+def _or_p3_tables(tables):
+    """raiko_amd.p3.Table list -> (OrP3Table array, keepalive)"""
+    keep = []
+    arr = (OrP3Table * len(tables))()
+    for i, t in enumerate(tables):
+        steps = np.ascontiguousarray(t.air.steps, dtype=np.uint32)
+        air = OrAir(steps=steps.ctypes.data, n_steps=steps.shape[0])
+        pv = np.ascontiguousarray(t.public_values, dtype=np.uint32)
+        keep += [steps, air, pv]
+        if t.trace is not None:
+            tr = np.ascontiguousarray(t.trace, dtype=np.uint32)
+            keep.append(tr)
+            arr[i].trace = tr.ctypes.data
+            arr[i].log_height = t.log_height
+        arr[i].width = t.air.width
+        arr[i].air = C.pointer(air)
+        arr[i].public_values = pv.ctypes.data
+        arr[i].n_public = pv.size
+    return arr, keep
+
+
+def oracle_p3_prove(tables, init=()):
+    """or_p3_prove under the oracle's current parameter set -> proof words"""
+    lib = oracle()
+    arr, keep = _or_p3_tables(tables)
+    iw = np.ascontiguousarray(init, dtype=np.uint32)
+    proof, n = u32p(), C.c_size_t(0)
+    rc = lib.or_p3_prove(arr, len(tables), ptr(iw), iw.size, C.byref(proof), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"or_p3_prove failed: {rc}")
+    out = np.ctypeslib.as_array(proof, shape=(n.value,)).copy()
+    lib.or_free(proof)
+    del keep
+    return out
+
+
+def oracle_p3_verify(tables, proof, init=()) -> int:
+    lib = oracle()
+    arr, keep = _or_p3_tables(tables)
+    iw = np.ascontiguousarray(init, dtype=np.uint32)
+    pf = np.ascontiguousarray(proof, dtype=np.uint32)
+    rc = lib.or_p3_verify(arr, len(tables), ptr(iw), iw.size, ptr(pf), pf.size)
     del keep
     return rc
 

@@ -1,0 +1,51 @@
+"""Seeded cases of the Plonky3-style STARK shared by the golden generator (tests/golden/make_p3_digests.py), the CPU test
+(oracle == golden, product verifier accepts) and the GPU test (rk_p3_prove == oracle == golden).
+case -> (preset, parameter overrides, [(air name, log_height, arg)], init words)"""
+import hashlib
+
+import numpy as np
+
+from raiko_amd import p3
+
+P3_CASES = {
+    "sp1_fib_k6": (1, dict(queries=8, pow_bits=6), [("fib", 6, None)], []),
+    "sp1_fib_k10_full": (1, dict(), [("fib", 10, None)], [1, 2, 3]),
+    "sp1_cubic_k5": (1, dict(queries=9, pow_bits=5), [("cubic", 5, 6)], [7]),
+    "sp1_mixed_fib8_cubic4": (1, dict(queries=10, pow_bits=7), [("fib", 8, None), ("cubic", 4, 5)], [5, 6, 7]),
+    "sp1_mixed_cubic6_fib3_wide7": (1, dict(queries=6, pow_bits=4), [("cubic", 6, 8), ("fib", 3, None), ("wide", 7, 12)], []),
+    "risc0_mixed_cubic5_fib7": (0, dict(queries=7, pow_bits=5), [("cubic", 5, 4), ("fib", 7, None)], [9]),
+    "risc0_fib_k1": (0, dict(queries=3), [("fib", 1, None)], []),
+    "sp1_blow2_wide_k9": (1, dict(queries=5, pow_bits=3, blowup_log2=2), [("wide", 9, 20)], [11, 12]),
+}
+
+_AIRS = {}
+
+
+def air_of(name, arg):
+    key = (name, arg)
+    if key not in _AIRS:
+        _AIRS[key] = p3.fibonacci_air() if name == "fib" else p3.cubic_air(arg) if name == "cubic" else p3.wide_air(arg)
+    return _AIRS[key]
+
+
+def tables_of(case):
+    _, _, specs, _ = P3_CASES[case]
+    out = []
+    for i, (name, k, arg) in enumerate(specs):
+        air = air_of(name, arg)
+        if name == "fib":
+            tr, pv = p3.fibonacci_trace(k, 1 + i, 2)
+        elif name == "cubic":
+            tr, pv = p3.cubic_trace(k, arg, seed=10 + i)
+        else:
+            tr, pv = p3.wide_trace(air, k, seed=20 + i)
+        out.append(p3.Table.from_canonical(air, tr, pv))
+    return out
+
+
+def init_of(case):
+    return p3.to_mont(np.array(P3_CASES[case][3], dtype=np.uint64))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint32).tobytes()).hexdigest()

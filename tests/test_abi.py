@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), "library does not export " + n
         assert n in _lib.SYMBOLS, "no ctypes prototype for " + n
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.rk_abi_version() == 3
+    assert lib.rk_abi_version() == 4
     assert lib.rk_strerror(-1) == b"invalid argument"
 
 

@@ -1,0 +1,122 @@
+"""rk_p3_prove on the GPU against the oracle (oracle/or_p3.c) and the committed digests: the proof words are identical
+for single tables (Fibonacci -- Plonky3's own uni-stark test AIR --, a degree-3 AIR with two quotient chunks), for
+mixed-height multi-table proofs under shared challenges (the way sp1-core proves the chips of a shard), under SP1's
+parameter set, risc0's field / Poseidon2 instance and a larger blow-up, with the quotient evaluated by the interpreter
+and by the hiprtc-generated kernel, from host and from device-resident traces; rk_p3_verify accepts them and refuses a
+proof made from a trace that breaks its AIR.  Reference call site: provers/sp1/driver/src/lib.rs:44-57."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from p3_cases import P3_CASES, air_of, init_of, sha, tables_of
+from raiko_amd import hal as H, p3
+
+pytestmark = pytest.mark.gpu
+P = o.P
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "p3_digests.json")))
+
+
+@pytest.fixture()
+def hal():
+    h = H.HipHal(0)
+    yield h
+    o.oracle_set_params()
+    h.close()
+
+
+@pytest.mark.parametrize("case", sorted(P3_CASES))
+def test_gpu_proof_equals_oracle_and_committed_digest(hal, case):
+    preset, over, _, _ = P3_CASES[case]
+    blob = hal.set_params(preset, **over)
+    o.oracle_set_params(preset, **over)
+    tables, init = tables_of(case), init_of(case)
+    got = p3.prove(hal, tables, init)
+    assert {"words": int(got.size), "sha256": sha(got)} == GOLD[case]       # the committed file alone
+    want = o.oracle_p3_prove(tables, init)
+    assert np.array_equal(got, want)
+    assert p3.verify(tables, got, init, params=blob) == 0
+    assert o.oracle_p3_verify(tables, got, init) == 0
+    tm = p3.last_timing(hal)
+    assert tm["total"] > 0 and tm["quotient"] > 0
+
+
+def test_generated_kernel_gives_the_same_proof(hal):
+    case = "sp1_mixed_cubic6_fib3_wide7"
+    preset, over, _, _ = P3_CASES[case]
+    hal.set_params(preset, **over)
+    tables, init = tables_of(case), init_of(case)
+    interp = p3.prove(hal, tables, init)
+    for t in tables:
+        t.air.compile(hal)          # rk_air_compile: straight-line HIP through hiprtc
+    jit = p3.prove(hal, tables, init)
+    assert np.array_equal(interp, jit)
+    assert sha(jit) == GOLD[case]["sha256"]
+    # fresh AIR objects for the other tests: a compiled list stays compiled for the life of its handle
+    from p3_cases import _AIRS
+    _AIRS.clear()
+
+
+def test_device_resident_traces(hal):
+    case = "sp1_mixed_fib8_cubic4"
+    preset, over, _, _ = P3_CASES[case]
+    hal.set_params(preset, **over)
+    tables, init = tables_of(case), init_of(case)
+    bufs = [hal.copy_from_elem(t.trace) for t in tables]
+    dev = [(H._ptr(b), t.log_height) for b, t in zip(bufs, tables)]
+    got = p3.prove(hal, tables, init, device_traces=dev)
+    assert sha(got) == GOLD[case]["sha256"]
+    for b, t in zip(bufs, tables):                     # on_device inputs are left untouched
+        assert np.array_equal(b.to_host().reshape(t.trace.shape), t.trace)
+
+
+def test_a_trace_that_breaks_its_air_is_refused_by_the_verifier(hal):
+    over = dict(queries=5, pow_bits=4)
+    blob = hal.set_params(1, **over)
+    o.oracle_set_params(1, **over)
+    air = air_of("cubic", 6)
+    tr, pv = p3.cubic_trace(6, 6, seed=2)
+    good = [p3.Table.from_canonical(air, tr, pv)]
+    assert p3.verify(good, p3.prove(hal, good), params=blob) == 0
+    tr[11, 2] = (int(tr[11, 2]) + 5) % P
+    bad = [p3.Table.from_canonical(air, tr, pv)]
+    pf = p3.prove(hal, bad)
+    assert np.array_equal(pf, o.oracle_p3_prove(bad))
+    assert p3.verify(bad, pf, params=blob) == 3
+
+
+def test_larger_shard_shaped_proof(hal):
+    """three tables of 2^15 / 2^12 / 2^9 rows, 48 / 24 / 2 columns, SP1's full parameter set"""
+    blob = hal.set_params(1)
+    o.oracle_set_params(1)
+    a1, a2, a3 = p3.wide_air(48, seed=5), p3.wide_air(24, seed=6), p3.fibonacci_air()
+    tables = [p3.Table.from_canonical(a1, *p3.wide_trace(a1, 15)), p3.Table.from_canonical(a2, *p3.wide_trace(a2, 12)),
+              p3.Table.from_canonical(a3, *p3.fibonacci_trace(9))]
+    init = p3.to_mont([3, 1, 4, 1, 5, 9, 2, 6, 5, 3])          # more than one sponge block of observations
+    got = p3.prove(hal, tables, init)
+    assert np.array_equal(got, o.oracle_p3_prove(tables, init))
+    assert p3.verify(tables, got, init, params=blob) == 0
+
+
+def test_capacity_and_argument_errors(hal):
+    import ctypes as C
+    from raiko_amd import _lib
+    hal.set_params(1, queries=4, pow_bits=2)
+    tables = [p3.Table.from_canonical(air_of("fib", None), *p3.fibonacci_trace(4))]
+    arr, keep = p3._c_tables(tables)
+    lib = _lib.load()
+    par = hal.get_params()
+    need = lib.rk_p3_proof_bound_words(C.byref(par), arr, 1)
+    out = np.zeros(need, dtype=np.uint32)
+    n = C.c_size_t(0)
+    assert lib.rk_p3_prove(hal._ctx, arr, 1, None, 0, out.ctypes.data_as(_lib.u32p), need - 1, C.byref(n)) == -5   # RK_ERR_CAPACITY
+    assert n.value == need
+    assert lib.rk_p3_prove(hal._ctx, arr, 1, None, 0, out.ctypes.data_as(_lib.u32p), need, C.byref(n)) == 0 and n.value == need
+    arr[0].log_height = 0
+    assert lib.rk_p3_prove(hal._ctx, arr, 1, None, 0, out.ctypes.data_as(_lib.u32p), need, C.byref(n)) == -1
+    arr[0].log_height = 4
+    arr[0].width = 3                                   # not the AIR's
+    assert lib.rk_p3_prove(hal._ctx, arr, 1, None, 0, out.ctypes.data_as(_lib.u32p), need, C.byref(n)) == -1
+    del keep

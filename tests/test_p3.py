@@ -1,0 +1,144 @@
+"""Plonky3-style STARK, CPU side: the oracle (oracle/or_p3.c) against its own verifier, against the committed digests and
+against the PRODUCT's host verifier rk_p3_verify (no GPU needed for verification), plus the AIR front end
+(rk_air_create: validation, symbolic degree) and hostile proofs.  Reference call site of the path:
+provers/sp1/driver/src/lib.rs:44-57 (`client.prove`); the Plonky3 crates are outside the reference tree -- RECALLED,
+parity unpinned: what pins the oracle here is that an independent verifier written from the verifier's side of the
+protocol (reduced openings recomputed from opened rows, folds as lines through (x, e), (-x, e')) accepts it and that
+the constraint identity holds only for traces that satisfy their AIR."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from p3_cases import P3_CASES, init_of, sha, tables_of
+from raiko_amd import _lib, hal, p3
+
+P = o.P
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "p3_digests.json")))
+
+
+@pytest.fixture()
+def params():
+    yield o.oracle_set_params
+    o.oracle_set_params()
+
+
+def test_cases_match_committed_digests_and_both_verifiers_accept(params):
+    assert sorted(GOLD) == sorted(P3_CASES)
+    for case, (preset, over, _, _) in P3_CASES.items():
+        params(preset, **over)
+        blob = hal.make_params(preset, **over)
+        tables, init = tables_of(case), init_of(case)
+        for t in tables:
+            assert t.air.check_trace(o.from_mont(t.trace), o.from_mont(t.public_values)) == [] or t.trace.shape[0] > 256
+        pf = o.oracle_p3_prove(tables, init)
+        assert {"words": int(pf.size), "sha256": sha(pf)} == GOLD[case], case
+        assert o.oracle_p3_verify(tables, pf, init) == 0
+        assert p3.verify(tables, pf, init, params=blob) == 0
+        # bound to the statement: other init words, other public values, another parameter set
+        assert p3.verify(tables, pf, np.concatenate([init, [1]]).astype(np.uint32), params=blob) != 0
+        if tables[0].public_values.size:
+            other = p3.Table(tables[0].air, tables[0].trace, tables[0].public_values.copy())
+            other.public_values[0] = (int(other.public_values[0]) + 1) % P
+            assert p3.verify([other] + tables[1:], pf, init, params=blob) != 0
+            assert o.oracle_p3_verify([other] + tables[1:], pf, init) != 0
+        assert p3.verify(tables, pf, init, params=hal.make_params(1 - preset)) != 0
+
+
+def test_symbolic_degree_and_info(params):
+    lib = o.oracle()
+    for name, arg, want in (("fib", None, 0), ("cubic", 6, 1), ("wide", 9, 1)):
+        from p3_cases import air_of
+        air = air_of(name, arg)
+        steps = np.ascontiguousarray(air.steps, dtype=np.uint32)
+        oair = o.OrAir(steps=steps.ctypes.data, n_steps=steps.shape[0])
+        assert air.log_quotient_degree() == want == lib.or_air_log_quotient_degree(oair) == air.info()["log_quotient_degree"]
+        assert air.info()["n_constraints"] == air.n_constraints
+    # a degree-5 constraint needs four chunks; a degree-9 one more than any supported blow-up covers
+    b = p3.AirBuilder(1)
+    x = b.local(0)
+    b.assert_zero(x * x * x * x * x - x)
+    assert b.build().info()["log_quotient_degree"] == 2
+
+
+def test_air_create_rejects_malformed_lists():
+    lib = _lib.load()
+    import ctypes as C
+
+    def create(steps, width=2, n_public=1):
+        a = np.array(steps, dtype=np.uint32).reshape(-1, 3)
+        h = C.c_void_p()
+        rc = lib.rk_air_create(a.ctypes.data, a.shape[0], width, n_public, C.byref(h))
+        if rc == 0:
+            lib.rk_air_destroy(h)
+        return rc
+
+    assert create([(p3.LOCAL, 0, 0), (p3.ASSERT_ZERO, 0, 0)]) == 0
+    assert create([(p3.LOCAL, 2, 0), (p3.ASSERT_ZERO, 0, 0)]) == -1          # column out of range
+    assert create([(p3.PUBLIC, 1, 0), (p3.ASSERT_ZERO, 0, 0)]) == -1         # public value out of range
+    assert create([(p3.LOCAL, 0, 0), (p3.ADD, 0, 1), (p3.ASSERT_ZERO, 1, 0)]) == -1   # operand not yet pushed
+    assert create([(p3.LOCAL, 0, 0), (p3.ASSERT_ZERO, 1, 0)]) == -1
+    assert create([(p3.CONST, P, 0), (p3.ASSERT_ZERO, 0, 0)]) == -1          # not canonical
+    assert create([(12, 0, 0)]) == -1                                        # unknown op
+    assert create([(p3.LOCAL, 0, 0)]) == 0                                   # no constraint at all is a valid (empty) AIR
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_hostile_proofs_are_rejected_by_both_verifiers_with_the_same_reason(params, preset):
+    over = dict(queries=6, pow_bits=5)
+    params(preset, **over)
+    blob = hal.make_params(preset, **over)
+    from p3_cases import air_of
+    a1, a2 = air_of("cubic", 5), air_of("fib", None)
+    t1 = p3.Table.from_canonical(a1, *p3.cubic_trace(5, 5, seed=3))
+    t2 = p3.Table.from_canonical(a2, *p3.fibonacci_trace(3))
+    tables, init = [t1, t2], p3.to_mont([4, 5])
+    pf = o.oracle_p3_prove(tables, init)
+    assert p3.verify(tables, pf, init, params=blob) == 0
+    rng = np.random.default_rng(preset)
+    seen = set()
+    for k in range(500):
+        s = pf.copy()
+        kind = k % 6
+        if kind == 0:
+            i = int(rng.integers(0, s.size)); s[i] = (int(s[i]) + 1) % P
+        elif kind == 1:
+            i = int(rng.integers(0, s.size)); s[i] = int(rng.integers(P, 1 << 32))           # not a field element
+        elif kind == 2:
+            s = s[: int(rng.integers(0, s.size))]
+        elif kind == 3:
+            s = np.concatenate([s, rng.integers(0, P, size=int(rng.integers(1, 30)), dtype=np.uint32)])
+        elif kind == 4:
+            a, b = sorted(int(x) for x in rng.integers(0, s.size, size=2))
+            s[a:b] = rng.integers(0, P, size=b - a, dtype=np.uint32)
+        else:
+            i = int(rng.integers(0, s.size)); s[i] ^= 1 << int(rng.integers(0, 30))
+        got, want = p3.verify(tables, s, init, params=blob), o.oracle_p3_verify(tables, s, init)
+        if np.array_equal(s, pf):
+            continue
+        assert got != 0 and want != 0
+        assert got == want, (k, got, want)
+        seen.add(got)
+    assert {1, 5, 6} <= seen
+    # a witness that breaks one constraint still yields a proof (Plonky3 checks constraints in debug builds only);
+    # the constraint identity at zeta exposes it
+    tr, pv = p3.cubic_trace(5, 5, seed=3)
+    tr[7, 0] = (int(tr[7, 0]) + 1) % P
+    bad = [p3.Table.from_canonical(a1, tr, pv), t2]
+    assert a1.check_trace(tr, pv) != []
+    pfb = o.oracle_p3_prove(bad, init)
+    assert o.oracle_p3_verify(bad, pfb, init) == 3 and p3.verify(bad, pfb, init, params=blob) == 3
+
+
+def test_quotient_degree_above_the_blowup_is_refused(params):
+    params(1)           # blow-up 2: two chunks at most
+    b = p3.AirBuilder(1)
+    x = b.local(0)
+    b.assert_zero(x * x * x * x - x)          # degree 4: four chunks
+    air = b.build()
+    t = p3.Table.from_canonical(air, np.zeros((4, 1), dtype=np.uint64))
+    with pytest.raises(RuntimeError):
+        o.oracle_p3_prove([t])
+    assert p3.verify([t], np.zeros(100, dtype=np.uint32)) == -1
