@@ -45,10 +45,14 @@ def parse_args():
     ap.add_argument("--total-segments", type=int, default=0,
                     help="strong scaling: this many segments in all, sharded round-robin over the ranks "
                          "(--steps is then ignored); default 0 = every rank proves --steps segments (weak)")
-    ap.add_argument("--preset", choices=["risc0", "sp1"], default="risc0",
+    ap.add_argument("--preset", choices=["risc0", "sp1", "sp1-p3"], default="risc0",
                     help="parameter set of the proofs (rk_session_opts.params): sp1 = SP1 core's RECALLED set -- x^4 - 11, "
                          "Poseidon2 width 16, blow-up 2, FRI fold 2 down to a constant, 100 queries, 16 proof-of-work bits; "
-                         "the contract line is risc0's")
+                         "the contract line is risc0's.  sp1-p3: not a segment proof at all but SP1's own proof system as far as "
+                         "it is built (rk_p3_prove: Plonky3-style uni-stark over the two-adic FRI PCS, --p3-shape tables of a "
+                         "chip-shaped synthetic AIR under SP1's parameter set); its line has its own metric")
+    ap.add_argument("--p3-shape", default="20x256,19x128,16x64,10x32", help="--preset sp1-p3: log2 rows x columns per table")
+    ap.add_argument("--p3-jit", action="store_true", help="--preset sp1-p3: quotient through the hiprtc-generated kernel")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (value_with_h2d) run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-small", action="store_true",
@@ -72,8 +76,28 @@ def device_segment(torch, seg_mod, po2, widths, seed, device, blowup_log2=2):
     return seg, groups, check
 
 
+def main_p3(args):
+    """BASELINE config 5 as far as it is built: one shard-shaped rk_p3_prove per step (tools/bench_p3.py), verified on the host"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_p3
+    ns = argparse.Namespace(shape=args.p3_shape, jit=args.p3_jit, reps=max(args.steps, 1), preset=1, no_verify=False)
+    r = bench_p3.run(ns)
+    out = {"metric": "proven trace cells/sec (Plonky3-style uni-stark, SP1 parameter set; NOT the contract metric)",
+           "value": r["cells_per_s"], "unit": "cells/s", "n_gpus": 1, "steps": ns.reps, "warmup": 1, "ms_per_step": r["wall_ms"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
+           "config": {"workload": "one rk_p3_prove of tables %s (log2 rows x columns, chip-shaped degree-3 AIR, %s ops per quotient "
+                                  "point), blow-up 2, 100 queries, 16 proof-of-work bits, Poseidon2 width 16" % (r["shape"], r["ops_per_point"]),
+                      "entry_point": "rk_p3_prove (on_device traces) + rk_p3_verify", "quotient": "generated kernel" if r["jit"] else "interpreter"},
+           "stages_ms": r["stages_ms"], "proof_words": r["proof_words"], "verify_rc": r["verify_rc"], "verify_ms": r["verify_ms"]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.preset == "sp1-p3":
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--preset sp1-p3 is a one-GPU line")
+        return main_p3(args)
     widths = tuple(int(x) for x in args.widths.split(","))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -389,3 +389,35 @@ def wide_trace(air, log_n, seed=4):
         a, b_, c, d = prev[idx[:, 0]], prev[idx[:, 1]], prev[idx[:, 2]], prev[idx[:, 3]]
         t[r] = ((a * b_ % P) * c % P + d) % P
     return t.astype(np.uint32), []
+
+
+def local_air(width, seed=7):
+    """A chip-shaped AIR for benchmarks whose trace is filled column-wise (no row-to-row recurrence except a counter):
+    columns [0, width/2) are inputs -- column 0 counts rows (first row 0, next = local + 1), the others are free --,
+    column width/2 + k = in_i * in_j * in_l + in_m for seeded picks: degree 3, two quotient chunks, 5 ops a constraint."""
+    assert width >= 4 and width % 2 == 0
+    half = width // 2
+    rng = np.random.default_rng(seed)
+    b = AirBuilder(width, 0)
+    b.when_first_row().assert_zero(b.local(0))
+    b.when_transition().assert_eq(b.next(0), b.local(0) + 1)
+    picks = rng.integers(0, half, size=(half, 4))
+    for k in range(half):
+        i, j, l, m = (int(v) for v in picks[k])
+        b.assert_eq(b.local(half + k), b.local(i) * b.local(j) * b.local(l) + b.local(m))
+    air = b.build()
+    air.picks = picks
+    return air
+
+
+def local_trace(air, log_n, seed=8):
+    n, w = 1 << log_n, air.width
+    half = w // 2
+    rng = np.random.default_rng(seed)
+    c = np.zeros((w, n), dtype=np.uint64)              # filled column by column, transposed at the end
+    c[:half] = rng.integers(0, P, size=(half, n), dtype=np.uint64)
+    c[0] = np.arange(n, dtype=np.uint64) % P
+    for k in range(half):
+        i, j, l, m = (int(v) for v in air.picks[k])
+        c[half + k] = (c[i] * c[j] % P * c[l] + c[m]) % P
+    return np.ascontiguousarray(c.T).astype(np.uint32), []

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""rk_p3_prove on shard-shaped inputs: per-stage wall clock (rk_p3_last_timing), proof size, verification.
+  python tools/bench_p3.py [--shape 20x256,19x128,...] [--jit] [--reps 3] [--preset 1]
+Prints one JSON line per run (profiles/r03_bench_p3*.jsonl)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from raiko_amd import hal as H, p3  # noqa: E402
+
+
+def device_trace(torch, air, log_n, seed):
+    """p3.local_trace on the GPU: (n, w) int32 tensor of Montgomery words"""
+    P = p3.P
+    n, w = 1 << log_n, air.width
+    half = w // 2
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    c = torch.zeros((w, n), dtype=torch.int64, device="cuda")
+    c[:half] = torch.randint(0, P, (half, n), dtype=torch.int64, device="cuda", generator=g)
+    c[0] = torch.arange(n, dtype=torch.int64, device="cuda") % P
+    for k in range(half):
+        i, j, l, m = (int(v) for v in air.picks[k])
+        c[half + k] = (c[i] * c[j] % P * c[l] + c[m]) % P
+    mont = c * ((1 << 32) % P) % P
+    return mont.t().contiguous().to(torch.int32)      # < 2^31: the same words as uint32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="20x256")
+    ap.add_argument("--jit", action="store_true")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--preset", type=int, default=1)
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+    print(json.dumps(run(args)), flush=True)
+
+
+def run(args):
+    import torch
+    hal = H.HipHal(0)
+    blob = hal.set_params(args.preset)
+    tables, bufs, dev = [], [], []
+    t0 = time.perf_counter()
+    cells = 0
+    for i, spec in enumerate(args.shape.split(",")):
+        k, w = (int(v) for v in spec.split("x"))
+        air = p3.local_air(w, seed=7 + i)
+        t = p3.Table(air, None, [])
+        t.log_height = k
+        if args.jit:
+            t.air.compile(hal)
+        tables.append(t)
+        b = device_trace(torch, air, k, 8 + i)
+        bufs.append(b)
+        dev.append((b.data_ptr(), k))
+        cells += (1 << k) * w
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    p3.prove(hal, tables, device_traces=dev)        # warm-up: first-touch allocations, tables
+    best = None
+    for _ in range(args.reps):
+        t1 = time.perf_counter()
+        pf = p3.prove(hal, tables, device_traces=dev)
+        wall = (time.perf_counter() - t1) * 1e3
+        tm = p3.last_timing(hal)
+        if best is None or wall < best[0]:
+            best = (wall, tm)
+    out = {"shape": args.shape, "preset": args.preset, "jit": args.jit, "trace_cells": int(cells), "wall_ms": round(best[0], 3),
+           "stages_ms": {k: round(v, 3) for k, v in best[1].items()}, "proof_words": int(pf.size),
+           "cells_per_s": round(cells / best[0] * 1e3, 1), "ops_per_point": [t.air.info()["n_ops"] for t in tables],
+           "setup_s": round(setup_s, 2)}
+    if not args.no_verify:
+        t2 = time.perf_counter()
+        out["verify_rc"] = p3.verify(tables, pf, params=blob)
+        out["verify_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
+    hal.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()
