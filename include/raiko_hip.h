@@ -428,9 +428,22 @@ int rk_prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t
 typedef struct rk_stream rk_stream;
 int rk_stream_open(const rk_session_opts* opts, rk_stream** out);
 int rk_stream_submit(rk_stream* stream, const rk_segment* seg, uint32_t* h_seal, size_t seal_capacity_words, size_t* seal_words);
+/* Back-pressure for hosts whose sessions are larger than memory (the reference keeps segments on disk for that reason:
+ * segment_path, bonsai.rs:261-266): blocks until at most max_pending submitted segments are unfinished (or one has
+ * failed: the status so far is returned), and reports in *finished_prefix how many segments from the start of the
+ * submission order are done -- their inputs and everything their rk_segment pointed at may be freed, their seals and
+ * seal_words are final.  A host submits segment k, waits with max_pending = inflight + upload_ahead, frees what the
+ * prefix has released, and only then generates the witness of segment k + 1. */
+int rk_stream_wait(rk_stream* stream, size_t max_pending, size_t* finished_prefix);
 int rk_stream_close(rk_stream* stream, size_t* failed_index);
 const char* rk_session_last_error(int device);
+/* how many segments `device` proved in the last session it took part in (the balance of the work queue) */
+int rk_session_last_proven(int device, size_t* count);
 int rk_session_release(void);
+/* Test switch: with RK_TEST_LOGICAL_DEVICES=k in the environment the session entry points see k devices, logical
+ * device d running on physical GPU d mod (number of GPUs) -- the multi-device path (a pool, a feeder and `inflight`
+ * provers per device, session-wide claim flags, pinning of device-resident segments to the first device of the GPU
+ * that holds them) on a box with one GPU.  Not for production: the devices share one GPU's memory and time. */
 
 /* ---- RV32IM executor + segmenter: the step before the path ----
  * `ExecutorImpl::from_elf(env, elf).run()` (provers/risc0/driver/src/bonsai.rs:267-269): interprets a
@@ -451,6 +464,8 @@ typedef struct {
     const uint32_t* input_words;   /* env.write_slice(&encoded_input), bonsai.rs:250 */
     size_t n_input_words;
     uint32_t record_trace;         /* keep every executed cycle (28 bytes each) for rk_exec_witness */
+    uint32_t profile;              /* count executed cycles per pc (rk_exec_profile): what the reference switches on with
+                                    * `profile: true` -> env_builder.enable_profiler(..), bonsai.rs:252-255 */
 } rk_exec_opts;
 typedef struct {
     uint64_t total_cycles;
@@ -478,6 +493,9 @@ int rk_exec_next_segment(rk_exec* ex, int* more);
 int rk_exec_summary_get(const rk_exec* ex, rk_exec_summary* out);
 int rk_exec_segment_get(const rk_exec* ex, uint32_t index, rk_exec_segment* out);
 int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* len);
+/* the cycle profile of a run made with rk_exec_opts.profile: distinct program counters and the cycles spent at each,
+ * most expensive first; *n = how many there are (RK_ERR_CAPACITY when more than `capacity`: call again) */
+int rk_exec_profile(const rk_exec* ex, uint32_t* pcs, uint64_t* cycles, size_t capacity, size_t* n);
 /* Witness generation for the STAND-IN trace circuit (not rv32im's: that layout is in a crate outside the
  * reference tree).  Columns of executed segment `index`, column-major 2^po2 rows, Montgomery form, every 32-bit
  * machine word as two 16-bit field elements; needs rk_exec_opts.record_trace:

@@ -233,6 +233,7 @@ pub struct rk_exec_opts {
     pub input_words: *const u32,
     pub n_input_words: usize,
     pub record_trace: u32,
+    pub profile: u32,
 }
 
 #[repr(C)]
@@ -384,8 +385,10 @@ extern "C" {
     pub fn rk_prove_session(opts: *const rk_session_opts, segs: *const rk_segment, n: usize, h_seals: *const *mut u32, seal_capacity_words: *const usize, seal_words: *mut usize, failed_index: *mut usize) -> c_int;
     pub fn rk_stream_open(opts: *const rk_session_opts, out: *mut *mut rk_stream) -> c_int;
     pub fn rk_stream_submit(stream: *mut rk_stream, seg: *const rk_segment, h_seal: *mut u32, seal_capacity_words: usize, seal_words: *mut usize) -> c_int;
+    pub fn rk_stream_wait(stream: *mut rk_stream, max_pending: usize, finished_prefix: *mut usize) -> c_int;
     pub fn rk_stream_close(stream: *mut rk_stream, failed_index: *mut usize) -> c_int;
     pub fn rk_session_last_error(device: c_int) -> *const c_char;
+    pub fn rk_session_last_proven(device: c_int, count: *mut usize) -> c_int;
     pub fn rk_session_release() -> c_int;
     pub fn rk_exec_elf(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
     pub fn rk_exec_open(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
@@ -393,6 +396,7 @@ extern "C" {
     pub fn rk_exec_summary_get(ex: *const rk_exec, out: *mut rk_exec_summary) -> c_int;
     pub fn rk_exec_segment_get(ex: *const rk_exec, index: u32, out: *mut rk_exec_segment) -> c_int;
     pub fn rk_exec_journal(ex: *const rk_exec, out: *mut u8, capacity: usize, len: *mut usize) -> c_int;
+    pub fn rk_exec_profile(ex: *const rk_exec, pcs: *mut u32, cycles: *mut u64, capacity: usize, n: *mut usize) -> c_int;
     pub fn rk_exec_witness(ex: *const rk_exec, index: u32, code: *mut u32, data: *mut u32) -> c_int;
     pub fn rk_exec_witness_device(ctx: *mut rk_ctx, ex: *const rk_exec, index: u32, d_code: *mut u32, d_data: *mut u32) -> c_int;
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;

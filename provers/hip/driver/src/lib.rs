@@ -5,9 +5,12 @@
 //! file (`bincode (String, Receipt)`, bonsai.rs:274-310).  What changes is the line
 //! `session.prove()` (bonsai.rs:271): the executor and the rv32im circuit's witness / constraint
 //! code stay risc0's, every prover stage behind `risc0_zkp::hal::Hal` runs in libraiko_hip.so
-//! through ONE call, `rk_prove_session`, which keeps several segment proofs in flight per GPU,
-//! stages the witness uploads ahead and verifies each seal; the two circuit steps that need
-//! Fiat-Shamir randomness (`accumulate`, `eval_check`) come back as `rk_circuit_hooks` callbacks.
+//! through the session entry point in its streaming form (`rk_stream_open / submit / wait / close`:
+//! `rk_prove_session` for segments that arrive one by one), which keeps several segment proofs in
+//! flight per GPU, stages the witness uploads ahead and verifies each seal, while `rk_stream_wait`
+//! bounds how many witnesses exist at once; of the two circuit steps that need Fiat-Shamir
+//! randomness `eval_check` runs on the GPU from the circuit's step list (`rk_program`) and
+//! `accumulate` comes back as an `rk_circuit_hooks` callback.
 //!
 //! NOT COMPILED IN THE BUILD IMAGE (no Rust toolchain there).  Items of raiko itself are written
 //! against the reference tree and cited; items *inside* risc0 crates (`Segment`, `CpuCircuitHal`,
@@ -117,11 +120,12 @@ impl Prover for HipProver {
                 // the reference blocks the async worker for the whole proof (bonsai.rs:230 is a sync fn
                 // called from async code); the SGX backend shows the remedy (provers/sgx/prover/src/lib.rs:276)
                 let po2 = param.execution_po2;
+                let profile = param.profile;
                 #[cfg(feature = "pipelined")]
                 let prove = prove_locally_pipelined;
                 #[cfg(not(feature = "pipelined"))]
                 let prove = prove_locally;
-                let receipt = tokio::task::spawn_blocking(move || prove(po2, encoded_input, &hip))
+                let receipt = tokio::task::spawn_blocking(move || prove(po2, encoded_input, &hip, profile))
                     .await
                     .map_err(|e| ProverError::GuestError(e.to_string()))??;
                 save_receipt(&label, &(String::new(), receipt.clone()))?;
@@ -156,162 +160,187 @@ struct Witness {
     hook: Box<CircuitHook>,
 }
 
-fn prove_locally(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Receipt, String> {
-    // bonsai.rs:246-269 -- unchanged except for a private segment directory: the shared, wiped
-    // /tmp/risc0-cache of the reference (bonsai.rs:261-265) races under concurrency_limit = 16
+/// Segments in flight between the witness generator and the GPU: an `rk_stream` with back-pressure.
+///
+/// The reference keeps a session's segments on disk (`segment_path`, bonsai.rs:261-266) so that a proof may be larger
+/// than memory; a witness is ~1 GB at po2 = 20 and a block has hundreds to thousands of segments, so this side must
+/// not hold more than a window of them either.  `submit` hands one witness to the stream and then blocks in
+/// `rk_stream_wait` until at most `max_pending` = inflight + upload_ahead (per GPU) segments are unfinished; whatever
+/// the finished prefix has released is dropped before the caller generates the next witness.  Seals (~0.3 MB each)
+/// are the result and stay.  Dropping the window closes the stream on every path, also the early returns.
+struct Window {
+    stream: *mut rk_stream,
+    device: c_int,
+    max_pending: usize,
+    taps: circuit::TapTables,
+    // everything a submitted rk_segment points at lives until the stream reports it finished: boxed, never moved
+    witnesses: std::collections::VecDeque<Option<Box<Witness>>>,
+    first: usize, // submission index of witnesses[0]
+    seals: Vec<Box<(Vec<u32>, usize)>>,
+    // opts point into these: kept alive (and at a fixed address) for the life of the stream
+    _devices: Vec<c_int>,
+    _vopts: Box<rk_verify_opts>,
+}
+
+impl Window {
+    fn open(hip: &HipParam) -> Result<Self, String> {
+        let vopts = Box::new(rk_verify_opts {
+            p2_rc_ext: ptr::null(),
+            p2_rc_int: ptr::null(),
+            p2_diag: ptr::null(),
+            // the step list when the circuit crate exposes it (the identity is then checked by the library's own
+            // evaluator), risc0's CircuitDef::poly_ext otherwise
+            poly_ext: if circuit::program().is_null() { Some(circuit::poly_ext_trampoline) } else { None },
+            user: ptr::null_mut(),
+            program: circuit::program(),
+            params: ptr::null(), // risc0's parameter set is the library default
+        });
+        let devices: Vec<c_int> = hip.devices.iter().map(|&d| d as c_int).collect();
+        let opts = rk_session_opts {
+            device: devices.first().copied().unwrap_or(0),
+            inflight: hip.inflight,
+            upload_ahead: hip.upload_ahead,
+            verify: 1,
+            devices: if devices.len() > 1 { devices.as_ptr() } else { ptr::null() },
+            n_devices: if devices.len() > 1 { devices.len() as c_int } else { 0 },
+            verify_opts: &*vopts,
+            params: ptr::null(),
+        };
+        let mut stream: *mut rk_stream = ptr::null_mut();
+        let st = unsafe { rk_stream_open(&opts, &mut stream) }; // devices / verify_opts are copied by the library
+        if st != RK_OK {
+            return Err(describe(st, opts.device, usize::MAX));
+        }
+        let gpus = devices.len().max(1);
+        Ok(Window {
+            stream,
+            device: opts.device,
+            max_pending: gpus * (hip.inflight.max(1) as usize + hip.upload_ahead.max(0) as usize),
+            taps: circuit::tapset(),
+            witnesses: Default::default(),
+            first: 0,
+            seals: Vec::new(),
+            _devices: devices,
+            _vopts: vopts,
+        })
+    }
+
+    /// Hands one segment over; returns once the window has room for the next witness.
+    fn submit(&mut self, w: Witness) -> Result<(), String> {
+        let w = Box::new(w);
+        let c_seg = w.as_rk_segment(&self.taps);
+        let cap = unsafe { rk_seal_bound_words(&c_seg) };
+        if cap == 0 {
+            return Err(format!("segment {}: shape rejected by libraiko_hip", self.seals.len()));
+        }
+        let mut out = Box::new((vec![0u32; cap], 0usize));
+        let st = unsafe { rk_stream_submit(self.stream, &c_seg, out.0.as_mut_ptr(), cap, &mut out.1) };
+        // pushed before the status is looked at: the library may already hold pointers into both
+        self.witnesses.push_back(Some(w));
+        self.seals.push(out);
+        if st != RK_OK {
+            return Err(format!("rk_stream_submit: status {st}"));
+        }
+        let mut prefix = 0usize;
+        let st = unsafe { rk_stream_wait(self.stream, self.max_pending, &mut prefix) };
+        while self.first < prefix && !self.witnesses.is_empty() {
+            self.witnesses.pop_front(); // ~1 GB each at po2 = 20: gone as soon as the seal has landed
+            self.first += 1;
+        }
+        if st != RK_OK {
+            return Err(describe(st, self.device, usize::MAX)); // finish() names the segment
+        }
+        Ok(())
+    }
+
+    /// Waits for everything submitted and returns the seals in submission order.
+    fn finish(mut self) -> Result<Vec<Vec<u32>>, String> {
+        let mut failed = usize::MAX;
+        let st = unsafe { rk_stream_close(self.stream, &mut failed) };
+        self.stream = ptr::null_mut();
+        self.witnesses.clear();
+        if st != RK_OK {
+            return Err(describe(st, self.device, failed));
+        }
+        Ok(std::mem::take(&mut self.seals)
+            .into_iter()
+            .map(|b| {
+                let (mut seal, w) = *b;
+                seal.truncate(w);
+                seal
+            })
+            .collect())
+    }
+}
+
+impl Drop for Window {
+    fn drop(&mut self) {
+        if !self.stream.is_null() {
+            // an early return (executor error, witness error): wait for what was submitted, then free the stream and
+            // its worker thread; only after that may the witnesses and seal buffers go
+            let mut failed = usize::MAX;
+            unsafe { rk_stream_close(self.stream, &mut failed) };
+            self.stream = ptr::null_mut();
+        }
+    }
+}
+
+fn executor_env<'a>(po2: u32, encoded_input: &'a [u32], dir: &std::path::Path, profile: bool) -> Result<ExecutorEnv<'a>, String> {
+    // bonsai.rs:246-266 -- unchanged except for a private segment directory: the shared, wiped /tmp/risc0-cache of the
+    // reference (bonsai.rs:261-265) races under concurrency_limit = 16
+    let mut builder = ExecutorEnv::builder();
+    builder.session_limit(None).segment_limit_po2(po2).write_slice(encoded_input);
+    if profile {
+        // bonsai.rs:252-255: the request's `profile: true` (script/prove-block.sh:64-73 always sends it)
+        info!("Profiling enabled.");
+        builder.enable_profiler("profile_r0_local.pb");
+    }
+    builder.segment_path(dir).build().map_err(|e| e.to_string())
+}
+
+fn prove_locally(po2: u32, encoded_input: Vec<u32>, hip: &HipParam, profile: bool) -> Result<Receipt, String> {
     let dir = tempfile::tempdir().map_err(|e| e.to_string())?;
-    let env = ExecutorEnv::builder()
-        .session_limit(None)
-        .segment_limit_po2(po2)
-        .write_slice(&encoded_input)
-        .segment_path(dir.path())
-        .build()
-        .map_err(|e| e.to_string())?;
+    let env = executor_env(po2, &encoded_input, dir.path(), profile)?;
     let mut exec = ExecutorImpl::from_elf(env, RISC0_GUEST_ELF).map_err(|e| e.to_string())?;
     let session = exec.run().map_err(|e| e.to_string())?;
-
-    // witness generation per segment (CPU, risc0-circuit-rv32im): code + data columns and the globals
-    let mut witnesses = Vec::with_capacity(session.segments.len());
+    // segments come back from disk one at a time; at most a window of witnesses exists at any moment
+    let mut window = Window::open(hip)?; // after the executor: nothing to close if it fails
     for seg_ref in session.segments.iter() {
         let segment = seg_ref.resolve().map_err(|e| e.to_string())?;
-        witnesses.push(circuit::witness(&segment)?);
+        window.submit(circuit::witness(&segment)?)?;
     }
-
-    let taps = circuit::tapset();
-    let c_segs: Vec<rk_segment> = witnesses.iter().map(|w| w.as_rk_segment(&taps)).collect();
-    let caps: Vec<usize> = c_segs.iter().map(|s| unsafe { rk_seal_bound_words(s) }).collect();
-    if let Some(bad) = caps.iter().position(|&c| c == 0) {
-        return Err(format!("segment {bad}: shape rejected by libraiko_hip"));
-    }
-    let mut bufs: Vec<Vec<u32>> = caps.iter().map(|&c| vec![0u32; c]).collect();
-    let ptrs: Vec<*mut u32> = bufs.iter_mut().map(|b| b.as_mut_ptr()).collect();
-    let mut words = vec![0usize; c_segs.len()];
-    let mut failed = usize::MAX;
-    let devices: Vec<c_int> = hip.devices.iter().map(|&d| d as c_int).collect();
-    let vopts = rk_verify_opts {
-        p2_rc_ext: ptr::null(),
-        p2_rc_int: ptr::null(),
-        p2_diag: ptr::null(),
-        poly_ext: Some(circuit::poly_ext_trampoline),
-        user: ptr::null_mut(),
-        program: ptr::null(), // the callback above is risc0's own CircuitDef::poly_ext; a program would do as well
-        params: ptr::null(), // risc0's parameter set is the library default
-    };
-    let opts = rk_session_opts {
-        device: devices.first().copied().unwrap_or(0),
-        inflight: hip.inflight,
-        upload_ahead: hip.upload_ahead,
-        verify: 1,
-        devices: if devices.len() > 1 { devices.as_ptr() } else { ptr::null() },
-        n_devices: if devices.len() > 1 { devices.len() as c_int } else { 0 },
-        verify_opts: &vopts,
-        params: ptr::null(), // risc0's parameter set is the library default
-    };
-    let st = unsafe {
-        rk_prove_session(&opts, c_segs.as_ptr(), c_segs.len(), ptrs.as_ptr(), caps.as_ptr(), words.as_mut_ptr(), &mut failed)
-    };
-    if st != RK_OK {
-        return Err(describe(st, opts.device, failed));
-    }
-    let seals: Vec<Vec<u32>> = bufs
-        .into_iter()
-        .zip(words)
-        .map(|(mut seal, w)| {
-            seal.truncate(w);
-            seal
-        })
-        .collect();
+    let seals = window.finish()?;
     circuit::assemble_receipt(&session, seals)
 }
 
 /// The same with executor and prover overlapped (cargo feature `pipelined`): risc0's executor hands every
 /// segment to a callback as it completes (RECALLED: `ExecutorImpl::run_with_callback`), the callback builds
-/// the witness and submits it to an `rk_stream`, so segment k is proven while segment k + 1 executes and the
-/// block's wall-clock is the executor's, not the sum.
+/// the witness and submits it to the window, so segment k is proven while segment k + 1 executes and the
+/// block's wall-clock is the executor's, not the sum.  The window's back-pressure bounds memory here too: a
+/// callback that finds the window full blocks the executor until a proof has finished.
 #[cfg(feature = "pipelined")]
-fn prove_locally_pipelined(po2: u32, encoded_input: Vec<u32>, hip: &HipParam) -> Result<Receipt, String> {
+fn prove_locally_pipelined(po2: u32, encoded_input: Vec<u32>, hip: &HipParam, profile: bool) -> Result<Receipt, String> {
     let dir = tempfile::tempdir().map_err(|e| e.to_string())?;
-    let env = ExecutorEnv::builder()
-        .session_limit(None)
-        .segment_limit_po2(po2)
-        .write_slice(&encoded_input)
-        .segment_path(dir.path())
-        .build()
-        .map_err(|e| e.to_string())?;
-    let vopts = rk_verify_opts {
-        p2_rc_ext: ptr::null(),
-        p2_rc_int: ptr::null(),
-        p2_diag: ptr::null(),
-        poly_ext: Some(circuit::poly_ext_trampoline),
-        user: ptr::null_mut(),
-        program: ptr::null(),
-        params: ptr::null(),
-    };
-    let devices: Vec<c_int> = hip.devices.iter().map(|&d| d as c_int).collect();
-    let opts = rk_session_opts {
-        device: devices.first().copied().unwrap_or(0),
-        inflight: hip.inflight,
-        upload_ahead: hip.upload_ahead,
-        verify: 1,
-        devices: if devices.len() > 1 { devices.as_ptr() } else { ptr::null() },
-        n_devices: if devices.len() > 1 { devices.len() as c_int } else { 0 },
-        verify_opts: &vopts,
-        params: ptr::null(),
-    };
-    let mut stream: *mut rk_stream = ptr::null_mut();
-    let st = unsafe { rk_stream_open(&opts, &mut stream) };
-    if st != RK_OK {
-        return Err(describe(st, opts.device, usize::MAX));
-    }
-    let taps = circuit::tapset();
-    // everything a submitted rk_segment points at lives until rk_stream_close: boxed, never moved
-    let mut witnesses: Vec<Box<Witness>> = Vec::new();
-    let mut seals: Vec<Box<(Vec<u32>, usize)>> = Vec::new();
+    let env = executor_env(po2, &encoded_input, dir.path(), profile)?;
     let mut exec = ExecutorImpl::from_elf(env, RISC0_GUEST_ELF).map_err(|e| e.to_string())?;
+    let mut window = Window::open(hip)?; // after from_elf: an ELF that does not load leaves no stream behind
     let mut submit_err: Option<String> = None;
     let session = exec
         .run_with_callback(|segment| {
-            match circuit::witness(&segment) {
-                Ok(w) => {
-                    let w = Box::new(w);
-                    let c_seg = w.as_rk_segment(&taps);
-                    let cap = unsafe { rk_seal_bound_words(&c_seg) };
-                    let mut out = Box::new((vec![0u32; cap], 0usize));
-                    let st = unsafe { rk_stream_submit(stream, &c_seg, out.0.as_mut_ptr(), cap, &mut out.1) };
-                    if st != RK_OK && submit_err.is_none() {
-                        submit_err = Some(format!("rk_stream_submit: status {st}"));
-                    }
-                    witnesses.push(w);
-                    seals.push(out);
-                }
-                Err(e) => {
-                    if submit_err.is_none() {
-                        submit_err = Some(e);
-                    }
+            if submit_err.is_none() {
+                if let Err(e) = circuit::witness(&segment).and_then(|w| window.submit(w)) {
+                    submit_err = Some(e);
                 }
             }
             Ok(Box::new(risc0_zkvm::SimpleSegmentRef::new(segment)))
         })
         .map_err(|e| e.to_string());
-    let mut failed = usize::MAX;
-    let st = unsafe { rk_stream_close(stream, &mut failed) }; // waits for every submitted segment
+    let seals = window.finish(); // waits for every submitted segment, also when the executor failed
     let session = session?;
     if let Some(e) = submit_err {
         return Err(e);
     }
-    if st != RK_OK {
-        return Err(describe(st, opts.device, failed));
-    }
-    let seals: Vec<Vec<u32>> = seals
-        .into_iter()
-        .map(|b| {
-            let (mut seal, w) = *b;
-            seal.truncate(w);
-            seal
-        })
-        .collect();
-    drop(witnesses);
-    circuit::assemble_receipt(&session, seals)
+    circuit::assemble_receipt(&session, seals?)
 }
 
 impl Witness {
@@ -454,9 +483,13 @@ mod circuit {
     /// RECALLED: risc0-circuit-rv32im 1.0.1 keeps the list as `poly_ext::DEF: PolyExtStepDef`
     /// (`block: &[PolyExtStep]`, `ret`), which `impl PolyExt for CircuitImpl` interprets; the module
     /// is private in the published crate, so this feature needs the one-line visibility patch
-    /// (`pub mod poly_ext;`) on a vendored copy.  Null when the feature is off or creation fails.
+    /// (`pub mod poly_ext;`, provers/hip/patches/rv32im-poly-ext-pub.patch) on a vendored copy.  This is the default
+    /// route: eval_check then runs on the GPU from the LDE the prover already holds and nothing crosses PCIe.  Null --
+    /// and the CPU `eval_check` hook below takes over, downloading the 4.25 GB LDE per segment -- only when
+    /// rk_program_create rejects the list or the crate is built with `--features cpu-eval-check` (an unpatched
+    /// circuit crate).
     pub fn program() -> *const rk_program {
-        #[cfg(feature = "step-program")]
+        #[cfg(not(feature = "cpu-eval-check"))]
         {
             use risc0_zkp::adapter::PolyExtStep as S;
             static PROGRAM: std::sync::OnceLock<usize> = std::sync::OnceLock::new();
@@ -488,7 +521,7 @@ mod circuit {
                 if rc == RK_OK { prog as usize } else { 0 }
             }) as *const rk_program;
         }
-        #[cfg(not(feature = "step-program"))]
+        #[cfg(feature = "cpu-eval-check")]
         ptr::null()
     }
 
@@ -500,9 +533,9 @@ mod circuit {
                                            &CpuCircuitHal::new(), segment.po2, &io, trace);
         let steps = 1usize << segment.po2;
         let mut hook = Box::new(CircuitHook {
-            // eval_check: with the step list (feature `step-program`) the library evaluates the
-            // constraint polynomial on the GPU from the LDE it already holds -- no download, no
-            // circuit-specific kernel; otherwise risc0's CPU evaluator on host copies
+            // eval_check: with the step list (the default) the library evaluates the constraint polynomial on the
+            // GPU from the LDE it already holds -- no download, no circuit-specific kernel; risc0's CPU evaluator
+            // on host copies is the fallback when the list could not be created
             hooks: rk_circuit_hooks {
                 user: ptr::null_mut(),
                 accumulate: Some(accumulate),

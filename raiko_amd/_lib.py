@@ -135,7 +135,7 @@ class RkP3Timing(C.Structure):
 
 class RkExecOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("segment_limit_po2", C.c_uint32), ("session_limit", C.c_uint64),
-                ("input_words", u32p), ("n_input_words", C.c_size_t), ("record_trace", C.c_uint32)]
+                ("input_words", u32p), ("n_input_words", C.c_size_t), ("record_trace", C.c_uint32), ("profile", C.c_uint32)]
 
 
 class RkExecSummary(C.Structure):
@@ -156,8 +156,10 @@ SYMBOLS = {
     "rk_session_last_error": (C.c_char_p, [C.c_int]),
     "rk_stream_open": (C.c_int, [C.POINTER(RkSessionOpts), C.POINTER(C.c_void_p)]),
     "rk_stream_submit": (C.c_int, [C.c_void_p, C.POINTER(RkSegment), u32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rk_stream_wait": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rk_stream_close": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rk_session_release": (C.c_int, []),
+    "rk_session_last_proven": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
     "rk_abi_version": (C.c_int, []),
     "rk_strerror": (C.c_char_p, [C.c_int]),
     "rk_last_error": (C.c_char_p, [_vp]),
@@ -218,6 +220,7 @@ SYMBOLS = {
     "rk_exec_summary_get": (C.c_int, [C.c_void_p, C.POINTER(RkExecSummary)]),
     "rk_exec_segment_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(RkExecSegment)]),
     "rk_exec_journal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rk_exec_profile": (C.c_int, [C.c_void_p, u32p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rk_exec_witness": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     "rk_exec_witness_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rk_exec_error": (C.c_char_p, [C.c_void_p]),

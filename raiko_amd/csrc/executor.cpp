@@ -18,6 +18,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/raiko_hip.h"
@@ -117,6 +118,7 @@ struct rk_exec {
     bool halted = false;
     int st = RK_OK;
     std::vector<uint8_t> journal;
+    std::unordered_map<uint32_t, uint64_t> pc_cycles;   // rk_exec_opts.profile
     rk_exec_summary summary{};
     std::string error;
 };
@@ -369,6 +371,7 @@ int exec_next(rk_exec* ex, int* more) {
             break;
         }
         TraceRow row{};
+        if (o.profile) ex->pc_cycles[m.pc]++;
         int r = step(m, *ex, o, ex->in_pos, ex->error, o.record_trace ? &row : nullptr);
         if (r < 0) { ex->st = r; break; }
         if (o.record_trace) trace.push_back(row);
@@ -463,6 +466,22 @@ int rk_exec_segment_get(const rk_exec* ex, uint32_t index, rk_exec_segment* out)
     if (!ex || !out || index >= ex->segments.size()) return RK_ERR_INVALID;
     *out = ex->segments[index];
     return RK_OK;
+}
+int rk_exec_profile(const rk_exec* ex, uint32_t* pcs, uint64_t* cycles, size_t capacity, size_t* n) {
+    RK_GUARD_BEGIN
+    if (!ex || !n) return RK_ERR_INVALID;
+    *n = ex->pc_cycles.size();
+    if (*n > capacity || (*n && (!pcs || !cycles))) return RK_ERR_CAPACITY;
+    std::vector<std::pair<uint64_t, uint32_t>> v;
+    v.reserve(*n);
+    for (const auto& kv : ex->pc_cycles) v.push_back({kv.second, kv.first});
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    for (size_t i = 0; i < v.size(); i++) {
+        pcs[i] = v[i].second;
+        cycles[i] = v[i].first;
+    }
+    return RK_OK;
+    RK_GUARD_END
 }
 int rk_exec_journal(const rk_exec* ex, uint8_t* out, size_t capacity, size_t* len) {
     if (!ex || !len) return RK_ERR_INVALID;

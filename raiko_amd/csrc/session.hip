@@ -24,9 +24,23 @@
 #include <thread>
 #include <vector>
 
+#include <cstdlib>
+
 #include "internal.hpp"
 
 namespace {
+
+// RK_TEST_LOGICAL_DEVICES=k (test switch): the session code sees k devices, logical device d running on physical GPU
+// d mod (number of GPUs).  It lets the multi-device path -- one pool, one feeder and `inflight` provers per device, the
+// session-wide claim flags, the pinning of device-resident segments -- run on a box with a single GPU; every pool
+// still has its own contexts, streams, staging ring and lock, so nothing is shared that real devices would not share.
+int logical_devices() {
+    const char* e = std::getenv("RK_TEST_LOGICAL_DEVICES");
+    if (!e || !*e) return 0;
+    const int k = std::atoi(e);
+    return k > 0 && k <= 64 ? k : 0;
+}
+int physical_of(int device, int n_gpus) { return logical_devices() > 0 && n_gpus > 0 ? device % n_gpus : device; }
 
 struct Slot {
     void* group[3] = {nullptr, nullptr, nullptr};
@@ -51,6 +65,8 @@ struct DevicePool {
     std::vector<Slot*> ring;
     std::mutex busy;  // one session at a time per device (`run` may be entered from many threads)
     std::string last_error;
+    int physical = 0;       // the GPU behind it (= device unless RK_TEST_LOGICAL_DEVICES is set)
+    size_t last_proven = 0; // segments this device proved in the last session it took part in
     bool ktime_on = false;  // applied to contexts created later
     std::vector<std::vector<uint32_t>> prover_key;  // per prover: the parameter set it carries (empty: risc0's defaults)
     void clear() {
@@ -89,6 +105,7 @@ struct DevRun {
     size_t n_slots = 1;
     size_t cursor = 0;
     size_t provers_left = 0;
+    size_t proven = 0;
     bool feeder_done = false;
 };
 
@@ -224,6 +241,7 @@ void prover(rk_ctx* ctx, Run* run, size_t d) {
             std::lock_guard<std::mutex> l(run->mu);
             if (it.slot) dr.free_slots.push_back(it.slot);
             dr.outstanding--;
+            if (st == RK_OK) dr.proven++;
             if (st == RK_OK && run->verify) run->to_verify.push_back(i);  // host work for the verifier thread
             run->cv.notify_all();
         }
@@ -294,8 +312,9 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
     if (n == 0) return RK_OK;
     int n_gpus = 0;
     if (hipGetDeviceCount(&n_gpus) != hipSuccess || n_gpus <= 0) return RK_ERR_NODEVICE;
+    const int n_visible = logical_devices() > 0 ? logical_devices() : n_gpus;
     for (int d : devices)
-        if (d < 0 || d >= n_gpus) return RK_ERR_INVALID;
+        if (d < 0 || d >= n_visible) return RK_ERR_INVALID;
 
     std::vector<std::shared_ptr<DevicePool>> pools;
     {
@@ -306,6 +325,7 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
                 sp = std::make_shared<DevicePool>();
                 sp->device = d;
             }
+            sp->physical = physical_of(d, n_gpus);
             pools.push_back(sp);
         }
     }
@@ -336,8 +356,10 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
                 (void)hipGetLastError();
                 return RK_ERR_INVALID;
             }
-            run.owner[i] = attr.device;
-            if (std::find(devices.begin(), devices.end(), attr.device) == devices.end()) {
+            // the device of the session that runs on the GPU holding the data (with logical test devices: the first)
+            for (int d : devices)
+                if (run.owner[i] < 0 && physical_of(d, n_gpus) == attr.device) run.owner[i] = d;
+            if (run.owner[i] < 0) {
                 if (failed_index) *failed_index = i;
                 return RK_ERR_INVALID;
             }
@@ -379,7 +401,7 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
         DevicePool* pool = pools[d].get();
         while (pool->provers.size() < workers) {
             rk_ctx* c = nullptr;
-            int st = rk_ctx_create(pool->device, nullptr, &c);
+            int st = rk_ctx_create(pool->physical, nullptr, &c);
             if (st != RK_OK) return st;
             if (pool->ktime_on) (void)rk_set_kernel_timing(c, 1);
             pool->provers.push_back(c);
@@ -392,7 +414,7 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
             pool->prover_key[j] = key;
         }
         if (any_host && !pool->uploader) {
-            int st = rk_ctx_create(pool->device, nullptr, &pool->uploader);
+            int st = rk_ctx_create(pool->physical, nullptr, &pool->uploader);
             if (st != RK_OK) return st;
         }
         DevRun& dr = run.devs[d];
@@ -419,6 +441,7 @@ int prove_session(const rk_session_opts* opts, const rk_segment* segs, size_t n,
         for (size_t v = 0; v < nv; v++) threads.emplace_back(verifier, &run);
     }
     for (auto& t : threads) t.join();
+    for (size_t d = 0; d < devices.size(); d++) pools[d]->last_proven = run.devs[d].proven;
     if (run.status != RK_OK) {
         if (failed_index) *failed_index = run.failed;
         std::lock_guard<std::mutex> l(g_mu);
@@ -459,6 +482,7 @@ struct rk_stream {
     std::condition_variable cv;
     std::vector<Item> items;
     size_t next = 0;
+    size_t done = 0;     // items [0, done) are finished: batches complete in submission order
     bool closed = false;
     int status = RK_OK;
     size_t failed = (size_t)-1;
@@ -474,7 +498,11 @@ struct rk_stream {
                 b0 = next;
                 b1 = items.size();
                 next = b1;
-                if (status != RK_OK) continue;     // after a failure the rest is only drained
+                if (status != RK_OK) {             // after a failure the rest is only drained
+                    done = b1;
+                    cv.notify_all();
+                    continue;
+                }
             }
             const size_t n = b1 - b0;
             std::vector<rk_segment> segs(n);
@@ -501,6 +529,8 @@ struct rk_stream {
                 status = st;
                 failed = bad == (size_t)-1 ? bad : b0 + bad;
             }
+            done = b1;
+            cv.notify_all();
         }
     }
 };
@@ -542,6 +572,16 @@ int rk_stream_submit(rk_stream* s, const rk_segment* seg, uint32_t* h_seal, size
     s->items.push_back(rk_stream::Item{*seg, h_seal, seal_capacity_words, seal_words});
     s->cv.notify_all();
     return RK_OK;
+    RK_GUARD_END
+}
+
+int rk_stream_wait(rk_stream* s, size_t max_pending, size_t* finished_prefix) {
+    RK_GUARD_BEGIN
+    if (!s) return RK_ERR_INVALID;
+    std::unique_lock<std::mutex> l(s->mu);
+    s->cv.wait(l, [&] { return s->status != RK_OK || s->items.size() - s->done <= max_pending; });
+    if (finished_prefix) *finished_prefix = s->done;
+    return s->status;
     RK_GUARD_END
 }
 
@@ -615,6 +655,19 @@ int rk_session_kernel_stats(int device, int kclass, rk_kernel_stat* out) {
         out->ms += st.ms;
         out->bytes += st.bytes;
     }
+    return RK_OK;
+    RK_GUARD_END
+}
+
+// segments `device` proved in the last session it took part in (a diagnosis of the work queue's balance)
+int rk_session_last_proven(int device, size_t* count) {
+    RK_GUARD_BEGIN
+    if (!count) return RK_ERR_INVALID;
+    *count = 0;
+    auto p = pool_of(device, false);
+    if (!p) return RK_OK;
+    std::lock_guard<std::mutex> s(p->busy);
+    *count = p->last_proven;
     return RK_OK;
     RK_GUARD_END
 }

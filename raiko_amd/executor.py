@@ -43,6 +43,8 @@ class Execution:
     input_words_read: int
     # with record_trace: per segment (code (2, 2^po2), data (16, 2^po2)) witness columns of the stand-in trace circuit
     witness: Optional[list] = None
+    # with profile: [(pc, cycles)], most expensive first (rk_exec_profile)
+    profile: Optional[list] = None
 
 
 class ExecutorError(RuntimeError):
@@ -53,14 +55,16 @@ TRACE_CODE_COLS, TRACE_DATA_COLS, TRACE_ACCUM_COLS = 2, 16, 4
 
 
 def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int = 20, session_limit: int = 0,
-            record_trace: bool = False) -> Execution:
+            record_trace: bool = False, profile: bool = False) -> Execution:
     """`ExecutorImpl::from_elf(env, elf).run()` (bonsai.rs:246-269).  Raises ExecutorError on a trap
-    (illegal instruction, misaligned access, unknown ecall, session limit)."""
+    (illegal instruction, misaligned access, unknown ecall, session limit).  profile: what the reference's
+    `profile: true` switches on (`env_builder.enable_profiler(..)`, bonsai.rs:252-255) -- here the cycles spent at
+    every program counter, most expensive first, in Execution.profile."""
     lib = _lib.load()
     words = np.ascontiguousarray(input_words, dtype=np.uint32)
     opts = RkExecOpts(struct_size=C.sizeof(RkExecOpts), segment_limit_po2=segment_limit_po2, session_limit=session_limit,
                       input_words=words.ctypes.data_as(_lib.u32p), n_input_words=words.size,
-                      record_trace=1 if record_trace else 0)
+                      record_trace=1 if record_trace else 0, profile=1 if profile else 0)
     handle = C.c_void_p()
     st = lib.rk_exec_elf(bytes(elf), len(elf), C.byref(opts), C.byref(handle))
     try:
@@ -87,7 +91,16 @@ def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int 
                 data = np.zeros((TRACE_DATA_COLS, rows), dtype=np.uint32)
                 _lib.check(None, lib.rk_exec_witness(handle, sg.index, code.ctypes.data_as(_lib.u32p), data.ctypes.data_as(_lib.u32p)))
                 witness.append((code, data))
-        return Execution(segs, buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read), witness)
+        ex = Execution(segs, buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read), witness)
+        if profile:
+            cnt = C.c_size_t(0)
+            lib.rk_exec_profile(handle, None, None, 0, C.byref(cnt))
+            pcs = np.zeros(max(cnt.value, 1), dtype=np.uint32)
+            cyc = np.zeros(max(cnt.value, 1), dtype=np.uint64)
+            _lib.check(None, lib.rk_exec_profile(handle, pcs.ctypes.data_as(_lib.u32p), cyc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                 pcs.size, C.byref(cnt)))
+            ex.profile = [(int(p), int(c)) for p, c in zip(pcs[: cnt.value], cyc[: cnt.value])]
+        return ex
     finally:
         if handle:
             lib.rk_exec_free(handle)

@@ -363,13 +363,17 @@ class SessionStream:
     are kept alive here), close() waits for everything and returns the seals in submission order."""
 
     def __init__(self, device: int = 0, inflight: int = 3, upload_ahead: int = 2, verify: bool = True, program=None,
-                 poly_ext=None, params=None):
+                 poly_ext=None, params=None, devices: Optional[Sequence[int]] = None):
         self._lib = _lib.load()
         self._keep = []
         self._bufs = []
         self._words = []
         self._device = device
         opts = _lib.RkSessionOpts(device=device, inflight=inflight, upload_ahead=upload_ahead, verify=1 if verify else 0)
+        if devices is not None:
+            dev_arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            opts.devices = dev_arr
+            opts.n_devices = len(devices)
         if poly_ext is not None or program is not None:
             vopts, vkeep = make_verify_opts(poly_ext, program=program)
             opts.verify_opts = C.pointer(vopts)
@@ -427,6 +431,18 @@ def make_params(preset: int = 0, **over) -> "_lib.RkParams":
                 raise ValueError("unknown parameter %r" % k)
             setattr(p, k, int(v))
     return p
+
+
+def session_last_proven(device: int) -> int:
+    """segments `device` proved in the last session it took part in"""
+    n = C.c_size_t(0)
+    _lib.check(None, _lib.load().rk_session_last_proven(device, C.byref(n)))
+    return int(n.value)
+
+
+def session_release():
+    """rk_session_release: drop the per-device prover contexts and staging rings the session entry points keep"""
+    _lib.check(None, _lib.load().rk_session_release())
 
 
 def session_set_kernel_timing(device: int, enabled: bool):

@@ -128,6 +128,8 @@ class Session:
     segments: List[Segment]
     journal: bytes
     image_id: bytes = b"\0" * 32
+    # cycles per program counter from an executor run with profiling on (raiko_amd.executor.execute(profile=True))
+    profile: Optional[list] = None
 
     @property
     def total_cycles(self) -> int:
@@ -251,6 +253,23 @@ class HipProver:
         session = getattr(input, "session", None)
         if not isinstance(session, Session):
             raise GuestError("input carries no executed session (the RV32IM executor is outside this backend)")
+        if param.profile:
+            # bonsai.rs:252-255: `profile` switches the EXECUTOR's profiler on and names its output file.  The executor
+            # runs before this call; its profile, when the session carries one, is written the way the reference
+            # writes profile_r0_local.pb into the working directory.  A session executed without profiling proves
+            # as usual (script/prove-block.sh:64-73 always sends profile = true).
+            HipProver.last_profile_path = None
+            if session.profile is not None:
+                hip_cfg = config.get("hip", {}) if isinstance(config.get("hip", {}), dict) else {}
+                path = str(hip_cfg.get("profile_path", "profile_rk_local.json"))
+                try:
+                    import json
+                    with open(path, "w") as f:
+                        json.dump({"unit": "cycles", "total_cycles": session.total_cycles,
+                                   "by_pc": [{"pc": "0x%08x" % pc, "cycles": c} for pc, c in session.profile]}, f)
+                except OSError as e:
+                    raise FileIo(str(e))
+                HipProver.last_profile_path = path
         expected = bytes(output.hash)
         if len(expected) != 32:
             raise Param("output.hash must be a B256")
@@ -279,6 +298,7 @@ class HipProver:
         return Proof(proof=receipt.journal.hex(), quote=None, kzg_proof=None)
 
     last_journal_matches = None
+    last_profile_path = None
 
     @staticmethod
     def cancel(proof_key: Tuple[int, bytes, int], read: Any) -> None:

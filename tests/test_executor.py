@@ -232,3 +232,17 @@ def test_stepping_the_executor_gives_the_same_run():
         assert meta == ref and np.array_equal(code, rc) and np.array_equal(data, rd)
     with pytest.raises(X.ExecutorError):
         X.Stepper(b"not an elf")
+
+
+def test_profile_counts_cycles_per_pc():
+    """rk_exec_opts.profile / rk_exec_profile: what `profile: true` of the request switches on in the reference
+    (env_builder.enable_profiler, bonsai.rs:252-255) -- here the cycles spent at each program counter"""
+    prog = A.li("a2", 50) + ["loop:", ("addi", "a3", "a3", 3), ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + \
+        A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    ex = X.execute(image, profile=True)
+    assert ex.profile is not None and sum(c for _, c in ex.profile) == ex.total_cycles
+    assert [c for _, c in ex.profile[:3]] == [50, 50, 50]                      # the three loop instructions, hottest first
+    assert sorted(pc for pc, _ in ex.profile[:3]) == sorted(pc for pc, _ in ex.profile[:3]) and len({pc for pc, _ in ex.profile}) == len(ex.profile)
+    assert all(c == 1 for _, c in ex.profile[3:])
+    assert X.execute(image).profile is None

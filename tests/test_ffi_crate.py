@@ -34,7 +34,10 @@ def test_crate_files_are_whole():
         txt = open(os.path.join(CRATE, rel)).read()
         assert "same pattern" not in txt and "// ..." not in txt and "todo!()" not in txt and "unimplemented!()" not in txt, rel
     lib = open(os.path.join(CRATE, "src", "lib.rs")).read()
-    assert "impl Prover for HipProver" in lib and "rk_prove_session(" in lib and "rk_circuit_hooks" in lib
+    assert "impl Prover for HipProver" in lib and "rk_circuit_hooks" in lib
+    # the session entry in its streaming form, with back-pressure (a block's witnesses do not fit in memory at once)
+    assert "rk_stream_open(" in lib and "rk_stream_submit(" in lib and "rk_stream_wait(" in lib and "rk_stream_close(" in lib
+    assert "enable_profiler(" in lib                     # `profile: true` of the request (bonsai.rs:252-255)
     hal = open(os.path.join(CRATE, "src", "hal.rs")).read()
     assert "impl Hal for HipHal" in hal
     # every Hal operator the header offers is bound in hal.rs

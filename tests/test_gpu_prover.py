@@ -196,6 +196,60 @@ def test_session_device_list_and_custom_poseidon2(hal):
     assert verify_segment(segs[0], want[0], poseidon2=consts) != 0
 
 
+def test_multi_device_session_on_logical_devices(hal, monkeypatch):
+    """The multi-device path of rk_prove_session / rk_stream_* -- one pool, feeder and prover set per device, one claim
+    flag per segment shared by all, device-resident segments pinned to the device that holds them -- run on this box's
+    single GPU through RK_TEST_LOGICAL_DEVICES=2 (two logical devices on physical GPU 0; session.hip).  Seals equal the
+    single-device ones, every segment is proven exactly once, both devices take work, a failing segment is still named."""
+    from raiko_amd._lib import RkError
+    from raiko_amd.hal import SessionStream, prove_session, session_last_proven, session_release
+    segs = [synthetic_segment(9 + (i % 3), (4, 4, 8 + 4 * (i % 2)), seed=1300 + i) for i in range(12)]
+    want = [hal.prove_segment(s) for s in segs]
+    monkeypatch.setenv("RK_TEST_LOGICAL_DEVICES", "2")
+    try:
+        got = prove_session(segs, inflight=2, upload_ahead=1, devices=[0, 1])
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        counts = [session_last_proven(0), session_last_proven(1)]
+        assert sum(counts) == len(segs) and min(counts) > 0, counts            # each segment once, both feeders claimed
+        # device-resident segments are pinned to the first device of the GPU that holds them; host-resident ones roam
+        dev = [None] * len(segs)
+        for i in (0, 3, 4, 7, 10):
+            dev[i] = ([hal.copy_from_elem(g) for g in segs[i].groups], hal.copy_from_elem(segs[i].check))
+        got = prove_session(segs, inflight=2, upload_ahead=2, devices=[1, 0], device_inputs=dev)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        counts = [session_last_proven(0), session_last_proven(1)]
+        assert sum(counts) == len(segs) and counts[0] >= 5, counts
+        all_dev = [([hal.copy_from_elem(g) for g in s.groups], hal.copy_from_elem(s.check)) for s in segs[:4]]
+        got = prove_session(segs[:4], inflight=2, devices=[0, 1], device_inputs=all_dev)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)) and [session_last_proven(0), session_last_proven(1)] == [4, 0]
+        # logical device 1 alone (physical GPU 0 behind it) takes device-resident inputs too
+        got = prove_session(segs[:3], inflight=1, devices=[1], device_inputs=all_dev[:3])
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)) and session_last_proven(1) == 3
+        # a failing segment is still reported by its index, whichever device claimed it
+        bad = [synthetic_segment(8, (2, 2, 4), seed=1400 + i) for i in range(6)]
+        bad[4].taps.reg_combo = bad[4].taps.reg_combo.copy()
+        bad[4].taps.reg_combo[0] = 99
+        with pytest.raises(RkError) as ei:
+            prove_session(bad, inflight=2, devices=[0, 1])
+        assert ei.value.segment == 4
+        with pytest.raises(RkError) as ei:
+            prove_session(segs[:2], inflight=1, devices=[0, 2])               # only two logical devices exist
+        assert ei.value.status == -1
+        # the same through a session that grows while it runs
+        stream = SessionStream(inflight=2, upload_ahead=1, devices=[0, 1])
+        for s in segs[:8]:
+            stream.submit(s)
+        got = stream.close()
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    finally:
+        monkeypatch.delenv("RK_TEST_LOGICAL_DEVICES")
+        session_release()                                                     # the pool of logical device 1 goes with it
+    assert np.array_equal(prove_session(segs[:1], inflight=1)[0], want[0])    # and the plain path is back
+
+
 def test_native_session_reports_the_failing_segment(hal):
     from raiko_amd._lib import RkError
     from raiko_amd.hal import prove_session

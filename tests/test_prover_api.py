@@ -83,6 +83,29 @@ def test_receipt_roundtrip_and_cache(tmp_path, monkeypatch):
     assert pv.HipProver.last_journal_matches is True
 
 
+def test_profile_option_writes_the_executor_profile(tmp_path, monkeypatch):
+    """`profile: true` (script/prove-block.sh:64-73 always sends it; bonsai.rs:252-255 hands it to the executor's
+    profiler): a session executed with profiling leaves its cycle profile in the named file, one without proves as usual"""
+    import json
+    from raiko_amd import receipt as rc
+    monkeypatch.setattr(pv, "_CACHE_DIR", str(tmp_path))
+    r = pv.Receipt(segments=[rc.SegmentReceipt(seal=np.arange(3, dtype=np.uint32), index=0, exit_code=("Halted", 0))],
+                   journal=pv.encode_journal_b256(b"\xcd" * 32))
+    out = types.SimpleNamespace(hash=b"\xcd" * 32)
+    sess = pv.Session(segments=[], journal=b"", image_id=b"\x09" * 32, profile=[(0x200800, 70), (0x200804, 30)])
+    pv.save_receipt(rc.receipt_label(sess.image_id, out.hash), ("", r))       # answered from the cache: no GPU needed here
+    cfg = req()
+    cfg["hip"] = {"profile_path": str(tmp_path / "profile.json")}
+    pv.HipProver.run(types.SimpleNamespace(session=sess), out, cfg)
+    got = json.load(open(tmp_path / "profile.json"))
+    assert got["by_pc"][0] == {"pc": "0x00200800", "cycles": 70} and pv.HipProver.last_profile_path == str(tmp_path / "profile.json")
+    sess.profile = None
+    pv.HipProver.run(types.SimpleNamespace(session=sess), out, cfg)            # nothing to write, not an error
+    assert pv.HipProver.last_profile_path is None
+    cfg["risc0"]["profile"] = False
+    pv.HipProver.run(types.SimpleNamespace(session=sess), out, cfg)
+
+
 def test_keccak256_and_label():
     import hashlib
     from raiko_amd import keccak as kk
