@@ -399,6 +399,15 @@ class SessionStream:
         self._words.append(words)
         _lib.check(None, self._lib.rk_stream_submit(self._h, C.byref(c), _u32p(buf), cap, C.byref(words)))
 
+    def wait(self, max_pending: int) -> int:
+        """rk_stream_wait: block until at most `max_pending` submitted segments are unfinished; returns the length of
+        the finished prefix (those segments' inputs may be freed).  Raises RkError once a segment has failed."""
+        prefix = C.c_size_t(0)
+        st = self._lib.rk_stream_wait(self._h, max_pending, C.byref(prefix))
+        if st != 0:
+            raise _lib.RkError(st, self._lib.rk_strerror(st).decode())
+        return int(prefix.value)
+
     def close(self):
         failed = C.c_size_t(0)
         st = self._lib.rk_stream_close(self._h, C.byref(failed))

@@ -239,8 +239,13 @@ def test_multi_device_session_on_logical_devices(hal, monkeypatch):
         assert ei.value.status == -1
         # the same through a session that grows while it runs
         stream = SessionStream(inflight=2, upload_ahead=1, devices=[0, 1])
-        for s in segs[:8]:
+        released = 0
+        for k, s in enumerate(segs[:8]):
             stream.submit(s)
+            prefix = stream.wait(3)                       # back-pressure: at most three unfinished segments
+            assert k + 1 - prefix <= 3 and prefix >= released
+            released = prefix
+        assert stream.wait(0) == 8
         got = stream.close()
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
