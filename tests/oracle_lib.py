@@ -141,6 +141,9 @@ def oracle():
             "or_params_preset": (None, [C.POINTER(OrParams), C.c_int]), "or_set_params": (C.c_int, [C.POINTER(OrParams)]),
             "or_prefix_products": (None, [vp, sz]),
             "or_pow_grind": (u32, [vp, C.c_uint]),
+            "or_iop_init": (None, [C.POINTER(OrIop)]), "or_iop_free": (None, [C.POINTER(OrIop)]),
+            "or_iop_commit": (None, [C.POINTER(OrIop), vp]),
+            "or_iop_random_bits": (u32, [C.POINTER(OrIop), C.c_uint]), "or_iop_random_elem": (u32, [C.POINTER(OrIop)]),
             "or_mmcs_commit": (None, [vp, u32, vp]),
             "or_mmcs_verify": (C.c_int, [vp, vp, u32, u32, vp, vp, vp]),
             "or_scatter": (None, [vp, vp, sz, vp, vp]),
