@@ -53,6 +53,11 @@ def parse_args():
                          "chip-shaped synthetic AIR under SP1's parameter set); its line has its own metric")
     ap.add_argument("--p3-shape", default="20x256,19x128,16x64,10x32", help="--preset sp1-p3: log2 rows x columns per table")
     ap.add_argument("--p3-jit", action="store_true", help="--preset sp1-p3: quotient through the hiprtc-generated kernel")
+    ap.add_argument("--circuit", type=str, default="",
+                    help="comma-separated op counts, e.g. 8000,33000: for each, the same S20 session again with the circuit's "
+                         "two stages inside the timed region -- eval_check from a synthetic step list of that many ops over "
+                         "the 256 columns (rk_program, compiled with hiprtc), the check group computed inside the proof; "
+                         "reported as `with_circuit`, never as `value` (the rv32im list itself is outside the tree)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (value_with_h2d) run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-small", action="store_true",
@@ -247,6 +252,53 @@ def main():
         except Exception as e:  # the headline line must not depend on this
             small = {"po2": 18, "error": repr(e)}
 
+    # the same session with a constraint list of rv32im-like size evaluated inside every proof (ADVICE r2 / VERDICT r2 #3):
+    # what `session.prove()` costs per segment once eval_check is in the region (bonsai.rs:271)
+    with_circuit = []
+    if args.circuit and world == 1 and blob is None:
+        from raiko_amd import circuit_program as cp
+        chal = HipHal(gpu_index)
+        for n_ops in (int(x) for x in args.circuit.split(",")):
+            try:
+                rng = np.random.default_rng(1)
+                taps = segs[0][0].taps
+                steps_, ret = cp.synthetic_program(rng, taps, 32, segs[0][0].n_accum_mix, n_fp_ops=n_ops, n_live=0, depth=2,
+                                                   n_constraints=max(8, n_ops // 10), local=True)
+                prog = cp.Program(steps_, ret, taps)
+                t0 = time.perf_counter()
+                prog.compile(chal)
+                compile_s = time.perf_counter() - t0
+                csegs = []
+                for seg, groups, _check in segs:
+                    cs = seg_mod.Segment(po2=seg.po2, taps=seg.taps, groups=[None, None, None], check=None, globals_=seg.globals_)
+                    cs.program = prog
+                    csegs.append((cs, groups))
+                chal.prove_segment(csegs[0][0], device_inputs=(csegs[0][1], None))      # warm
+                chal.prove_segment(csegs[1][0], device_inputs=(csegs[1][1], None))
+                cstage = chal.last_timing()
+
+                def csession(n):
+                    return prove_session([csegs[i % 2][0] for i in range(n)], device=gpu_index, inflight=inflight,
+                                         upload_ahead=args.upload_ahead, verify=not args.no_verify,
+                                         device_inputs=[(csegs[i % 2][1], None) for i in range(n)])
+                csession(inflight)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                csession(my_steps)
+                torch.cuda.synchronize()
+                ce = time.perf_counter() - t0
+                with_circuit.append({"ops": prog.info()["n_ops"], "steps_in_list": prog.info()["n_steps"],
+                                     "value": round(my_steps * (1 << args.po2) / ce, 1), "unit": "cycles/s",
+                                     "ms_per_step": round(ce / max(my_steps, 1) * 1e3, 3),
+                                     "serial_stage_ms": {k: round(v, 3) for k, v in cstage.items()},
+                                     "hiprtc_compile_s": round(compile_s, 2),
+                                     "what": "S%d with eval_check of a synthetic %d-op constraint list over the 256 columns inside every "
+                                             "proof (rk_circuit_hooks.program, generated kernel); accum still given" % (args.po2, prog.info()["n_ops"])})
+                prog.close()
+            except Exception as e:  # the headline line must not depend on this
+                with_circuit.append({"ops": n_ops, "error": repr(e)})
+        chal.close()
+
     if rank == 0:
         cycles = total_segments * (1 << args.po2)
         value = cycles / elapsed
@@ -333,6 +385,10 @@ def main():
             out["h2d_seals_identical"] = bool(same)
         if small is not None:
             out["segments_of_2^18_cycles"] = small
+        if with_circuit:
+            out["with_circuit"] = with_circuit
+        out["config"]["circuit_stages"] = ("excluded from `value`: accum and the check evaluations are resident inputs (BASELINE.md's S20); "
+                                           "see `with_circuit` (--circuit N) for the same session with eval_check inside the region")
         if seals:
             # every seal was verified inside the timed region unless --no-verify; check the last one here too
             out["seal_verified"] = verify_segment(segs[(my_steps - 1) % 2][0], seals[-1], params=blob) == 0

@@ -27,7 +27,7 @@
 namespace {
 
 using bb::Ext;
-constexpr size_t CHUNK = 300;
+constexpr size_t CHUNK = 128;
 constexpr uint32_t NONE = rk::PROGRAM_NONE;
 
 // what the generated kernel receives (same layout as `struct Args` in the source below)
@@ -39,45 +39,59 @@ struct JitArgs {
     uint64_t d;
     uint32_t glob_base, mix_base, pw_base, wm;
     uint32_t blow, split;   // log2 (domain / trace rows); the result leaves in 2^split chunks (rk::EvalDomain)
-    uint32_t str[3], pad;   // point i of the domain is element i << str[g] of a column of group g
-    uint32_t inv_den[16];
+    uint32_t str[3], one;   // point i of the domain is element i << str[g] of a column of group g; one = 1 (see below)
+    uint32_t inv_base, pad; // the 1 / (x^n - 1) values sit in the table too: indexing an ARRAY inside the kernel arguments by
+                            // the lane's point makes the compiler copy the whole argument block to scratch and read
+                            // every argument back from there with vector loads
 };
 
+// Shape of the generated kernel (measured on the ISA of an 8 k-op list, tools/jit_census.sh):
+//   * ONE function.  The statements are cut into blocks of CHUNK, each inside `if (flag) { ... }` with `flag` = 1
+//     laundered through an empty asm, so every block is its own basic block (instruction selection and scheduling
+//     work per basic block: one block of 10^4 statements costs the compiler tens of minutes) yet nothing is a call:
+//     the kernel arguments stay in SGPRs (column bases are scalar arithmetic, a tap is one `global_load v, voff, s[base]`),
+//     the power table is read through the scalar cache, values that cross a block boundary stay in registers.
+//     The earlier form -- one __noinline__ function per block -- received its arguments through a pointer in VGPRs:
+//     every argument read was a flat load, every tap address a 64-bit VALU multiply-add, every carried value a
+//     scratch access: 10.9 VALU instructions per list op against 5 here.
+//   * Mix states are kept unreduced.  tot = sum_k mont(pw_k, c_k) = (sum_k pw_k c_k) R^-1, so a state is four 64-bit
+//     sums of plain products (one v_mad_u64_u32 per component and constraint), folded back below 2^60 by
+//     hi * (2^32 mod p) + lo (one more v_mad_u64_u32) whenever the next product could overflow -- the bound of every
+//     sum is tracked here, at generation time -- and Montgomery-reduced once, where its value is needed (an AND_COND's
+//     inner block, the result).  32 instructions per constraint became 5 to 6; the field values are the same.
 const char* PRELUDE = R"SRC(
 #define RK_FI __device__ inline __attribute__((always_inline))
-#define RK_NI __device__ __attribute__((noinline))
 typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef const __attribute__((address_space(4))) u32* const_u32;
 namespace bb {
 constexpr u32 P = 2013265921u;
 constexpr u32 MPRIME = 0x88000001u;
+constexpr u32 ONE = 268435454u;   // 2^32 mod p
 RK_FI u32 add(u32 a, u32 b) { u32 r = a + b, s = r - P; return s < r ? s : r; }
 RK_FI u32 sub(u32 a, u32 b) { u32 r = a - b, s = r + P; return s < r ? s : r; }
-RK_FI u32 mul(u32 a, u32 b) {
-    u64 t = (u64)a * b;
+RK_FI u32 redc(u64 t) {   // t < 2^32 p  ->  t 2^-32 mod p, canonical
     u32 q = (u32)t * (0u - MPRIME);
     u64 w = t + (u64)q * P;
     u32 r = (u32)(w >> 32), s = r - P;
     return s < r ? s : r;
 }
+RK_FI u32 mul(u32 a, u32 b) { return redc((u64)a * b); }
 struct Ext { u32 c[4]; };
+struct Acc { u64 c[4]; };   // an unreduced mix state: component e = sum of products, congruent to tot_e 2^32
 RK_FI Ext ext_zero() { return Ext{{0, 0, 0, 0}}; }
-RK_FI Ext add(const Ext& a, const Ext& b) { return Ext{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}}; }
+RK_FI Acc acc_zero() { return Acc{{0, 0, 0, 0}}; }
 RK_FI Ext scale(const Ext& a, u32 s) { return Ext{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}}; }
-RK_FI Ext mul(const Ext& a, const Ext& b, u32 wm) {
-    u32 h0 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
-    u32 h1 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
-    u32 h2 = mul(a.c[3], b.c[3]);
-    Ext r;
-    r.c[0] = add(mul(a.c[0], b.c[0]), mul(wm, h0));
-    r.c[1] = add(add(mul(a.c[0], b.c[1]), mul(a.c[1], b.c[0])), mul(wm, h1));
-    r.c[2] = add(add(add(mul(a.c[0], b.c[2]), mul(a.c[1], b.c[1])), mul(a.c[2], b.c[0])), mul(wm, h2));
-    r.c[3] = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
-    return r;
+RK_FI u64 fold(u64 t) { return (u64)(u32)(t >> 32) * ONE + (u32)t; }   // same residue, below 2^60.1
+RK_FI Acc fold(const Acc& a) { return Acc{{fold(a.c[0]), fold(a.c[1]), fold(a.c[2]), fold(a.c[3])}}; }
+RK_FI Ext fin(const Acc& a) { return Ext{{redc(a.c[0]), redc(a.c[1]), redc(a.c[2]), redc(a.c[3])}}; }   // components < 2^32 p
+// x + pw * v, component-wise plain products
+RK_FI Acc eqz(const Acc& x, const Ext& pw, u32 v) {
+    return Acc{{x.c[0] + (u64)pw.c[0] * v, x.c[1] + (u64)pw.c[1] * v, x.c[2] + (u64)pw.c[2] * v, x.c[3] + (u64)pw.c[3] * v}};
 }
 }  // namespace bb
 using bb::Ext;
+using bb::Acc;
 struct Args {
     const u32* lde[3];
     u64 len[3];
@@ -86,13 +100,14 @@ struct Args {
     u64 d;
     u32 glob_base, mix_base, pw_base, wm;
     u32 blow, split;
-    u32 str[3], pad;
-    u32 inv_den[16];
+    u32 str[3], one;
+    u32 inv_base, pad;
 };
 RK_FI Ext load_pw(const_u32 tab, u32 base, u32 j) {
     const_u32 p = tab + base + 4 * j;
     return Ext{{p[0], p[1], p[2], p[3]}};
 }
+RK_FI u32 ld(const char* base, u32 byte_off) { return *(const u32*)(base + byte_off); }
 )SRC";
 
 struct Fp {
@@ -104,6 +119,13 @@ struct Mx {
     uint64_t k = 0;
     bool zero = false, live = false;
 };
+
+// bounds of the unreduced sums, in units the 64-bit accumulators hold exactly
+typedef unsigned __int128 u128;
+constexpr u128 LIMIT = ((u128)1 << 64) - 1;
+constexpr u128 PROD = (u128)(bb::P - 1) * (bb::P - 1);                               // one product of canonical words
+constexpr u128 FOLDED = (u128)0xffffffffu * bb::ONE + 0xffffffffu;                   // after bb::fold
+constexpr u128 REDC_OK = ((u128)bb::P << 32) - 1;                                    // bb::redc's precondition
 
 // the source of the kernel; *powers: the exponents its table holds
 std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
@@ -180,8 +202,8 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
         }
     }
     const size_t n_chunks = std::max<size_t>(1, (items.size() + CHUNK - 1) / CHUNK);
-    // chunk of every statement's result; chunks that read it
-    std::vector<uint32_t> fp_chunk(fp.size(), NONE), mx_chunk(mx.size(), NONE), fp_last(fp.size(), 0), mx_last(mx.size(), 0);
+    // the last block that reads every statement's result
+    std::vector<uint32_t> fp_last(fp.size(), 0), mx_last(mx.size(), 0);
     auto note = [&](bool is_mix, uint32_t j, uint32_t c) {
         uint32_t& last = is_mix ? mx_last[j] : fp_last[j];
         last = std::max(last, c);
@@ -190,13 +212,11 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
         const uint32_t c = (uint32_t)(t / CHUNK);
         const Item& it = items[t];
         if (it.is_mix) {
-            mx_chunk[it.idx] = c;
             const Mx& m = mx[it.idx];
             if (!is_leaf(m.v)) note(false, m.v, c);
             if (!mx[m.x].zero) note(true, name_mx(m.x), c);
             if (m.op == RK_STEP_AND_COND) note(true, name_mx(m.inner), c);
         } else {
-            fp_chunk[it.idx] = c;
             const Fp& v = fp[it.idx];
             if (!is_leaf(v.a)) note(false, v.a, c);
             if (!is_leaf(v.b)) note(false, v.b, c);
@@ -204,44 +224,63 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
     }
     const bool ret_zero = mx[pg.ret].zero;
     const uint32_t ret_name = ret_zero ? NONE : name_mx(pg.ret);
-    if (!ret_zero) note(true, ret_name, (uint32_t)n_chunks);  // read by the kernel after the last function
+    if (!ret_zero) note(true, ret_name, (uint32_t)n_chunks);  // read by the kernel after the last block
+
+    // which (back, group) byte offsets the list needs: computed once, ahead of the blocks
+    std::set<std::pair<uint32_t, uint32_t>> offs;
+    for (size_t j = 0; j < fp.size(); j++)
+        if (fp[j].live && fp[j].op == RK_STEP_GET) offs.insert({pg.taps[fp[j].a].back, pg.taps[fp[j].a].group});
+    auto off_name = [](uint32_t back, uint32_t group) {
+        return "o" + (back == 0xffffffffu ? std::string("n") : std::to_string(back)) + "_" + std::to_string(group);
+    };
 
     std::vector<uint32_t> fp_slot(fp.size(), NONE), mx_slot(mx.size(), NONE);
+    std::vector<u128> mx_bound(mx.size(), 0);   // of the value named x<idx> (or its carried copy)
     std::vector<uint32_t> free_fp, free_mx;
     uint32_t next_fp = 0, next_mx = 0;
     std::vector<std::vector<std::pair<bool, uint32_t>>> release(n_chunks + 1);
-    std::ostringstream src;
-    src << PRELUDE;
-    std::vector<std::string> calls;
+    std::ostringstream blocks;
     for (size_t c = 0; c < n_chunks; c++) {
         std::ostringstream body;
         std::set<uint32_t> have_fp, have_mx;
+        uint32_t tmp = 0;
         auto use_fp = [&](uint32_t j) -> std::string {
             std::string nm = "f" + std::to_string(j);
             if (have_fp.count(j)) return nm;
             have_fp.insert(j);
             const Fp& v = fp[j];
             if (v.op == RK_STEP_CONST) {
-                body << "    const u32 " << nm << " = " << bb::encode(v.a) << "u;\n";
+                body << "        const u32 " << nm << " = " << bb::encode(v.a) << "u;\n";
             } else if (v.op == RK_STEP_GET) {
                 const rk::Tap& t = pg.taps[v.a];
-                body << "    const u32 " << nm << " = a.lde[" << t.group << "][(u64)" << t.offset << "u * a.len[" << t.group << "] + (";
-                if (t.back == 0) body << "i";
-                else body << "((i + a.d - ((u64)" << t.back << "u << a.blow)) & (a.d - 1))";
-                body << " << a.str[" << t.group << "])];\n";
+                // the column's base through the block's opaque scalar sf (= 1): scalar arithmetic that no pass can share
+                // between blocks -- shared, the hundreds of 64-bit bases of a long list outgrow the scalar registers
+                // and the compiler moves all of them into VGPRs (256 VGPRs, scratch spills)
+                body << "        const u32 " << nm << " = ld(gb" << t.group << " + (u64)(" << t.offset << "u * sf) * lb" << t.group << ", "
+                     << off_name(t.back, t.group) << ");\n";
             } else if (v.op == RK_STEP_GET_GLOBAL) {
-                body << "    const u32 " << nm << " = tab[a." << (v.a == 0 ? "glob_base" : "mix_base") << " + " << v.b << "u];\n";
+                body << "        const u32 " << nm << " = tab[a." << (v.a == 0 ? "glob_base" : "mix_base") << " + " << v.b << "u];\n";
             } else {
-                body << "    const u32 " << nm << " = c[" << fp_slot[j] << "];\n";
+                body << "        const u32 " << nm << " = c" << fp_slot[j] << ";\n";
             }
             return nm;
         };
+        // the name of mix state j as an Acc of this block (its carried copy when it was made in an earlier one)
         auto use_mx = [&](uint32_t j) -> std::string {
             std::string nm = "x" + std::to_string(j);
             if (have_mx.count(j)) return nm;
             have_mx.insert(j);
-            body << "    const Ext " << nm << " = cx[" << mx_slot[j] << "];\n";
+            const uint32_t k = mx_slot[j];
+            body << "        const Acc " << nm << " = Acc{{m" << k << "_0, m" << k << "_1, m" << k << "_2, m" << k << "_3}};\n";
             return nm;
+        };
+        // an Acc expression of value `nm` (bound *b) that leaves room for `extra` more: folded first when it must be
+        auto room = [&](std::string nm, u128* b, u128 extra) -> std::string {
+            if (*b + extra <= LIMIT) return nm;
+            const std::string t = "t" + std::to_string(tmp++);
+            body << "        const Acc " << t << " = bb::fold(" << nm << ");\n";
+            *b = FOLDED;
+            return t;
         };
         for (size_t t = c * CHUNK; t < std::min(items.size(), (c + 1) * CHUNK); t++) {
             const Item& it = items[t];
@@ -249,7 +288,7 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
                 const Fp& v = fp[it.idx];
                 const char* fn = v.op == RK_STEP_ADD ? "add" : v.op == RK_STEP_SUB ? "sub" : "mul";
                 std::string a_ = use_fp(v.a), b_ = use_fp(v.b);
-                body << "    const u32 f" << it.idx << " = bb::" << fn << "(" << a_ << ", " << b_ << ");\n";
+                body << "        const u32 f" << it.idx << " = bb::" << fn << "(" << a_ << ", " << b_ << ");\n";
                 have_fp.insert(it.idx);
                 if (fp_last[it.idx] > c) {
                     uint32_t k;
@@ -261,14 +300,60 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
                     }
                     fp_slot[it.idx] = k;
                     release[fp_last[it.idx]].push_back({false, it.idx});
-                    body << "    c[" << k << "] = f" << it.idx << ";\n";
+                    body << "        c" << k << " = f" << it.idx << ";\n";
                 }
             } else {
                 const Mx& m = mx[it.idx];
-                std::string term = "bb::scale(load_pw(tab, a.pw_base, " + std::to_string(pw_idx(mx[m.x].k)) + "), " + use_fp(m.v) + ")";
-                if (m.op == RK_STEP_AND_COND) term = "bb::mul(" + term + ", " + use_mx(name_mx(m.inner)) + ", a.wm)";
-                if (!mx[m.x].zero) term = "bb::add(" + use_mx(name_mx(m.x)) + ", " + term + ")";
-                body << "    const Ext x" << it.idx << " = " << term << ";\n";
+                const std::string me = "x" + std::to_string(it.idx);
+                const std::string pw = "load_pw(tab, a.pw_base, " + std::to_string(pw_idx(mx[m.x].k)) + ")";
+                // the state this one extends (absent when it is identically zero)
+                std::string xs = "bb::acc_zero()";
+                u128 bound = 0;
+                if (!mx[m.x].zero) {
+                    const uint32_t xn = name_mx(m.x);
+                    xs = use_mx(xn);
+                    bound = mx_bound[xn];
+                }
+                const std::string vs = use_fp(m.v);   // may emit the leaf's own statement: before anything of this one
+                if (m.op == RK_STEP_AND_EQZ) {
+                    xs = room(xs, &bound, PROD);
+                    body << "        const Acc " << me << " = bb::eqz(" << xs << ", " << pw << ", " << vs << ");\n";
+                    bound += PROD;
+                } else {
+                    // x.tot + cond * inner.tot * x.mul: u = pw * cond (canonical), T = the inner block's total (canonical),
+                    // added as the plain ext product u * T -- its x^4 wrap terms go through one Montgomery product so
+                    // that they, too, enter as plain products wm * h
+                    const uint32_t in = name_mx(m.inner);
+                    u128 ib = mx_bound[in];
+                    std::string is = use_mx(in);
+                    if (ib > REDC_OK) {
+                        const std::string t2 = "t" + std::to_string(tmp++);
+                        body << "        const Acc " << t2 << " = bb::fold(" << is << ");\n";
+                        is = t2;
+                    }
+                    // (names that cannot collide with a type: "u32" / "u64" would)
+                    const std::string u = "cu_" + std::to_string(it.idx), T = "cT_" + std::to_string(it.idx), h = "ch_" + std::to_string(it.idx) + "_";
+                    body << "        const Ext " << u << " = bb::scale(" << pw << ", " << vs << ");\n";
+                    body << "        const Ext " << T << " = bb::fin(" << is << ");\n";
+                    body << "        const u32 " << h << "0 = bb::add(bb::add(bb::mul(" << u << ".c[1], " << T << ".c[3]), bb::mul(" << u << ".c[2], " << T
+                         << ".c[2])), bb::mul(" << u << ".c[3], " << T << ".c[1]));\n";
+                    body << "        const u32 " << h << "1 = bb::add(bb::mul(" << u << ".c[2], " << T << ".c[3]), bb::mul(" << u << ".c[3], " << T << ".c[2]));\n";
+                    body << "        const u32 " << h << "2 = bb::mul(" << u << ".c[3], " << T << ".c[3]);\n";
+                    // products per component: 2, 3, 4, 4 -- added in two steps so that a fold in between always suffices
+                    xs = room(xs, &bound, 2 * PROD);
+                    const std::string s1 = "t" + std::to_string(tmp++);
+                    body << "        const Acc " << s1 << " = Acc{{" << xs << ".c[0] + (u64)" << u << ".c[0] * " << T << ".c[0] + (u64)a.wm * " << h << "0, "
+                         << xs << ".c[1] + (u64)" << u << ".c[0] * " << T << ".c[1] + (u64)" << u << ".c[1] * " << T << ".c[0], "
+                         << xs << ".c[2] + (u64)" << u << ".c[0] * " << T << ".c[2] + (u64)" << u << ".c[1] * " << T << ".c[1], "
+                         << xs << ".c[3] + (u64)" << u << ".c[0] * " << T << ".c[3] + (u64)" << u << ".c[1] * " << T << ".c[2]}};\n";
+                    bound += 2 * PROD;
+                    std::string s1n = room(s1, &bound, 2 * PROD);
+                    body << "        const Acc " << me << " = Acc{{" << s1n << ".c[0], " << s1n << ".c[1] + (u64)a.wm * " << h << "1, "
+                         << s1n << ".c[2] + (u64)" << u << ".c[2] * " << T << ".c[0] + (u64)a.wm * " << h << "2, "
+                         << s1n << ".c[3] + (u64)" << u << ".c[2] * " << T << ".c[1] + (u64)" << u << ".c[3] * " << T << ".c[0]}};\n";
+                    bound += 2 * PROD;
+                }
+                mx_bound[it.idx] = bound;
                 have_mx.insert(it.idx);
                 if (mx_last[it.idx] > c) {
                     uint32_t k;
@@ -280,26 +365,42 @@ std::string generate(const rk_program& pg, std::vector<uint32_t>* powers_out) {
                     }
                     mx_slot[it.idx] = k;
                     release[mx_last[it.idx]].push_back({true, it.idx});
-                    body << "    cx[" << k << "] = x" << it.idx << ";\n";
+                    for (int e = 0; e < 4; e++) body << "        m" << k << "_" << e << " = " << me << ".c[" << e << "];\n";
                 }
             }
         }
         for (const auto& r : release[c]) (r.first ? free_mx : free_fp).push_back(r.first ? mx_slot[r.second] : fp_slot[r.second]);
-        src << (n_chunks == 1 ? "RK_FI" : "RK_NI") << " void part" << c
-            << "(const Args& a, const_u32 tab, u64 i, u32* c, Ext* cx) {\n"
-            << body.str() << "}\n";
-        calls.push_back("    part" + std::to_string(c) + "(a, tab, i, c, cx);\n");
+        // a fresh flag per block: a.one = 1 made opaque in a VGPR (an "s" constraint fails with `illegal VGPR to SGPR
+        // copy` once scalar registers run short in a long kernel), read back as a scalar so that the branch is uniform
+        blocks << "    {\n    u32 flag = a.one;\n    asm volatile(\"\" : \"+v\"(flag));\n    const u32 sf = __builtin_amdgcn_readfirstlane(flag);\n"
+               << "    if (sf) {\n" << body.str() << "    }\n    }\n";
     }
+    std::ostringstream src;
+    src << PRELUDE;
     src << "extern \"C\" __global__ __attribute__((amdgpu_flat_work_group_size(1, 256))) void rk_jit_eval_check(Args a) {\n"
-        << "    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;\n"
-        << "    if (i >= a.d) return;\n"
-        << "    const const_u32 tab = (const_u32)a.tab;\n"
-        << "    u32 c[" << std::max<uint32_t>(1, next_fp) << "];\n"
-        << "    Ext cx[" << std::max<uint32_t>(1, next_mx) << "];\n";
-    for (const std::string& call : calls) src << call;
-    src << "    const Ext tot = bb::scale(" << (ret_zero ? std::string("bb::ext_zero()") : "cx[" + std::to_string(mx_slot[ret_name]) + "]")
-        << ", a.inv_den[i & ((1u << a.blow) - 1)]);\n"
-        << "    const u64 rows = a.d >> a.split, at = (i & ((1u << a.split) - 1)) * 4 * rows + (i >> a.split);\n"
+        << "    const u32 i = blockIdx.x * 256u + threadIdx.x, d = (u32)a.d;\n"
+        << "    if (i >= d) return;\n"
+        << "    const const_u32 tab = (const_u32)a.tab;\n";
+    for (const auto& o : offs) {
+        src << "    const u32 " << off_name(o.first, o.second) << " = ((";
+        if (o.first == 0) src << "i";
+        else src << "((i + d - (" << o.first << "u << a.blow)) & (d - 1u))";   // back = 2^32 - 1: one row ahead, modulo d
+        src << ") << a.str[" << o.second << "]) << 2;\n";
+    }
+    for (uint32_t g = 0; g < 3; g++)
+        src << "    const char* const gb" << g << " = (const char*)a.lde[" << g << "];\n    const u64 lb" << g << " = a.len[" << g << "] * 4;\n";
+    for (uint32_t k = 0; k < next_fp; k++) src << "    u32 c" << k << " = 0;\n";
+    for (uint32_t k = 0; k < next_mx; k++)
+        for (int e = 0; e < 4; e++) src << "    u64 m" << k << "_" << e << " = 0;\n";
+    src << blocks.str();
+    if (ret_zero) {
+        src << "    const Ext tot = bb::ext_zero();\n";
+    } else {
+        const uint32_t k = mx_slot[ret_name];
+        src << "    const Acc r0 = Acc{{m" << k << "_0, m" << k << "_1, m" << k << "_2, m" << k << "_3}};\n"
+            << "    const Ext tot = bb::scale(bb::fin(" << (mx_bound[ret_name] > REDC_OK ? "bb::fold(r0)" : "r0") << "), tab[a.inv_base + (i & ((1u << a.blow) - 1u))]);\n";
+    }
+    src << "    const u64 rows = a.d >> a.split, at = (u64)(i & ((1u << a.split) - 1)) * 4 * rows + (i >> a.split);\n"
         << "    for (int e = 0; e < 4; e++) a.check[at + (u64)e * rows] = tot.c[e];\n"
         << "}\n";
     return src.str();
@@ -317,7 +418,7 @@ const JitEntry* program_jit(rk_program* pg, int device) {
 }
 
 int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const EvalDomain& v, const uint32_t* d_tab, uint32_t glob_base,
-                       uint32_t mix_base, uint32_t pw_base, uint32_t* d_check, const uint32_t inv_den[16]) {
+                       uint32_t mix_base, uint32_t pw_base, uint32_t* d_check, uint32_t inv_base) {
     const unsigned blow = v.ratio_log2;
     JitArgs a{};
     for (int g = 0; g < 3; g++) {
@@ -326,6 +427,7 @@ int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const EvalDomain& v, con
         a.str[g] = v.stride_log2[g];
     }
     a.split = v.split_log2;
+    a.one = 1;
     a.tab = (uint64_t)(uintptr_t)d_tab;
     a.check = d_check;
     a.d = (uint64_t)1 << (v.po2 + blow);
@@ -334,7 +436,7 @@ int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const EvalDomain& v, con
     a.pw_base = pw_base;
     a.wm = ctx->sys.wm;
     a.blow = blow;
-    std::memcpy(a.inv_den, inv_den, sizeof a.inv_den);
+    a.inv_base = inv_base;
     size_t sz = sizeof a;
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     RK_HIP_TRY(ctx, hipModuleLaunchKernel(je.kernel, (unsigned)((a.d + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, nullptr, cfg));

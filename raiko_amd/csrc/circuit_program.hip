@@ -562,17 +562,23 @@ int program_eval_domain(const rk_program* cprog, const EvalDomain& v, const uint
     }
 
     if (const JitEntry* je = program_jit(pg, ctx->device)) {
-        // the generated kernel (rk_program_compile): table = globals | mix | the powers its code indexes
-        const size_t o_mix = v.n_globals, o_pw = (o_mix + v.n_mix + 3) & ~(size_t)3, words = o_pw + 4 * (size_t)je->n_powers;
+        // the generated kernel (rk_program_compile): table = globals | mix | the powers its code indexes | 1 / (x^n - 1)
+        const size_t o_mix = v.n_globals, o_pw = (o_mix + v.n_mix + 3) & ~(size_t)3, o_inv = o_pw + 4 * (size_t)je->n_powers, words = o_inv + 16;
         std::vector<uint32_t> tab(words + 4, 0);
         if (v.n_globals) std::memcpy(tab.data(), v.globals, (size_t)v.n_globals * 4);
         if (v.n_mix) std::memcpy(&tab[o_mix], v.mix, (size_t)v.n_mix * 4);
         program_power_table(pg, je->powers, poly_mix, wm, &tab[o_pw]);
+        std::memcpy(&tab[o_inv], inv_den, sizeof inv_den);
         void* d_tab = nullptr;
-        RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
-        RK_HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
-        RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `tab` is a stack-lifetime host buffer
-        return program_jit_launch(ctx, *je, v, (const uint32_t*)d_tab, 0, (uint32_t)o_mix, (uint32_t)o_pw, d_check, inv_den);
+        if (words * 4 <= ((size_t)1 << 20)) {   // staged through the context's page-locked ring: no wait per proof
+            RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
+            RK_TRY(upload(ctx, d_tab, tab.data(), words * 4));
+        } else {
+            RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
+            RK_HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
+            RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `tab` is a stack-lifetime host buffer
+        }
+        return program_jit_launch(ctx, *je, v, (const uint32_t*)d_tab, 0, (uint32_t)o_mix, (uint32_t)o_pw, d_check, (uint32_t)o_inv);
     }
     EvalArgs a{};
     const uint4* d_ops = nullptr;

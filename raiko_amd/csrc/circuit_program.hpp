@@ -50,7 +50,7 @@ void program_power_table(const rk_program* pg, const std::vector<uint32_t>& powe
 // circuit_jit.hip
 const JitEntry* program_jit(rk_program* pg, int device);
 int program_jit_launch(rk_ctx* ctx, const JitEntry& je, const EvalDomain& dom, const uint32_t* d_tab, uint32_t glob_base,
-                       uint32_t mix_base, uint32_t pw_base, uint32_t* d_check, const uint32_t inv_den[16]);
+                       uint32_t mix_base, uint32_t pw_base, uint32_t* d_check, uint32_t inv_base);
 }  // namespace rk
 
 struct rk_program {
