@@ -13,6 +13,8 @@
 //     costs the compiler tens of minutes), values that cross a cut travel through per-lane carry arrays,
 //     leaves are re-read where they are used.
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +31,110 @@ namespace {
 using bb::Ext;
 constexpr size_t CHUNK = 128;
 constexpr uint32_t NONE = rk::PROGRAM_NONE;
+
+// SHA-256 (FIPS 180-4) for the code-object cache: the files are executable content, a 64-bit FNV name is not an identity
+struct Sha256 {
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint8_t buf[64];
+    size_t fill = 0;
+    uint64_t total = 0;
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const uint8_t* p) {
+        static const uint32_t K[64] = {
+            0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu,
+            0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau,
+            0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u,
+            0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u,
+            0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu,
+            0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const void* data, size_t n) {
+        const uint8_t* p = (const uint8_t*)data;
+        total += n;
+        while (n) {
+            const size_t k = std::min(n, 64 - fill);
+            std::memcpy(buf + fill, p, k);
+            fill += k; p += k; n -= k;
+            if (fill == 64) {
+                block(buf);
+                fill = 0;
+            }
+        }
+    }
+    void finish(uint8_t out[32]) {
+        const uint64_t bits = total * 8;
+        const uint8_t one = 0x80, zero = 0;
+        update(&one, 1);
+        while (fill != 56) update(&zero, 1);
+        uint8_t len[8];
+        for (int i = 0; i < 8; i++) len[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(len, 8);
+        for (int i = 0; i < 8; i++)
+            for (int j = 0; j < 4; j++) out[4 * i + j] = (uint8_t)(h[i] >> (24 - 8 * j));
+    }
+};
+
+// the cache directory must be this user's and writable by nobody else (mode & 022 == 0)
+bool cache_dir_is_private(const char* dir) {
+    struct stat st;
+    if (::stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return st.st_uid == ::geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// file = "RKJIT2\0\0" | key digest 32 | body digest 32 | body length u64 LE | body
+constexpr char CACHE_MAGIC[8] = {'R', 'K', 'J', 'I', 'T', '2', 0, 0};
+std::vector<char> cache_read(const std::string& path, const uint8_t key[32]) {
+    std::vector<char> code;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return code;
+    uint8_t head[8 + 32 + 32 + 8];
+    if (std::fread(head, 1, sizeof head, f) == sizeof head && std::memcmp(head, CACHE_MAGIC, 8) == 0 && std::memcmp(head + 8, key, 32) == 0) {
+        uint64_t n = 0;
+        for (int i = 0; i < 8; i++) n |= (uint64_t)head[72 + i] << (8 * i);
+        if (n > 0 && n < ((uint64_t)1 << 31)) {
+            code.resize((size_t)n);
+            uint8_t d[32];
+            Sha256 h;
+            if (std::fread(code.data(), 1, (size_t)n, f) == (size_t)n && std::fgetc(f) == EOF) {
+                h.update(code.data(), code.size());
+                h.finish(d);
+                if (std::memcmp(d, head + 40, 32) != 0) code.clear();
+            } else {
+                code.clear();
+            }
+        }
+    }
+    std::fclose(f);
+    return code;
+}
+void cache_write(const std::string& path, const uint8_t key[32], const std::vector<char>& code) {
+    uint8_t head[8 + 32 + 32 + 8];
+    std::memcpy(head, CACHE_MAGIC, 8);
+    std::memcpy(head + 8, key, 32);
+    Sha256 h;
+    h.update(code.data(), code.size());
+    h.finish(head + 40);
+    for (int i = 0; i < 8; i++) head[72 + i] = (uint8_t)((uint64_t)code.size() >> (8 * i));
+    // written under a temporary name, renamed when complete: a reader never sees half a file
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)::getpid()) + "_" + std::to_string((unsigned long long)(uintptr_t)&head);
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = std::fwrite(head, 1, sizeof head, f) == sizeof head && std::fwrite(code.data(), 1, code.size(), f) == code.size();
+    std::fclose(f);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
 
 // what the generated kernel receives (same layout as `struct Args` in the source below)
 struct JitArgs {
@@ -460,40 +566,32 @@ int rk_program_compile(rk_program* pg, rk_ctx* ctx) {
     je.n_powers = (uint32_t)je.powers.size();
     hipDeviceProp_t props;
     RK_HIP_TRY(ctx, hipGetDeviceProperties(&props, ctx->device));
-    // RK_JIT_CACHE_DIR (opt-in): code objects keyed by a hash of the generated source, the architecture string and
-    // the hiprtc version -- a circuit of 30 k steps costs ~20 s to compile, a host restart should not pay it again
+    // RK_JIT_CACHE_DIR (opt-in): a circuit of 30 k steps costs ~30 s to compile, a host restart should not pay it again.
+    // A cache file is code that will run on the GPU, so it is only taken from a directory that belongs to this user and
+    // that nobody else can write to, and only when the SHA-256 digests stored in it match: `key` = the generated source,
+    // the architecture string and the hiprtc version (so a file can never stand for another list), `body` = the code
+    // object itself (a truncated or edited file is recompiled, not loaded).
     int rtc_major = 0, rtc_minor = 0;
     (void)hiprtcVersion(&rtc_major, &rtc_minor);
     std::string cache_path;
+    uint8_t key[32] = {0};
     if (const char* dir = std::getenv("RK_JIT_CACHE_DIR")) {
-        if (*dir) {
-            uint64_t hsh = 1469598103934665603ull;  // FNV-1a
-            auto mix = [&](const char* ptr, size_t n) {
-                for (size_t i = 0; i < n; i++) hsh = (hsh ^ (unsigned char)ptr[i]) * 1099511628211ull;
-            };
-            mix(src.data(), src.size());
-            mix(props.gcnArchName, std::strlen(props.gcnArchName));
+        if (*dir && cache_dir_is_private(dir)) {
+            Sha256 h;
+            h.update(src.data(), src.size());
+            h.update(props.gcnArchName, std::strlen(props.gcnArchName));
             char tail[96];
             std::snprintf(tail, sizeof tail, "|hiprtc %d.%d|%zu", rtc_major, rtc_minor, src.size());
-            mix(tail, std::strlen(tail));
-            char name[64];
-            std::snprintf(name, sizeof name, "/rkjit_%016llx.hsaco", (unsigned long long)hsh);
+            h.update(tail, std::strlen(tail));
+            h.finish(key);
+            char name[80];
+            std::snprintf(name, sizeof name, "/rkjit_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x.hsaco", key[0], key[1], key[2], key[3], key[4],
+                          key[5], key[6], key[7], key[8], key[9], key[10], key[11]);
             cache_path = std::string(dir) + name;
         }
     }
     std::vector<char> code;
-    if (!cache_path.empty()) {
-        if (FILE* f = std::fopen(cache_path.c_str(), "rb")) {
-            std::fseek(f, 0, SEEK_END);
-            const long n = std::ftell(f);
-            std::fseek(f, 0, SEEK_SET);
-            if (n > 0) {
-                code.resize((size_t)n);
-                if (std::fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
-            }
-            std::fclose(f);
-        }
-    }
+    if (!cache_path.empty()) code = cache_read(cache_path, key);
     if (code.empty()) {
         hiprtcProgram prog = nullptr;
         if (hiprtcCreateProgram(&prog, src.c_str(), "rk_program.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -517,14 +615,7 @@ int rk_program_compile(rk_program* pg, rk_ctx* ctx) {
         code.resize(code_size);
         (void)hiprtcGetCode(prog, code.data());
         (void)hiprtcDestroyProgram(&prog);
-        if (!cache_path.empty()) {  // best effort: written under a temporary name, renamed when complete
-            const std::string tmp = cache_path + ".tmp" + std::to_string((unsigned long long)(uintptr_t)&je);
-            if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
-                const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
-                std::fclose(f);
-                if (!ok || std::rename(tmp.c_str(), cache_path.c_str()) != 0) (void)std::remove(tmp.c_str());
-            }
-        }
+        if (!cache_path.empty()) cache_write(cache_path, key, code);   // best effort
     }
     RK_HIP_TRY(ctx, hipModuleLoadData(&je.module, code.data()));
     hipError_t e = hipModuleGetFunction(&je.kernel, je.module, "rk_jit_eval_check");

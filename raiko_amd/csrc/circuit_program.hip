@@ -334,9 +334,10 @@ struct EvalArgs {
     uint64_t consts;     // program constants | globals | accum mix
     uint64_t powers;     // 4 words per distinct power of poly_mix
     uint64_t taps;       // uint4 per tap: column base (64-bit), shift in points, log2 of the column's stride per point
-    uint32_t* spill;
+    uint32_t* spill;     // [slot][point of the tile]
     uint32_t* check;
     size_t d;
+    size_t base, tile;   // the launch covers points [base, base + tile): the spill matrix is sized for one tile
     uint32_t n_ops, glob_base, mix_base;
     uint32_t lds_fp, lds_mix, n_fp_slots;
     uint32_t ret_slot, wm;
@@ -372,7 +373,7 @@ struct Lane {
             }
         } else if (kind == K_SPILL) {
 #pragma unroll
-            for (int p = 0; p < P; p++) out[p] = a.spill[(size_t)idx * a.d + i + p * NL];
+            for (int p = 0; p < P; p++) out[p] = a.spill[(size_t)idx * a.tile + (i - a.base) + p * NL];
         } else {
             const uint32_t c = consts[(kind == K_CONST ? 0u : kind == K_GLOBAL ? a.glob_base : a.mix_base) + idx];
 #pragma unroll
@@ -383,7 +384,7 @@ struct Lane {
 #pragma unroll
         for (int p = 0; p < P; p++) {
             if (!spilled) lds[slot * WG + p * NL] = v[p];
-            else a.spill[(size_t)slot * a.d + i + p * NL] = v[p];
+            else a.spill[(size_t)slot * a.tile + (i - a.base) + p * NL] = v[p];
         }
     }
     __device__ __forceinline__ void load_mix(uint32_t slot, Ext (&r)[P]) const {
@@ -394,11 +395,11 @@ struct Lane {
 #pragma unroll
                 for (int e = 0; e < 4; e++) r[p].c[e] = q[e * WG + p * NL];
         } else {
-            const uint32_t* q = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+            const uint32_t* q = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.tile + (i - a.base);
 #pragma unroll
             for (int p = 0; p < P; p++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) r[p].c[e] = q[(size_t)e * a.d + p * NL];
+                for (int e = 0; e < 4; e++) r[p].c[e] = q[(size_t)e * a.tile + p * NL];
         }
     }
     __device__ __forceinline__ void store_mix(uint32_t slot, const Ext (&v)[P]) const {
@@ -409,11 +410,11 @@ struct Lane {
 #pragma unroll
                 for (int e = 0; e < 4; e++) q[e * WG + p * NL] = v[p].c[e];
         } else {
-            uint32_t* q = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.d + i;
+            uint32_t* q = a.spill + ((size_t)(a.n_fp_slots - a.lds_fp) + 4 * (size_t)(slot - a.lds_mix)) * a.tile + (i - a.base);
 #pragma unroll
             for (int p = 0; p < P; p++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) q[(size_t)e * a.d + p * NL] = v[p].c[e];
+                for (int e = 0; e < 4; e++) q[(size_t)e * a.tile + p * NL] = v[p].c[e];
         }
     }
 };
@@ -423,7 +424,7 @@ template <int P>
 __global__ __launch_bounds__(WG / P) void program_kernel(EvalArgs a) {
     extern __shared__ uint32_t lds_all[];
     constexpr int NL = WG / P;
-    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t i = a.base + (size_t)blockIdx.x * WG + threadIdx.x;
     if (i >= a.d) return;  // P == 1 only; no barrier anywhere below
     Lane<P> ln{a, (lds_u32*)lds_all + threadIdx.x, i, (const_u32)a.consts, (const_u4)a.taps};
     const const_u4 code = (const_u4)a.code;
@@ -570,14 +571,8 @@ int program_eval_domain(const rk_program* cprog, const EvalDomain& v, const uint
         program_power_table(pg, je->powers, poly_mix, wm, &tab[o_pw]);
         std::memcpy(&tab[o_inv], inv_den, sizeof inv_den);
         void* d_tab = nullptr;
-        if (words * 4 <= ((size_t)1 << 20)) {   // staged through the context's page-locked ring: no wait per proof
-            RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
-            RK_TRY(upload(ctx, d_tab, tab.data(), words * 4));
-        } else {
-            RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
-            RK_HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
-            RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `tab` is a stack-lifetime host buffer
-        }
+        RK_TRY(scratch(ctx, words * 4 + 16, &d_tab));
+        RK_TRY(upload(ctx, d_tab, tab.data(), words * 4));  // through the page-locked ring (no wait) when it fits
         return program_jit_launch(ctx, *je, v, (const uint32_t*)d_tab, 0, (uint32_t)o_mix, (uint32_t)o_pw, d_check, (uint32_t)o_inv);
     }
     EvalArgs a{};
@@ -605,8 +600,7 @@ int program_eval_domain(const rk_program* cprog, const EvalDomain& v, const uint
     }
     void* d_pack = nullptr;
     RK_TRY(scratch(ctx, words * 4 + 16, &d_pack));
-    RK_HIP_TRY(ctx, hipMemcpyAsync(d_pack, pack.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pack is a stack-lifetime host buffer
+    RK_TRY(upload(ctx, d_pack, pack.data(), words * 4));  // through the page-locked ring (no wait) when it fits, copy + wait otherwise
     const uint32_t* dp = (const uint32_t*)d_pack;
     a.consts = (uint64_t)(uintptr_t)dp;
     a.glob_base = (uint32_t)o_glob;
@@ -624,16 +618,29 @@ int program_eval_domain(const rk_program* cprog, const EvalDomain& v, const uint
     a.blow = blow;
     a.split = v.split_log2;
     std::memcpy(a.inv_den, inv_den, sizeof a.inv_den);
-    const size_t spill_words = ((size_t)(pg->n_fp_slots - a.lds_fp) + 4 * (size_t)(pg->n_mix_slots - a.lds_mix)) * d;
+    // The values that do not fit the LDS budget live in an HBM matrix [slot][point].  Sized for the whole domain it
+    // would be live_slots * d words (a list with 2 k live values at 2^22 points: 37 GB per proof, times the proofs in
+    // flight): the domain is walked in tiles instead, every tile reusing one matrix of at most SPILL_CAP bytes -- small
+    // enough to stay in the 256 MB of Infinity Cache for typical lists.
+    const size_t spill_rows = (size_t)(pg->n_fp_slots - a.lds_fp) + 4 * (size_t)(pg->n_mix_slots - a.lds_mix);
+    constexpr size_t SPILL_CAP = (size_t)1 << 30;
+    size_t tile = d;
+    while (spill_rows * tile * 4 > SPILL_CAP && tile > (size_t)WG * 256 && tile % 2 == 0) tile /= 2;
     void* d_spill = nullptr;
-    if (spill_words) RK_TRY(dev_alloc(ctx, spill_words * 4, &d_spill));
+    if (spill_rows) RK_TRY(dev_alloc(ctx, spill_rows * tile * 4, &d_spill));
     a.spill = (uint32_t*)d_spill;
+    a.tile = tile;
     const size_t lds_bytes = (size_t)(a.lds_fp + 4 * a.lds_mix) * WG * 4;
-    if (d % WG == 0)  // two points per lane: the per-op scalar work is paid once per 128 points
-        hipLaunchKernelGGL(program_kernel<2>, dim3((unsigned)(d / WG)), dim3(WG / 2), lds_bytes, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(program_kernel<1>, dim3((unsigned)((d + WG - 1) / WG)), dim3(WG), lds_bytes, ctx->stream, a);
-    int rc = post_launch(ctx, "program_kernel");
+    int rc = RK_OK;
+    for (size_t base = 0; base < d && rc == RK_OK; base += tile) {
+        a.base = base;
+        const size_t n_pts = std::min(tile, d - base);
+        if (n_pts % WG == 0)  // two points per lane: the per-op scalar work is paid once per 128 points
+            hipLaunchKernelGGL(program_kernel<2>, dim3((unsigned)(n_pts / WG)), dim3(WG / 2), lds_bytes, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(program_kernel<1>, dim3((unsigned)((n_pts + WG - 1) / WG)), dim3(WG), lds_bytes, ctx->stream, a);
+        rc = post_launch(ctx, "program_kernel");
+    }
     if (d_spill) {
         int fr = dev_free(ctx, d_spill);  // stream-ordered: the block is reused only by later work of this stream
         if (rc == RK_OK) rc = fr;

@@ -258,12 +258,15 @@ def test_runtime_compiled_toy_circuit_seal(hal, toy):
 
 def test_jit_cache_directory(hal, tmp_path, monkeypatch):
     """RK_JIT_CACHE_DIR: the code object of a compiled list is written once and loaded by the next program with the
-    same generated source (a second host process in real life); a truncated file is not trusted blindly -- the
-    module fails to load and the call reports it instead of running garbage"""
+    same generated source (a second host process in real life).  A cache file is GPU code, so it carries SHA-256
+    digests of what it was built from and of its own body: a truncated or edited file is ignored and recompiled (the
+    results stay right), and a directory that others may write to is not used at all."""
+    import os
     import time
     rng = np.random.default_rng(4242)
     taps = synthetic_tapset(6, 4, 20)
     steps, ret = random_program(rng, taps, 3, 2, n_fp_ops=400, n_live=20, depth=3, n_constraints=40)
+    os.chmod(tmp_path, 0o700)
     monkeypatch.setenv("RK_JIT_CACHE_DIR", str(tmp_path))
     first, second, interp = cp.Program(steps, ret, taps), cp.Program(steps, ret, taps), cp.Program(steps, ret, taps)
     t0 = time.perf_counter()
@@ -271,6 +274,7 @@ def test_jit_cache_directory(hal, tmp_path, monkeypatch):
     t1 = time.perf_counter()
     files = list(tmp_path.glob("rkjit_*.hsaco"))
     assert len(files) == 1 and files[0].stat().st_size > 1000
+    assert files[0].read_bytes()[:8] == b"RKJIT2\0\0"
     second.compile(hal)
     t2 = time.perf_counter()
     assert len(list(tmp_path.iterdir())) == 1               # nothing new, no temporary left behind
@@ -282,7 +286,20 @@ def test_jit_cache_directory(hal, tmp_path, monkeypatch):
     want = run_eval_check(hal, interp, po2, lde, globals_, mix, pm)
     assert np.array_equal(run_eval_check(hal, first, po2, lde, globals_, mix, pm), want)
     assert np.array_equal(run_eval_check(hal, second, po2, lde, globals_, mix, pm), want)
-    files[0].write_bytes(files[0].read_bytes()[:200])
-    third = cp.Program(steps, ret, taps)
-    with pytest.raises(Exception):
+    # an edited body (one byte of code flipped) and a truncated file: neither is loaded, both are replaced by a fresh build
+    good = files[0].read_bytes()
+    for bad in (good[:-5] + bytes([good[-5] ^ 1]) + good[-4:], good[:200]):
+        files[0].write_bytes(bad)
+        third = cp.Program(steps, ret, taps)
         third.compile(hal)
+        assert np.array_equal(run_eval_check(hal, third, po2, lde, globals_, mix, pm), want)
+        assert files[0].read_bytes() == good                # the rebuilt file is the original again
+    # a directory somebody else could write to is not trusted: nothing is read from it, nothing written to it
+    open_dir = tmp_path / "shared"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o777)
+    monkeypatch.setenv("RK_JIT_CACHE_DIR", str(open_dir))
+    fourth = cp.Program(steps, ret, taps)
+    fourth.compile(hal)
+    assert list(open_dir.iterdir()) == []
+    assert np.array_equal(run_eval_check(hal, fourth, po2, lde, globals_, mix, pm), want)
