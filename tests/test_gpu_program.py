@@ -303,3 +303,25 @@ def test_jit_cache_directory(hal, tmp_path, monkeypatch):
     fourth.compile(hal)
     assert list(open_dir.iterdir()) == []
     assert np.array_equal(run_eval_check(hal, fourth, po2, lde, globals_, mix, pm), want)
+
+
+def test_interpreter_walks_the_domain_in_tiles_when_the_spill_matrix_is_large(hal):
+    """a list with hundreds of values alive at once: the interpreter's HBM slot matrix would be live_slots x domain words
+    (1.4 GB here, tens of GB at 2^22 points); it is capped at 1 GiB and the domain walked in tiles that reuse it
+    (circuit_program.hip).  Same output as the generated kernel, which keeps such values in per-lane registers / scratch."""
+    rng = np.random.default_rng(99)
+    taps = synthetic_tapset(4, 4, 12)
+    steps, ret = random_program(rng, taps, 3, 2, n_fp_ops=900, n_live=420, depth=2, n_constraints=30)
+    interp, jit = cp.Program(steps, ret, taps), cp.Program(steps, ret, taps)
+    assert interp.info()["n_fp_slots"] > 320                 # > 1 GiB / (2^20 points x 4 bytes) beyond the LDS budget
+    jit.compile(hal)
+    po2 = 18
+    d = 4 << po2
+    lde = [o.rand_elems(rng, (int(w), d)) for w in taps.group_size]
+    globals_, mix, pm = o.rand_elems(rng, (3,)), o.rand_elems(rng, (2,)), o.rand_elems(rng, (4,))
+    a = run_eval_check(hal, interp, po2, lde, globals_, mix, pm)
+    b = run_eval_check(hal, jit, po2, lde, globals_, mix, pm)
+    assert np.array_equal(a, b)
+    # and against the oracle's literal interpreter on a slice of the domain's columns: same list, small domain
+    small = [x[:, : 4 << 6].copy() for x in lde]
+    assert np.array_equal(run_eval_check(hal, interp, 6, small, globals_, mix, pm), oracle_eval_check(interp, taps, 6, small, globals_, mix, pm))
