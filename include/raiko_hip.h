@@ -588,6 +588,31 @@ int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_
                  const uint32_t* proof, size_t proof_words);
 /* exact proof size for the tables' shapes (log_height, width, air); 0 for shapes rk_p3_prove rejects */
 size_t rk_p3_proof_bound_words(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables);
+/* Many independent proofs -- the shards of one SP1 execution -- with `batch` of them in flight per GPU: what SP1's
+ * SHARD_BATCH_SIZE bounds (docs/README_Sp1.md:27-32; shards are proven from one work queue, the latency-bound parts of
+ * one proof -- transcript round trips, the small FRI layers -- under the throughput-bound parts of the others).  One
+ * worker thread and prover context per slot, kept per device for the life of the process like rk_prove_session's
+ * (rk_session_release frees them too); proof i lands in shards[i].h_proof.  verify != 0: every proof is checked with
+ * rk_p3_verify by its worker before the next shard is taken.  Returns RK_OK or the first failure (RK_ERR_VERIFY for a
+ * proof that does not verify) with the shard's index in *failed_index. */
+typedef struct {
+    const rk_p3_table* tables;
+    uint32_t n_tables;
+    const uint32_t* init_words;
+    size_t n_init;
+    uint32_t* h_proof;
+    size_t capacity_words;
+    size_t proof_words;            /* out */
+} rk_p3_shard;
+typedef struct {
+    int device;                    /* the GPU, when n_devices == 0 */
+    int batch;                     /* proofs in flight per GPU, 1..16 (SHARD_BATCH_SIZE) */
+    int verify;
+    const int* devices;            /* optional list of distinct GPUs sharing the work queue */
+    int n_devices;
+    const rk_params* params;       /* NULL = the SP1 preset */
+} rk_p3_session_opts;
+int rk_p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t n, size_t* failed_index);
 /* wall-clock per stage of the last rk_p3_prove on this ctx, milliseconds (the stream is drained at every boundary) */
 typedef struct { float lde, commit, quotient, open, fri, query, total; } rk_p3_timing;
 int rk_p3_last_timing(rk_ctx* ctx, rk_p3_timing* out);

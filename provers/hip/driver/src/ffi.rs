@@ -293,6 +293,29 @@ pub struct rk_p3_table {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct rk_p3_shard {
+    pub tables: *const rk_p3_table,
+    pub n_tables: u32,
+    pub init_words: *const u32,
+    pub n_init: usize,
+    pub h_proof: *mut u32,
+    pub capacity_words: usize,
+    pub proof_words: usize,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rk_p3_session_opts {
+    pub device: c_int,
+    pub batch: c_int,
+    pub verify: c_int,
+    pub devices: *const c_int,
+    pub n_devices: c_int,
+    pub params: *const rk_params,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct rk_p3_timing {
     pub lde: f32,
     pub commit: f32,
@@ -408,6 +431,7 @@ extern "C" {
     pub fn rk_p3_prove(ctx: *mut rk_ctx, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, h_proof: *mut u32, capacity_words: usize, proof_words: *mut usize) -> c_int;
     pub fn rk_p3_verify(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, proof: *const u32, proof_words: usize) -> c_int;
     pub fn rk_p3_proof_bound_words(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32) -> usize;
+    pub fn rk_p3_prove_shards(opts: *const rk_p3_session_opts, shards: *mut rk_p3_shard, n: usize, failed_index: *mut usize) -> c_int;
     pub fn rk_p3_last_timing(ctx: *mut rk_ctx, out: *mut rk_p3_timing) -> c_int;
     pub fn rk_last_timing(ctx: *mut rk_ctx, out: *mut rk_timing) -> c_int;
     pub fn rk_set_kernel_timing(ctx: *mut rk_ctx, enabled: c_int) -> c_int;

@@ -129,6 +129,16 @@ class RkP3Table(C.Structure):
                 ("public_values", u32p), ("n_public", C.c_uint32), ("on_device", C.c_uint32)]
 
 
+class RkP3Shard(C.Structure):
+    _fields_ = [("tables", C.POINTER(RkP3Table)), ("n_tables", C.c_uint32), ("init_words", u32p), ("n_init", C.c_size_t),
+                ("h_proof", u32p), ("capacity_words", C.c_size_t), ("proof_words", C.c_size_t)]
+
+
+class RkP3SessionOpts(C.Structure):
+    _fields_ = [("device", C.c_int), ("batch", C.c_int), ("verify", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int),
+                ("params", C.POINTER(RkParams))]
+
+
 class RkP3Timing(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lde", "commit", "quotient", "open", "fri", "query", "total")]
 
@@ -240,6 +250,7 @@ SYMBOLS = {
     "rk_p3_verify": (C.c_int, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32, u32p, _sz, u32p, _sz]),
     "rk_p3_proof_bound_words": (_sz, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32]),
     "rk_p3_last_timing": (C.c_int, [_vp, C.POINTER(RkP3Timing)]),
+    "rk_p3_prove_shards": (C.c_int, [C.POINTER(RkP3SessionOpts), C.POINTER(RkP3Shard), _sz, C.POINTER(_sz)]),
     "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
     "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),
 }

@@ -23,9 +23,13 @@
 #include "internal.hpp"
 #include "circuit_program.hpp"
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 struct rk_air {
     std::vector<rk_air_step> steps;
@@ -735,9 +739,146 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     return r.pos == r.n ? 0 : 1;
 }
 
+// ---------------------------------------------------------------- shards in flight (rk_p3_prove_shards)
+struct ShardPool {
+    std::mutex busy;                 // one batch at a time per device
+    std::vector<rk_ctx*> ctxs;
+    std::vector<std::vector<uint32_t>> key;   // the parameter set each context carries
+    ~ShardPool() {
+        for (rk_ctx* c : ctxs) (void)rk_ctx_destroy(c);
+    }
+};
+std::mutex g_shard_mu;
+std::map<int, std::shared_ptr<ShardPool>> g_shard_pools;
+
+std::vector<uint32_t> params_key(const rk_params& p) {
+    std::vector<uint32_t> k = {p.ext_w, p.root_2_27, p.coset_shift, p.p2_width, p.p2_m4, p.p2_pad_free, p.queries, p.blowup_log2,
+                               p.fri_fold_log2, p.fri_min_degree, p.pow_bits};
+    rk::Sys sys;
+    auto any = std::make_unique<p2::Any>();
+    if (rk::resolve_params(&p, &sys, any.get()) != RK_OK) return {};
+    k.insert(k.end(), any->rc_ext(), any->rc_ext() + 8 * any->cells());
+    k.insert(k.end(), any->rc_int(), any->rc_int() + any->rounds_partial());
+    k.insert(k.end(), any->diag(), any->diag() + any->cells());
+    return k;
+}
+
+int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t n, size_t* failed_index) {
+    if (failed_index) *failed_index = (size_t)-1;
+    if (!opts || (n && !shards) || opts->batch < 1 || opts->batch > 16) return RK_ERR_INVALID;
+    if (opts->n_devices < 0 || opts->n_devices > 64 || (opts->n_devices > 0 && !opts->devices)) return RK_ERR_INVALID;
+    if (n == 0) return RK_OK;
+    std::vector<int> devices;
+    if (opts->n_devices > 0) devices.assign(opts->devices, opts->devices + opts->n_devices);
+    else devices.push_back(opts->device);
+    std::sort(devices.begin(), devices.end());   // pools are locked in ascending order
+    if (std::adjacent_find(devices.begin(), devices.end()) != devices.end()) return RK_ERR_INVALID;
+    int n_gpus = 0;
+    if (hipGetDeviceCount(&n_gpus) != hipSuccess || n_gpus <= 0) return RK_ERR_NODEVICE;
+    for (int d : devices)
+        if (d < 0 || d >= n_gpus) return RK_ERR_INVALID;
+    rk_params par;
+    rk::params_preset(&par, RK_PRESET_SP1);
+    if (opts->params) par = *opts->params;
+    const std::vector<uint32_t> key = params_key(par);
+    if (key.empty()) return RK_ERR_INVALID;
+    for (size_t i = 0; i < n; i++)
+        if (!shards[i].h_proof || (shards[i].n_init && !shards[i].init_words)) return RK_ERR_INVALID;
+
+    std::vector<std::shared_ptr<ShardPool>> pools;
+    {
+        std::lock_guard<std::mutex> l(g_shard_mu);
+        for (int d : devices) {
+            auto& sp = g_shard_pools[d];
+            if (!sp) sp = std::make_shared<ShardPool>();
+            pools.push_back(sp);
+        }
+    }
+    std::vector<std::unique_lock<std::mutex>> held;
+    for (auto& p : pools) held.emplace_back(p->busy);
+    const size_t per_dev = std::min<size_t>((size_t)opts->batch, n);
+    for (size_t d = 0; d < devices.size(); d++) {
+        ShardPool& pool = *pools[d];
+        while (pool.ctxs.size() < per_dev) {
+            rk_ctx* c = nullptr;
+            RK_TRY(rk_ctx_create(devices[d], nullptr, &c));
+            pool.ctxs.push_back(c);
+            pool.key.emplace_back();
+        }
+        for (size_t j = 0; j < per_dev; j++) {
+            if (pool.key[j] == key) continue;
+            RK_TRY(rk_set_params(pool.ctxs[j], &par));
+            pool.key[j] = key;
+        }
+    }
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    int status = RK_OK;
+    size_t failed = (size_t)-1;
+    auto fail = [&](int st, size_t i) {
+        std::lock_guard<std::mutex> l(mu);
+        if (status == RK_OK) {
+            status = st;
+            failed = i;
+        }
+    };
+    auto worker = [&](rk_ctx* ctx) {
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> l(mu);
+                if (status != RK_OK) return;
+            }
+            const size_t i = next.fetch_add(1);
+            if (i >= n) return;
+            rk_p3_shard& sh = shards[i];
+            int st = RK_ERR_INTERNAL;
+            try {
+                st = rk_p3_prove(ctx, sh.tables, sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.capacity_words, &sh.proof_words);
+                if (st == RK_OK && opts->verify) {
+                    const int v = rk_p3_verify(&par, sh.tables, sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.proof_words);
+                    if (v != 0) st = RK_ERR_VERIFY;
+                }
+            } catch (...) {
+            }
+            if (st != RK_OK) {
+                fail(st, i);
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t d = 0; d < devices.size(); d++)
+        for (size_t j = 0; j < per_dev; j++) threads.emplace_back(worker, pools[d]->ctxs[j]);
+    for (auto& t : threads) t.join();
+    if (failed_index) *failed_index = failed;
+    return status;
+}
+
 }  // namespace
 
+namespace rk {
+void p3_release_pools() {
+    std::map<int, std::shared_ptr<ShardPool>> pools;
+    {
+        std::lock_guard<std::mutex> l(g_shard_mu);
+        pools.swap(g_shard_pools);
+    }
+    for (auto& kv : pools) {
+        std::lock_guard<std::mutex> l(kv.second->busy);   // wait for a running batch
+        std::vector<rk_ctx*> ctxs;
+        ctxs.swap(kv.second->ctxs);
+        for (rk_ctx* c : ctxs) (void)rk_ctx_destroy(c);
+    }
+}
+}  // namespace rk
+
 extern "C" {
+
+int rk_p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t n, size_t* failed_index) {
+    RK_GUARD_BEGIN
+    return p3_prove_shards(opts, shards, n, failed_index);
+    RK_GUARD_END
+}
 
 int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, rk_air** out) {
     RK_GUARD_BEGIN

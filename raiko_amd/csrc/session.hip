@@ -674,6 +674,7 @@ int rk_session_last_proven(int device, size_t* count) {
 
 int rk_session_release(void) {
     RK_GUARD_BEGIN
+    rk::p3_release_pools();
     std::map<int, std::shared_ptr<DevicePool>> pools;
     {
         std::lock_guard<std::mutex> l(g_mu);

@@ -281,6 +281,39 @@ def prove(hal, tables, init=(), device_traces=None):
     return out[: n.value].copy()
 
 
+def prove_shards(shards, params, device=0, batch=3, verify=True, devices=None, device_traces=None):
+    """rk_p3_prove_shards: `shards` = list of (tables, init words); `batch` proofs in flight per GPU (SP1's SHARD_BATCH_SIZE).
+    -> list of proof word arrays, in order.  device_traces: optional per shard list as in prove()."""
+    lib = _lib.load()
+    n = len(shards)
+    arr = (_lib.RkP3Shard * n)()
+    keep, bufs = [], []
+    for i, (tables, init) in enumerate(shards):
+        ctab, k = _c_tables(tables, device_traces[i] if device_traces else None)
+        iw = np.ascontiguousarray(init, dtype=np.uint32)
+        cap = lib.rk_p3_proof_bound_words(C.byref(params), ctab, len(tables))
+        if cap == 0:
+            raise _lib.RkError(_lib.RK_ERR_INVALID, "shard %d: shapes the prover rejects" % i)
+        buf = np.zeros(cap, dtype=np.uint32)
+        arr[i].tables, arr[i].n_tables = ctab, len(tables)
+        arr[i].init_words, arr[i].n_init = iw.ctypes.data_as(_lib.u32p), iw.size
+        arr[i].h_proof, arr[i].capacity_words = buf.ctypes.data_as(_lib.u32p), cap
+        keep += [ctab, k, iw]
+        bufs.append(buf)
+    opts = _lib.RkP3SessionOpts(device=device, batch=batch, verify=1 if verify else 0, params=C.pointer(params))
+    if devices is not None:
+        dev_arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        opts.devices, opts.n_devices = dev_arr, len(devices)
+    failed = C.c_size_t(0)
+    st = lib.rk_p3_prove_shards(C.byref(opts), arr, n, C.byref(failed))
+    if st != 0:
+        e = _lib.RkError(st, lib.rk_strerror(st).decode() + (" (shard %d)" % failed.value if failed.value != C.c_size_t(-1).value else ""))
+        e.segment = int(failed.value) if failed.value != C.c_size_t(-1).value else -1
+        raise e
+    del keep
+    return [bufs[i][: arr[i].proof_words].copy() for i in range(n)]
+
+
 def verify(tables, proof, init=(), params=None) -> int:
     """rk_p3_verify (host only).  params: an RkParams blob (raiko_amd.hal.make_params) or None for the SP1 preset"""
     lib = _lib.load()

@@ -100,6 +100,34 @@ def test_larger_shard_shaped_proof(hal):
     assert p3.verify(tables, got, init, params=blob) == 0
 
 
+def test_shards_in_flight_give_the_same_proofs(hal):
+    """rk_p3_prove_shards: independent proofs (the shards of one SP1 execution) from one work queue with `batch` in
+    flight (SHARD_BATCH_SIZE, docs/README_Sp1.md:27-32): the proofs are those of one-at-a-time proving, in order; a shard
+    whose trace breaks its AIR is reported by its index when verification is on"""
+    from raiko_amd._lib import RkError
+    over = dict(queries=6, pow_bits=4)
+    blob = hal.set_params(1, **over)
+    a1, a2 = air_of("cubic", 6), air_of("fib", None)
+    shards = []
+    for i in range(7):
+        t1 = p3.Table.from_canonical(a1, *p3.cubic_trace(5 + i % 3, 6, seed=40 + i))
+        t2 = p3.Table.from_canonical(a2, *p3.fibonacci_trace(3 + i % 4, 1 + i, 2))
+        shards.append(([t1, t2] if i % 2 else [t2, t1], p3.to_mont([i, 7])))
+    want = [p3.prove(hal, tables, init) for tables, init in shards]
+    for batch in (1, 3):
+        got = p3.prove_shards(shards, blob, batch=batch, verify=True)
+        assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    tr, pv = p3.cubic_trace(5, 6, seed=77)
+    tr[9, 0] = (int(tr[9, 0]) + 1) % P
+    bad = list(shards)
+    bad[4] = ([p3.Table.from_canonical(a1, tr, pv)], p3.to_mont([1]))
+    with pytest.raises(RkError) as ei:
+        p3.prove_shards(bad, blob, batch=2, verify=True)
+    assert ei.value.status == -7 and ei.value.segment == 4
+    assert len(p3.prove_shards(bad, blob, batch=2, verify=False)) == 7           # proving alone does not notice
+    H.session_release()
+
+
 def test_capacity_and_argument_errors(hal):
     import ctypes as C
     from raiko_amd import _lib

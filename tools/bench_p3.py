@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--preset", type=int, default=1)
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--shards", type=int, default=0, help="also prove this many copies of the shape as independent shards through "
+                                                          "rk_p3_prove_shards with --batch of them in flight (SP1's SHARD_BATCH_SIZE)")
+    ap.add_argument("--batch", type=int, default=3)
     args = ap.parse_args()
     print(json.dumps(run(args)), flush=True)
 
@@ -81,6 +84,16 @@ def run(args):
         t2 = time.perf_counter()
         out["verify_rc"] = p3.verify(tables, pf, params=blob)
         out["verify_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
+    if getattr(args, "shards", 0):
+        shards = [(tables, [i + 1]) for i in range(args.shards)]
+        dts = [dev] * args.shards
+        p3.prove_shards(shards[: args.batch], blob, batch=args.batch, verify=False, device_traces=dts[: args.batch])   # contexts, tables
+        t3 = time.perf_counter()
+        proofs = p3.prove_shards(shards, blob, batch=args.batch, verify=not args.no_verify, device_traces=dts)
+        dt = time.perf_counter() - t3
+        out["shards"] = {"n": args.shards, "batch": args.batch, "wall_ms": round(dt * 1e3, 2), "ms_per_shard": round(dt * 1e3 / args.shards, 3),
+                         "cells_per_s": round(cells * args.shards / dt, 1), "verified_inside": not args.no_verify,
+                         "distinct_proofs": len({pf.tobytes() for pf in proofs})}
     hal.close()
     return out
 
