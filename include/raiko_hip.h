@@ -593,7 +593,7 @@ size_t rk_p3_proof_bound_words(const rk_params* params, const rk_p3_table* table
  * one proof -- transcript round trips, the small FRI layers -- under the throughput-bound parts of the others).  One
  * worker thread and prover context per slot, kept per device for the life of the process like rk_prove_session's
  * (rk_session_release frees them too); proof i lands in shards[i].h_proof.  verify != 0: every proof is checked with
- * rk_p3_verify by its worker before the next shard is taken.  Returns RK_OK or the first failure (RK_ERR_VERIFY for a
+ * rk_p3_verify on host threads of their own while the GPU goes on.  Returns RK_OK or the first failure (RK_ERR_VERIFY for a
  * proof that does not verify) with the shard's index in *failed_index. */
 typedef struct {
     const rk_p3_table* tables;

@@ -25,7 +25,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -813,6 +815,9 @@ int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t 
     }
     std::atomic<size_t> next{0};
     std::mutex mu;
+    std::condition_variable cv;
+    std::deque<size_t> to_verify;      // proven shards waiting for a verifier thread
+    size_t workers_left = 0;
     int status = RK_OK;
     size_t failed = (size_t)-1;
     auto fail = [&](int st, size_t i) {
@@ -821,34 +826,68 @@ int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t 
             status = st;
             failed = i;
         }
+        cv.notify_all();
     };
     auto worker = [&](rk_ctx* ctx) {
         for (;;) {
             {
                 std::lock_guard<std::mutex> l(mu);
-                if (status != RK_OK) return;
+                if (status != RK_OK) break;
             }
             const size_t i = next.fetch_add(1);
-            if (i >= n) return;
+            if (i >= n) break;
             rk_p3_shard& sh = shards[i];
             int st = RK_ERR_INTERNAL;
             try {
                 st = rk_p3_prove(ctx, sh.tables, sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.capacity_words, &sh.proof_words);
-                if (st == RK_OK && opts->verify) {
-                    const int v = rk_p3_verify(&par, sh.tables, sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.proof_words);
-                    if (v != 0) st = RK_ERR_VERIFY;
-                }
             } catch (...) {
             }
             if (st != RK_OK) {
                 fail(st, i);
+                break;
+            }
+            if (opts->verify) {   // host work (~40 ms for 100 queries): never on the thread that feeds the GPU
+                std::lock_guard<std::mutex> l(mu);
+                to_verify.push_back(i);
+                cv.notify_all();
+            }
+        }
+        std::lock_guard<std::mutex> l(mu);
+        workers_left--;
+        cv.notify_all();
+    };
+    auto verifier = [&]() {
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return !to_verify.empty() || workers_left == 0 || status != RK_OK; });
+                if (status != RK_OK || to_verify.empty()) return;
+                i = to_verify.front();
+                to_verify.pop_front();
+            }
+            int v = RK_ERR_INTERNAL;
+            try {
+                const rk_p3_shard& sh = shards[i];
+                v = rk_p3_verify(&par, sh.tables, sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.proof_words);
+            } catch (...) {
+            }
+            if (v != 0) {
+                fail(RK_ERR_VERIFY, i);
                 return;
             }
         }
     };
     std::vector<std::thread> threads;
+    workers_left = devices.size() * per_dev;
     for (size_t d = 0; d < devices.size(); d++)
         for (size_t j = 0; j < per_dev; j++) threads.emplace_back(worker, pools[d]->ctxs[j]);
+    if (opts->verify) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        size_t nv = std::min<size_t>(std::min<size_t>(16, 4 * devices.size()), std::max<unsigned>(1, hw / 4));
+        nv = std::min(nv, n);
+        for (size_t v = 0; v < nv; v++) threads.emplace_back(verifier);
+    }
     for (auto& t : threads) t.join();
     if (failed_index) *failed_index = failed;
     return status;
