@@ -445,6 +445,29 @@ int rk_session_release(void);
  * provers per device, session-wide claim flags, pinning of device-resident segments to the first device of the GPU
  * that holds them) on a box with one GPU.  Not for production: the devices share one GPU's memory and time. */
 
+/* ---- the one collective of the path, for hosts that run one process per GPU (raiko's own single-process
+ * host needs none: rk_prove_session writes every seal into the caller's buffers) ----
+ * Rank r proves global segments r, r + world, ... and the ranks exchange the variable-length seals with two
+ * ncclAllGather calls over RCCL (xGMI inside a node): a length table, then padded payloads.  RCCL is looked up at run
+ * time (librccl.so.1); RK_ERR_NODEVICE when it is not there.  rk_comm_unique_id is called by one rank, the 128 bytes go to
+ * the others out of band (a file, MPI, the launcher's store), every rank then calls rk_comm_create. */
+typedef struct rk_comm rk_comm;
+#define RK_COMM_ID_BYTES 128
+int rk_comm_unique_id(uint8_t id[RK_COMM_ID_BYTES]);
+int rk_comm_create(const uint8_t id[RK_COMM_ID_BYTES], int rank, int world, int device, rk_comm** out);
+int rk_comm_destroy(rk_comm* comm);
+const char* rk_comm_last_error(rk_comm* comm);
+/* h_local_seals / local_words: this rank's n_local seals in the order it proved them (segments rank, rank + world, ...;
+ * n_local must be that count for n_total).  On return EVERY rank has out_words[i] for all i < n_total and, where h_out and
+ * h_out[i] are given, seal i copied into h_out[i] (RK_ERR_CAPACITY if out_capacity[i] is too small; the others are
+ * still delivered). */
+int rk_gather_seals(rk_comm* comm, const uint32_t* const* h_local_seals, const size_t* local_words, size_t n_local, size_t n_total,
+                    uint32_t* const* h_out, const size_t* out_capacity, size_t* out_words);
+/* the host half of the gather: the gathered length table (world x per_rank words) and padded payloads
+ * (world x per_rank x max_len words) into segment order */
+int rk_gather_unpack(const uint32_t* all_lens, const uint32_t* all_payload, int world, size_t per_rank, size_t max_len, size_t n_total,
+                     uint32_t* const* h_out, const size_t* out_capacity, size_t* out_words);
+
 /* ---- RV32IM executor + segmenter: the step before the path ----
  * `ExecutorImpl::from_elf(env, elf).run()` (provers/risc0/driver/src/bonsai.rs:267-269): interprets a
  * 32-bit RISC-V ELF (RV32I + M) and cuts the run into segments of at most 2^segment_limit_po2

@@ -65,11 +65,17 @@ pub const RK_KCLASS_POLY: rk_kclass = 4;
 pub const RK_KCLASS_COUNT: rk_kclass = 5;
 
 pub const RK_MAX_QUERIES: u32 = 256;
+pub const RK_COMM_ID_BYTES: u32 = 128;
 pub const RK_TRACE_CODE_COLS: u32 = 2;
 pub const RK_TRACE_DATA_COLS: u32 = 16;
 
 #[repr(C)]
 pub struct rk_air {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct rk_comm {
     _private: [u8; 0],
 }
 
@@ -413,6 +419,12 @@ extern "C" {
     pub fn rk_session_last_error(device: c_int) -> *const c_char;
     pub fn rk_session_last_proven(device: c_int, count: *mut usize) -> c_int;
     pub fn rk_session_release() -> c_int;
+    pub fn rk_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn rk_comm_create(id: *const u8, rank: c_int, world: c_int, device: c_int, out: *mut *mut rk_comm) -> c_int;
+    pub fn rk_comm_destroy(comm: *mut rk_comm) -> c_int;
+    pub fn rk_comm_last_error(comm: *mut rk_comm) -> *const c_char;
+    pub fn rk_gather_seals(comm: *mut rk_comm, h_local_seals: *const *const u32, local_words: *const usize, n_local: usize, n_total: usize, h_out: *const *mut u32, out_capacity: *const usize, out_words: *mut usize) -> c_int;
+    pub fn rk_gather_unpack(all_lens: *const u32, all_payload: *const u32, world: c_int, per_rank: usize, max_len: usize, n_total: usize, h_out: *const *mut u32, out_capacity: *const usize, out_words: *mut usize) -> c_int;
     pub fn rk_exec_elf(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
     pub fn rk_exec_open(elf: *const u8, elf_bytes: usize, opts: *const rk_exec_opts, out: *mut *mut rk_exec) -> c_int;
     pub fn rk_exec_next_segment(ex: *mut rk_exec, more: *mut c_int) -> c_int;

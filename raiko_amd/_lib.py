@@ -251,6 +251,12 @@ SYMBOLS = {
     "rk_p3_proof_bound_words": (_sz, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32]),
     "rk_p3_last_timing": (C.c_int, [_vp, C.POINTER(RkP3Timing)]),
     "rk_p3_prove_shards": (C.c_int, [C.POINTER(RkP3SessionOpts), C.POINTER(RkP3Shard), _sz, C.POINTER(_sz)]),
+    "rk_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rk_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rk_comm_destroy": (C.c_int, [_vp]),
+    "rk_comm_last_error": (C.c_char_p, [_vp]),
+    "rk_gather_seals": (C.c_int, [_vp, C.POINTER(u32p), C.POINTER(_sz), _sz, _sz, C.POINTER(u32p), C.POINTER(_sz), C.POINTER(_sz)]),
+    "rk_gather_unpack": (C.c_int, [u32p, u32p, C.c_int, _sz, _sz, _sz, C.POINTER(u32p), C.POINTER(_sz), C.POINTER(_sz)]),
     "rk_session_set_kernel_timing": (C.c_int, [C.c_int, C.c_int]),
     "rk_session_kernel_stats": (C.c_int, [C.c_int, C.c_int, C.POINTER(RkKernelStat)]),
 }

@@ -111,3 +111,33 @@ def test_prover_run_sharded_over_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == ["ok", "ok"]
+
+
+def test_gather_unpack_restores_segment_order():
+    """rk_gather_unpack: the host half of the C-level seal gather (rk_gather_seals = two ncclAllGather calls + this):
+    simulated ranks' padded payloads come back in segment order, for totals that do and do not divide by the world size"""
+    import ctypes as C
+    from raiko_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    for world, n_total in ((1, 3), (2, 5), (4, 4), (8, 13), (3, 1)):
+        seals = [rng.integers(0, 2**32, size=int(rng.integers(1, 50)), dtype=np.uint32) for _ in range(n_total)]
+        per_rank = (n_total + world - 1) // world
+        max_len = max(s.size for s in seals)
+        lens = np.zeros((world, per_rank), dtype=np.uint32)
+        pay = np.zeros((world, per_rank, max_len), dtype=np.uint32)
+        for i, s in enumerate(seals):
+            lens[i % world, i // world] = s.size
+            pay[i % world, i // world, : s.size] = s
+        outs = [np.zeros(max_len, dtype=np.uint32) for _ in range(n_total)]
+        ptrs = (_lib.u32p * n_total)(*[o.ctypes.data_as(_lib.u32p) for o in outs])
+        caps = (C.c_size_t * n_total)(*[max_len] * n_total)
+        words = (C.c_size_t * n_total)()
+        assert lib.rk_gather_unpack(lens.ctypes.data_as(_lib.u32p), pay.ctypes.data_as(_lib.u32p), world, per_rank, max_len, n_total,
+                                    ptrs, caps, words) == 0
+        for i, s in enumerate(seals):
+            assert words[i] == s.size and np.array_equal(outs[i][: s.size], s)
+        caps[0] = 0                                                    # one buffer too small: reported, the others delivered
+        assert lib.rk_gather_unpack(lens.ctypes.data_as(_lib.u32p), pay.ctypes.data_as(_lib.u32p), world, per_rank, max_len, n_total,
+                                    ptrs, caps, words) == -5
+    assert lib.rk_gather_unpack(None, None, 1, 1, 0, 1, None, None, None) == -1

@@ -66,3 +66,41 @@ def test_gather_seals_over_rccl_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl-gather-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+_RK_COMM_ONE_RANK = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from raiko_amd import _lib
+lib = _lib.load()
+uid = C.create_string_buffer(128)
+assert lib.rk_comm_unique_id(uid) == 0
+comm = C.c_void_p()
+assert lib.rk_comm_create(uid, 0, 1, 0, C.byref(comm)) == 0
+rng = np.random.default_rng(5)
+local = [rng.integers(0, 2**32, size=n, dtype=np.uint32) for n in (7, 260000, 1, 33)]
+n = len(local)
+lp = (_lib.u32p * n)(*[a.ctypes.data_as(_lib.u32p) for a in local])
+lw = (C.c_size_t * n)(*[a.size for a in local])
+outs = [np.zeros(a.size, dtype=np.uint32) for a in local]
+op = (_lib.u32p * n)(*[a.ctypes.data_as(_lib.u32p) for a in outs])
+oc = (C.c_size_t * n)(*[a.size for a in outs])
+ow = (C.c_size_t * n)()
+st = lib.rk_gather_seals(comm, lp, lw, n, n, op, oc, ow)
+assert st == 0, (st, lib.rk_comm_last_error(comm))
+for a, b, w in zip(outs, local, ow):
+    assert w == b.size and np.array_equal(a, b)
+assert lib.rk_gather_seals(comm, lp, lw, n - 1, n, op, oc, ow) == -1      # not this rank's share of n segments
+assert lib.rk_comm_destroy(comm) == 0
+print("rk-comm-gather-ok")
+"""
+
+
+def test_rk_gather_seals_single_rank():
+    """the C-level seal gather (rk_comm_* / rk_gather_seals: RCCL looked up at run time, two ncclAllGather calls) with a
+    one-rank communicator -- what a one-GPU box can run; the unpacking for N ranks is tests/test_dist.py"""
+    code = _RK_COMM_ONE_RANK % {"root": ROOT}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rk-comm-gather-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
