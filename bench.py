@@ -53,11 +53,12 @@ def parse_args():
                          "chip-shaped synthetic AIR under SP1's parameter set); its line has its own metric")
     ap.add_argument("--p3-shape", default="20x256,19x128,16x64,10x32", help="--preset sp1-p3: log2 rows x columns per table")
     ap.add_argument("--p3-jit", action="store_true", help="--preset sp1-p3: quotient through the hiprtc-generated kernel")
-    ap.add_argument("--circuit", type=str, default="",
+    ap.add_argument("--circuit", type=str, default="8000",
                     help="comma-separated op counts, e.g. 8000,33000: for each, the same S20 session again with the circuit's "
                          "two stages inside the timed region -- eval_check from a synthetic step list of that many ops over "
                          "the 256 columns (rk_program, compiled with hiprtc), the check group computed inside the proof; "
-                         "reported as `with_circuit`, never as `value` (the rv32im list itself is outside the tree)")
+                         "reported as `with_circuit`, never as `value` (the rv32im list itself is outside the tree); "
+                         "default 8000 (5 s of hiprtc), '' to skip, 33000 costs ~30 s of compilation")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (value_with_h2d) run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-small", action="store_true",

@@ -130,8 +130,7 @@ int hash_level(rk_ctx* ctx, const rk_matrix* mats, uint32_t n, uint32_t h, uint3
     std::memcpy(pack.data() + desc_bytes, cols.data(), col_bytes);
     void* d = nullptr;
     RK_TRY(rk::scratch(ctx, pack.size(), &d));
-    RK_HIP_TRY(ctx, hipMemcpyAsync(d, pack.data(), pack.size(), hipMemcpyHostToDevice, ctx->stream));
-    RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `pack` is a stack-lifetime host buffer
+    RK_TRY(rk::upload(ctx, d, pack.data(), pack.size()));  // through the page-locked ring: no wait (21 FRI layers of a proof commit one after the other)
     const unsigned blocks = (unsigned)(((size_t)h + HASH_BLOCK - 1) / HASH_BLOCK);
     rk::KTimer kt(ctx, RK_KCLASS_HASH_ROWS, (double)h * cols.size() * 4 + (double)h * 32);
     RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_rows_multi_kernel<C>, dim3(blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_out,

@@ -679,8 +679,7 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
         }
     }
     const size_t qrow = 4 * qh.size();
-    for (uint32_t qi = 0; qi < sys.queries; qi++) {
-        const uint32_t index = ch.sample_bits(log_max);
+    auto check_query = [&](uint32_t index, Reader r) -> int {
         // every table is in both batches: both trees have the global maximum height
         const uint32_t* trows = r.take(trow);
         const uint32_t* tpath = r.take(8 * (size_t)log_max);
@@ -737,8 +736,47 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
             folded = bb::add(e0, bb::mul(bb::sub(betas[rd], bb::ext_from(x0)), slope, wm));
         }
         if (!bb::eq(folded, final_poly)) return 7;
+        return 0;
+    };
+    // the query positions come from the transcript one after the other; the queries themselves are independent and of
+    // one size, so they are checked on a few threads (100 queries cost ~40 ms of Poseidon2 on one core)
+    size_t per_query = trow + qrow + 16 * (size_t)log_max;
+    for (uint32_t rd = 0; rd < n_rounds; rd++) per_query += 4 + 8 * (size_t)(log_max - 1 - rd);
+    const size_t q0 = r.pos;
+    if (q0 + per_query * sys.queries != words) return 1;   // short or trailing words
+    std::vector<uint32_t> indices(sys.queries);
+    for (uint32_t qi = 0; qi < sys.queries; qi++) indices[qi] = ch.sample_bits(log_max);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = sys.queries >= 16 ? std::max(1u, std::min(4u, hw / 2)) : 1u;
+    std::vector<int> first_bad(n_thr, 0);
+    std::vector<uint32_t> first_at(n_thr, 0xffffffffu);
+    auto run = [&](unsigned t) {
+        for (uint32_t qi = t; qi < sys.queries; qi += n_thr) {
+            Reader rq{proof, words};
+            rq.pos = q0 + per_query * qi;
+            const int rc = check_query(indices[qi], rq);
+            if (rc != 0) {
+                first_bad[t] = rc;
+                first_at[t] = qi;
+                return;
+            }
+        }
+    };
+    if (n_thr == 1) {
+        run(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_thr; t++) pool.emplace_back(run, t);
+        for (auto& th_ : pool) th_.join();
     }
-    return r.pos == r.n ? 0 : 1;
+    uint32_t best = 0xffffffffu;
+    int rc = 0;
+    for (unsigned t = 0; t < n_thr; t++)   // the verdict of the first failing query, as a sequential check would give it
+        if (first_at[t] < best) {
+            best = first_at[t];
+            rc = first_bad[t];
+        }
+    return rc;
 }
 
 // ---------------------------------------------------------------- shards in flight (rk_p3_prove_shards)

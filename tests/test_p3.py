@@ -142,3 +142,26 @@ def test_quotient_degree_above_the_blowup_is_refused(params):
     with pytest.raises(RuntimeError):
         o.oracle_p3_prove([t])
     assert p3.verify([t], np.zeros(100, dtype=np.uint32)) == -1
+
+
+def test_full_parameter_set_verifier_threads_agree_with_the_oracle(params):
+    """100 queries: rk_p3_verify checks them on several threads and reports the verdict of the FIRST failing query, the
+    one a sequential verifier (the oracle's) gives"""
+    case = "sp1_fib_k10_full"
+    preset, over, _, _ = P3_CASES[case]
+    params(preset, **over)
+    blob = hal.make_params(preset, **over)
+    tables, init = tables_of(case), init_of(case)
+    pf = o.oracle_p3_prove(tables, init)
+    rng = np.random.default_rng(8)
+    seen = set()
+    for k in range(80):
+        s = pf.copy()
+        for _ in range(1 + k % 3):                      # one to three changed words: several queries may fail at once
+            i = int(rng.integers(0, s.size))
+            s[i] = (int(s[i]) + 1 + int(rng.integers(0, 5))) % P
+        got, want = p3.verify(tables, s, init, params=blob), o.oracle_p3_verify(tables, s, init)
+        assert got == want != 0, (k, got, want)
+        seen.add(got)
+    assert len(seen) >= 2
+    assert p3.verify(tables, pf[:-3], init, params=blob) == 1 == o.oracle_p3_verify(tables, pf[:-3], init)
