@@ -16,6 +16,13 @@ P3_CASES = {
     "risc0_mixed_cubic5_fib7": (0, dict(queries=7, pow_bits=5), [("cubic", 5, 4), ("fib", 7, None)], [9]),
     "risc0_fib_k1": (0, dict(queries=3), [("fib", 1, None)], []),
     "sp1_blow2_wide_k9": (1, dict(queries=5, pow_bits=3, blowup_log2=2), [("wide", 9, 20)], [11, 12]),
+    # many small tables of mixed heights (a shard with a dozen chips), tables of equal height, a 2-row table beside a tall
+    # one, a width that is no multiple of any tile (301 columns), an AIR without constraints
+    "sp1_twelve_tables": (1, dict(queries=4, pow_bits=3), [("fib", 1 + i % 6, None) if i % 2 else ("cubic", 2 + i % 5, 4 + i % 3) for i in range(12)], [1]),
+    "sp1_same_height": (1, dict(queries=5, pow_bits=2), [("cubic", 6, 5), ("fib", 6, None), ("wide", 6, 9)], []),
+    "sp1_tiny_beside_tall": (1, dict(queries=5, pow_bits=2), [("fib", 1, None), ("wide", 11, 7)], [2, 3]),
+    "sp1_width_301": (1, dict(queries=3, pow_bits=2), [("wide", 6, 301)], []),
+    "risc0_empty_air": (0, dict(queries=4), [("empty", 4, 3), ("fib", 5, None)], [8]),
 }
 
 _AIRS = {}
@@ -24,7 +31,12 @@ _AIRS = {}
 def air_of(name, arg):
     key = (name, arg)
     if key not in _AIRS:
-        _AIRS[key] = p3.fibonacci_air() if name == "fib" else p3.cubic_air(arg) if name == "cubic" else p3.wide_air(arg)
+        if name == "empty":      # `width` columns, nothing asserted: a valid AIR whose quotient is zero
+            b = p3.AirBuilder(arg)
+            b.local(0)
+            _AIRS[key] = b.build()
+        else:
+            _AIRS[key] = p3.fibonacci_air() if name == "fib" else p3.cubic_air(arg) if name == "cubic" else p3.wide_air(arg)
     return _AIRS[key]
 
 
@@ -37,6 +49,8 @@ def tables_of(case):
             tr, pv = p3.fibonacci_trace(k, 1 + i, 2)
         elif name == "cubic":
             tr, pv = p3.cubic_trace(k, arg, seed=10 + i)
+        elif name == "empty":
+            tr, pv = np.random.default_rng(30 + i).integers(0, p3.P, size=(1 << k, arg)), []
         else:
             tr, pv = p3.wide_trace(air, k, seed=20 + i)
         out.append(p3.Table.from_canonical(air, tr, pv))

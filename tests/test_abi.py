@@ -106,6 +106,9 @@ def test_plain_c_caller_compiles_against_the_header(tmp_path):
     exe3 = _build_demo(tmp_path, "pcs_demo")
     r = subprocess.run([exe3], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no usable GPU" in r.stderr
+    exe4 = _build_demo(tmp_path, "p3_demo")          # the AIR front end is host code: it runs before the GPU is looked for
+    r = subprocess.run([exe4], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no usable GPU" in r.stderr and "5 constraints, degree 2, 1 quotient chunk(s)" in r.stdout
 
 
 @pytest.mark.gpu
@@ -145,3 +148,16 @@ def test_plain_c_caller_runs_the_pcs_steps(tmp_path):
         r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout, r.stderr)
         assert "constant" in r.stdout and "NOT constant" not in r.stdout and "grind(12 bits) -> witness" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_proves_an_air(tmp_path):
+    """examples/p3_demo.c: the Fibonacci AIR as a step list through rk_air_create / rk_p3_prove / rk_p3_verify from C under
+    SP1's parameter set; a wrong public value fails the constraint identity, a changed proof word the openings"""
+    import subprocess
+    exe = _build_demo(tmp_path, "p3_demo")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "raiko_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for k in ("3", "12", "17"):
+        r = subprocess.run([exe, k], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "verifier: 0" in r.stdout and "wrong public value: verifier 3" in r.stdout and "fibonacci proven and verified" in r.stdout
