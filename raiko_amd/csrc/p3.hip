@@ -237,7 +237,8 @@ struct TableState {
     size_t n = 0, H = 0, w = 0;
     DevBuf lde;                   // H x w row-major, bit-reversed rows (committed)
     DevBuf cols;                  // w columns of H natural-order evaluations (until the quotient is done)
-    std::vector<DevBuf> chunk;    // qd matrices H x 4
+    DevBuf chunks;                // H x (4 qd) row-major: the qd chunk LDEs side by side (as one matrix they hash, open and
+                                  // reduce exactly like qd matrices of width 4 that follow each other in the batch)
     std::vector<uint32_t> y;      // opened values: local 4w | next 4w | chunks 16 each
 };
 
@@ -405,12 +406,9 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         }
         RK_TRY(qb.alloc(ctx, n_qcols * s.H * 4));
         RK_TRY(rk::ntt_forward(ctx, qb.u32(), q.u32(), s.n, n_qcols, blow));
-        s.chunk.resize(qd);
-        for (size_t j = 0; j < qd; j++) {
-            RK_TRY(s.chunk[j].alloc(ctx, s.H * 4 * 4));
-            RK_TRY(rk::pcs_cols_to_rows_bitrev(ctx, s.chunk[j].u32(), qb.u32() + 4 * j * s.H, s.H, 4));
-            qmats.push_back(rk_matrix{s.chunk[j].u32(), (uint32_t)s.H, 4, 1});
-        }
+        RK_TRY(s.chunks.alloc(ctx, s.H * n_qcols * 4));
+        RK_TRY(rk::pcs_cols_to_rows_bitrev(ctx, s.chunks.u32(), qb.u32(), s.H, n_qcols));
+        qmats.push_back(rk_matrix{s.chunks.u32(), (uint32_t)s.H, (uint32_t)n_qcols, 1});
         Hq = std::max(Hq, s.H);
     }
     lap(tm.quotient);
@@ -429,7 +427,7 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     DevBuf d_ys;
     {
         size_t wmax = 4;
-        for (const TableState& s : ts) wmax = std::max(wmax, s.w);
+        for (const TableState& s : ts) wmax = std::max(wmax, std::max(s.w, (size_t)4 << s.lqd));
         RK_TRY(d_ys.alloc(ctx, 2 * wmax * 16));
     }
     for (uint32_t t = 0; t < n_tables; t++) {  // round 0: every trace at zeta and zeta * g
@@ -452,13 +450,12 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     for (uint32_t t = 0; t < n_tables; t++) {  // round 1: every quotient chunk at zeta
         TableState& s = ts[t];
         const unsigned lh = s.k + blow;
-        for (size_t j = 0; j < s.chunk.size(); j++) {
-            uint32_t* y = s.y.data() + 8 * s.w + 16 * j;
-            RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunk[j].u32(), s.H, 4, zeta.c, 1));
-            RK_TRY(d2h(ctx, y, d_ys.p, 64));
-            RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunk[j].u32(), s.H, 4, 1, zeta.c, y, alpha2, num_reduced[lh]));
-            num_reduced[lh] += 4;
-        }
+        const size_t wq = (size_t)4 << s.lqd;
+        uint32_t* y = s.y.data() + 8 * s.w;
+        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunks.u32(), s.H, wq, zeta.c, 1));
+        RK_TRY(d2h(ctx, y, d_ys.p, wq * 16));
+        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunks.u32(), s.H, wq, 1, zeta.c, y, alpha2, num_reduced[lh]));
+        num_reduced[lh] += wq;
     }
     for (const TableState& s : ts) push(s.y.data(), s.y.size());
     lap(tm.open);
