@@ -171,7 +171,10 @@ typedef struct {
     const uint32_t* d_values;      /* device */
     uint32_t height;               /* power of two */
     uint32_t width;
-    uint32_t row_major;            /* 1: (r, c) at r * width + c; 0: at c * height + r */
+    uint32_t row_major;            /* 1: (r, c) at r * width + c; 0: at c * height + r; 2: at c * height + bitrev(r) -- a column-major
+                                    * matrix whose columns are in NATURAL order while the committed rows are the bit-reversed
+                                    * ones (Plonky3 commits `lde.bit_reverse_rows()`): the evaluations exactly as the NTT leaves
+                                    * them, no reordering pass */
 } rk_matrix;
 int rk_mmcs_commit(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, uint32_t* d_nodes, uint32_t h_root[8]);
 /* Mmcs::open_batch at leaf `index` of the tallest matrices: row (index >> log2(H / height)) of every

@@ -182,9 +182,12 @@ int program_poly_ext(const rk_program* prog, uint32_t wm, const uint32_t poly_mi
 int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t h, size_t w, uint32_t** keep_cols = nullptr);
 // column-major w columns of H words (natural order) -> row-major H x w with row bitrev(j) = index j
 int pcs_cols_to_rows_bitrev(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_cols, size_t H, size_t w);
-int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const uint32_t* h_points, size_t n_points);
+// cols: d_lde is column-major in natural order (rk_matrix layout 2) instead of row-major with bit-reversed rows
+int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const uint32_t* h_points, size_t n_points,
+                bool cols = false);
 int pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t H, size_t w, size_t n_points,
-                        const uint32_t* h_points, const uint32_t* h_ys, const bb::Ext& alpha, uint64_t alpha_offset);
+                        const uint32_t* h_points, const uint32_t* h_ys, const bb::Ext& alpha, uint64_t alpha_offset, bool cols = false);
+int pcs_coset_lde_cols(rk_ctx* ctx, uint32_t* d_cols, const uint32_t* d_in, size_t h, size_t w);
 int ext_sub_at(rk_ctx* ctx, uint32_t* d_ext, const uint32_t* h_idx, const bb::Ext* h_delta, size_t n);
 // p3.hip: the contexts rk_p3_prove_shards keeps per device (freed by rk_session_release)
 void p3_release_pools();

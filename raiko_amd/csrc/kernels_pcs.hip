@@ -64,14 +64,64 @@ struct BaryPoint {
     Ext z, scaling;  // the point; (z^h - s^h) / (h s^(h-1))
 };
 constexpr int BARY_MAX_POINTS = 4;
+// natural != 0: stored at index i instead (for column-major matrices kept in natural order)
 __global__ void bary_weights_kernel(uint32_t* __restrict__ wts, const BaryPoint* __restrict__ pts, size_t h, unsigned k, uint32_t shiftm,
-                                    uint32_t wm, ntt::Tables tb) {
+                                    uint32_t wm, ntt::Tables tb, int natural) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h) return;
     const uint32_t gi = ntt::root_pow(tb, 0, (uint32_t)(i << (ntt::LAMBDA - k)));
     Ext d = pts[blockIdx.y].z;
     d.c[0] = bb::sub(d.c[0], bb::mul(shiftm, gi));
-    store_ext(wts + ((size_t)blockIdx.y * h + bb::bitrev((uint32_t)i, k)) * 4, bb::scale(bb::inv(d, wm), gi));
+    store_ext(wts + ((size_t)blockIdx.y * h + (natural ? i : bb::bitrev((uint32_t)i, k))) * 4, bb::scale(bb::inv(d, wm), gi));
+}
+// The same sums for a COLUMN-major matrix in natural order (w columns of H words; the low coset is every 2^blow-th
+// element): lanes along i, every lane carries BC columns of its i's so that a weight is loaded once per BC matrix words;
+// partial[chunk][p][c] as above.
+constexpr int BC = 8, BARYC_THREADS = 256;
+template <int NP>
+__global__ __launch_bounds__(BARYC_THREADS) void bary_dot_cols_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ wts,
+                                                                      const uint32_t* __restrict__ M, size_t h, size_t H, size_t w, unsigned blow,
+                                                                      size_t rows_per_chunk) {
+    __shared__ uint32_t red[BARYC_THREADS / 64][NP * BC * 4];
+    const size_t i_begin = (size_t)blockIdx.x * rows_per_chunk, i_end = i_begin + rows_per_chunk < h ? i_begin + rows_per_chunk : h;
+    const size_t c0 = (size_t)blockIdx.y * BC;
+    Ext acc[NP][BC];
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int cc = 0; cc < BC; cc++) acc[q][cc] = bb::ext_zero();
+    for (size_t i = i_begin + threadIdx.x; i < i_end; i += BARYC_THREADS) {
+        Ext wq[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) wq[q] = load_ext(wts + ((size_t)q * h + i) * 4);
+#pragma unroll
+        for (int cc = 0; cc < BC; cc++) {
+            if (c0 + cc >= w) break;
+            const uint32_t m = M[(c0 + cc) * H + (i << blow)];
+#pragma unroll
+            for (int q = 0; q < NP; q++) acc[q][cc] = bb::add(acc[q][cc], bb::scale(wq[q], m));
+        }
+    }
+    // the wave's sum by butterfly shuffles, then the block's through LDS
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int cc = 0; cc < BC; cc++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t v = acc[q][cc].c[e];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v = bb::add(v, (uint32_t)__shfl_xor((int)v, off, 64));
+                if (lane == 0) red[wave][(q * BC + cc) * 4 + e] = v;
+            }
+    __syncthreads();
+    if (threadIdx.x < NP * BC * 4) {
+        uint32_t v = red[0][threadIdx.x];
+        for (unsigned wv = 1; wv < BARYC_THREADS / 64; wv++) v = bb::add(v, red[wv][threadIdx.x]);
+        const unsigned q = threadIdx.x / (BC * 4), cc = (threadIdx.x / 4) % BC, e = threadIdx.x & 3;
+        if (c0 + cc < w) partial[(((size_t)blockIdx.x * NP + q) * w + c0 + cc) * 4 + e] = v;
+    }
 }
 // partial[chunk][p][c] = sum over the chunk's rows of wts[p][r] * M[r][c]: lanes along the row (coalesced), the rows of
 // a chunk split over the blockDim.y sub-rows, combined through LDS; the matrix is read once for all NP points
@@ -189,6 +239,39 @@ __global__ __launch_bounds__(RO_ROWS) void reduce_openings_kernel(uint32_t* __re
     store_ext(ro + r * 4, out);
 }
 
+// "reduce rows" for a COLUMN-major matrix in natural order: lane = natural index j, the row's dot product with the powers
+// of alpha built from coalesced column loads (the powers come through the scalar cache: the column index is uniform),
+// the result added to ro at the committed row bitrev(j)
+__global__ __launch_bounds__(256) void reduce_openings_cols_kernel(uint32_t* __restrict__ ro, const uint32_t* __restrict__ M, size_t H, size_t w,
+                                                                   unsigned bits, uint64_t apow_addr, const PcsPoint* __restrict__ pts,
+                                                                   unsigned n_points, uint32_t shiftm, uint32_t wm, ntt::Tables tb) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint32_t* const_u32;
+#else
+    typedef const uint32_t* const_u32;
+#endif
+    const const_u32 apow = (const_u32)apow_addr;
+    Ext acc = bb::ext_zero();
+    for (size_t c = 0; c < w; c++) {
+        const uint32_t m = M[c * H + j];
+        acc.c[0] = bb::add(acc.c[0], bb::mul(apow[4 * c + 0], m));
+        acc.c[1] = bb::add(acc.c[1], bb::mul(apow[4 * c + 1], m));
+        acc.c[2] = bb::add(acc.c[2], bb::mul(apow[4 * c + 2], m));
+        acc.c[3] = bb::add(acc.c[3], bb::mul(apow[4 * c + 3], m));
+    }
+    const uint32_t x = bb::mul(shiftm, ntt::root_pow(tb, 0, (uint32_t)j << (ntt::LAMBDA - bits)));
+    uint32_t* dst = ro + (size_t)bb::bitrev((uint32_t)j, bits) * 4;
+    Ext out = load_ext(dst);
+    for (unsigned q = 0; q < n_points; q++) {
+        const PcsPoint p = pts[q];
+        const Ext den = Ext{{bb::sub(x, p.z.c[0]), bb::neg(p.z.c[1]), bb::neg(p.z.c[2]), bb::neg(p.z.c[3])}};
+        out = bb::add(out, bb::mul(p.coef, bb::mul(bb::sub(acc, p.rys), bb::inv(den, wm), wm), wm));
+    }
+    store_ext(dst, out);
+}
+
 }  // namespace
 
 namespace rk {
@@ -225,7 +308,28 @@ int pcs_coset_lde_rows(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_
     return st;
 }
 
-int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const uint32_t* h_points, size_t n_points) {
+// the coset LDE of a row-major h x w matrix as `w` columns of H = h << blow-up evaluations in natural order (what the
+// two NTTs leave; rk_matrix layout 2 commits it as it is)
+int pcs_coset_lde_cols(rk_ctx* ctx, uint32_t* d_cols, const uint32_t* d_in, size_t h, size_t w) {
+    const unsigned blow = ctx->sys.blowup_log2;
+    if (!is_pow2(h) || h < 2 || w == 0 || log2u(h) + blow > 24) return RK_ERR_INVALID;
+    void* a = nullptr;
+    RK_TRY(dev_alloc(ctx, h * w * 4, &a));
+    int st;
+    {
+        KTimer kt(ctx, RK_KCLASS_BIT_REVERSE, (double)h * w * 8);
+        hipLaunchKernelGGL(rows_to_cols_kernel, dim3((unsigned)((h + TT - 1) / TT), (unsigned)((w + TT - 1) / TT)), dim3(TT, 8), 0,
+                           ctx->stream, (uint32_t*)a, d_in, h, w);
+        st = post_launch(ctx, "rows_to_cols_kernel");
+    }
+    if (st == RK_OK) st = ntt_reverse(ctx, (uint32_t*)a, h, w, /*fuse_zk_shift=*/true);
+    if (st == RK_OK) st = ntt_forward(ctx, d_cols, (const uint32_t*)a, h, w, blow);
+    dev_free(ctx, a);
+    return st;
+}
+
+int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t H, size_t w, const uint32_t* h_points, size_t n_points,
+                bool cols) {
     const unsigned blow = ctx->sys.blowup_log2;
     if (!is_pow2(H) || (H >> blow) < 1 || w == 0 || log2u(H) > 24 || n_points == 0 || n_points > BARY_MAX_POINTS) return RK_ERR_INVALID;
     const size_t h = H >> blow;
@@ -240,7 +344,8 @@ int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t 
         zer.c[0] = bb::sub(zer.c[0], bb::pow(s, (uint64_t)h));
         pts[q].scaling = bb::scale(zer, denom_inv);
     }
-    const size_t rows_per_chunk = std::max<size_t>(BARY_Y * 16, (h + 1023) / 1024), chunks = (h + rows_per_chunk - 1) / rows_per_chunk;
+    const size_t rows_per_chunk = cols ? std::max<size_t>(BARYC_THREADS, (h + 63) / 64) : std::max<size_t>(BARY_Y * 16, (h + 1023) / 1024);
+    const size_t chunks = (h + rows_per_chunk - 1) / rows_per_chunk;
     void* buf = nullptr;
     RK_TRY(dev_alloc(ctx, n_points * h * 16 + chunks * n_points * w * 16 + sizeof pts, &buf));
     uint32_t* wts = (uint32_t*)buf;
@@ -250,9 +355,18 @@ int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t 
     if (st == RK_OK) {
         KTimer kt(ctx, RK_KCLASS_POLY, (double)h * w * 4 + (double)h * 32 * n_points);
         hipLaunchKernelGGL(bary_weights_kernel, dim3((unsigned)((h + TPB - 1) / TPB), (unsigned)n_points), dim3(TPB), 0, ctx->stream, wts,
-                           (const BaryPoint*)d_pts, h, k, s, wm, ctx->tb);
+                           (const BaryPoint*)d_pts, h, k, s, wm, ctx->tb, cols ? 1 : 0);
         st = post_launch(ctx, "bary_weights_kernel");
-        if (st == RK_OK) {
+        if (st == RK_OK && cols) {
+            const dim3 grid((unsigned)chunks, (unsigned)((w + BC - 1) / BC)), block(BARYC_THREADS);
+            switch (n_points) {
+                case 1: hipLaunchKernelGGL(bary_dot_cols_kernel<1>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, H, w, blow, rows_per_chunk); break;
+                case 2: hipLaunchKernelGGL(bary_dot_cols_kernel<2>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, H, w, blow, rows_per_chunk); break;
+                case 3: hipLaunchKernelGGL(bary_dot_cols_kernel<3>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, H, w, blow, rows_per_chunk); break;
+                default: hipLaunchKernelGGL(bary_dot_cols_kernel<4>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, H, w, blow, rows_per_chunk); break;
+            }
+            st = post_launch(ctx, "bary_dot_cols_kernel");
+        } else if (st == RK_OK) {
             const dim3 grid((unsigned)chunks), block(BARY_X, BARY_Y);
             switch (n_points) {
                 case 1: hipLaunchKernelGGL(bary_dot_kernel<1>, grid, block, 0, ctx->stream, partial, (const uint32_t*)wts, d_lde, h, w, rows_per_chunk); break;
@@ -273,7 +387,7 @@ int pcs_eval_at(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde, size_t 
 }
 
 int pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t H, size_t w, size_t n_points,
-                        const uint32_t* h_points, const uint32_t* h_ys, const bb::Ext& alpha, uint64_t alpha_offset) {
+                        const uint32_t* h_points, const uint32_t* h_ys, const bb::Ext& alpha, uint64_t alpha_offset, bool cols) {
     if (!is_pow2(H) || w == 0 || log2u(H) > 24 || n_points == 0 || n_points > PCS_MAX_POINTS) return RK_ERR_INVALID;
     const uint32_t wm = ctx->sys.wm;
     std::vector<uint32_t> pack(w * 4 + n_points * (sizeof(PcsPoint) / 4));
@@ -301,6 +415,11 @@ int pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, 
     const uint32_t* dp = (const uint32_t*)d;
     const size_t blocks = (H + RO_ROWS - 1) / RO_ROWS;
     KTimer kt(ctx, RK_KCLASS_POLY, (double)H * w * 4 + (double)H * 32);
+    if (cols) {
+        hipLaunchKernelGGL(reduce_openings_cols_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, ctx->stream, d_ro_ext, d_lde, H, w, log2u(H),
+                           (uint64_t)(uintptr_t)dp, (const PcsPoint*)(dp + w * 4), (unsigned)n_points, ctx->sys.shiftm, wm, ctx->tb);
+        return post_launch(ctx, "reduce_openings_cols_kernel");
+    }
     hipLaunchKernelGGL(reduce_openings_kernel, dim3((unsigned)blocks), dim3(RO_ROWS), 0, ctx->stream, d_ro_ext, d_lde, H, w, log2u(H), dp,
                        (const PcsPoint*)(dp + w * 4), (unsigned)n_points, ctx->sys.shiftm, wm, ctx->tb);
     return post_launch(ctx, "reduce_openings_kernel");

@@ -36,12 +36,17 @@ struct ColRef {
 #define RK_CONST_AS
 #endif
 
+// nat_bits != 0: lane t is the NATURAL index of a layout-2 matrix (column-major, committed row r stored at index
+// bitrev(r)): its loads are then coalesced and the digest goes to row bitrev(t); otherwise lane t is the committed row
 template <class C>
 __global__ __launch_bounds__(HASH_BLOCK) void hash_rows_multi_kernel(uint32_t* __restrict__ out, uint64_t mats_addr, uint64_t cols_addr,
                                                                      uint32_t n_cols, size_t rows,
-                                                                     const typename C::Consts* __restrict__ kc, int pad_free) {
-    const size_t row = (size_t)blockIdx.x * HASH_BLOCK + threadIdx.x;
-    if (row >= rows) return;
+                                                                     const typename C::Consts* __restrict__ kc, int pad_free, unsigned nat_bits,
+                                                                     unsigned bits) {
+    const size_t t = (size_t)blockIdx.x * HASH_BLOCK + threadIdx.x;
+    if (t >= rows) return;
+    const size_t other = bb::bitrev((uint32_t)t, bits);           // bits = log2 rows
+    const size_t row = nat_bits ? other : t, nat = nat_bits ? t : other;
     const RK_CONST_AS MatDesc* mats = (const RK_CONST_AS MatDesc*)mats_addr;
     const RK_CONST_AS ColRef* cols = (const RK_CONST_AS ColRef*)cols_addr;
     const typename C::Consts& k = *kc;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(HASH_BLOCK) void hash_rows_multi_kernel(uint32_t* _
     auto load = [&](uint32_t g) -> uint32_t {
         const ColRef cr = {cols[g].mat, cols[g].col};
         const MatDesc m = {mats[cr.mat].base, mats[cr.mat].width, mats[cr.mat].row_major};
-        return m.row_major ? m.base[row * m.width + cr.col] : m.base[(size_t)cr.col * rows + row];
+        return m.row_major == 1 ? m.base[row * m.width + cr.col] : m.base[(size_t)cr.col * rows + (m.row_major == 2 ? nat : row)];
     };
     const uint32_t full = n_cols / C::RATE;
     for (uint32_t b = 0; b < full; b++) {
@@ -107,7 +112,7 @@ int check_mats(const rk_matrix* mats, uint32_t n, uint32_t* max_h) {
     uint32_t H = 0;
     for (uint32_t m = 0; m < n; m++) {
         if (!mats[m].d_values || mats[m].height == 0 || (mats[m].height & (mats[m].height - 1)) || mats[m].width == 0 ||
-            mats[m].row_major > 1 || mats[m].height > (1u << ntt::LAMBDA))
+            mats[m].row_major > 2 || mats[m].height > (1u << ntt::LAMBDA))
             return RK_ERR_INVALID;
         H = std::max(H, mats[m].height);
     }
@@ -119,8 +124,10 @@ int check_mats(const rk_matrix* mats, uint32_t n, uint32_t* max_h) {
 int hash_level(rk_ctx* ctx, const rk_matrix* mats, uint32_t n, uint32_t h, uint32_t* d_out) {
     std::vector<MatDesc> descs;
     std::vector<ColRef> cols;
+    bool all_nat = true;   // every matrix of this level is layout 2: lanes walk the natural index (coalesced loads)
     for (uint32_t m = 0; m < n; m++) {
         if (mats[m].height != h) continue;
+        all_nat = all_nat && mats[m].row_major == 2;
         for (uint32_t c = 0; c < mats[m].width; c++) cols.push_back(ColRef{(uint32_t)descs.size(), c});
         descs.push_back(MatDesc{mats[m].d_values, mats[m].width, mats[m].row_major});
     }
@@ -136,7 +143,7 @@ int hash_level(rk_ctx* ctx, const rk_matrix* mats, uint32_t n, uint32_t h, uint3
     RK_P2_DISPATCH(ctx, hipLaunchKernelGGL(hash_rows_multi_kernel<C>, dim3(blocks), dim3(HASH_BLOCK), 0, ctx->stream, d_out,
                                            (uint64_t)(uintptr_t)d, (uint64_t)(uintptr_t)((unsigned char*)d + desc_bytes),
                                            (uint32_t)cols.size(), (size_t)h, (const typename C::Consts*)ctx->d_p2,
-                                           ctx->h_p2.pad_free ? 1 : 0));
+                                           ctx->h_p2.pad_free ? 1 : 0, all_nat ? 1u : 0u, log2u(h)));
     return rk::post_launch(ctx, "hash_rows_multi_kernel");
 }
 
@@ -199,11 +206,12 @@ int rk_mmcs_open(rk_ctx* ctx, const rk_matrix* mats, uint32_t n_mats, const uint
     for (uint32_t m = 0; m < n_mats; m++) {
         const rk_matrix& M = mats[m];
         const uint32_t r = index / (H / M.height);
-        if (M.row_major) {
+        if (M.row_major == 1) {
             RK_HIP_TRY(ctx, hipMemcpyAsync(h_rows + pos, M.d_values + (size_t)r * M.width, (size_t)M.width * 4, hipMemcpyDeviceToHost,
                                            ctx->stream));
         } else {
-            RK_HIP_TRY(ctx, hipMemcpy2DAsync(h_rows + pos, 4, M.d_values + r, (size_t)M.height * 4, 4, M.width, hipMemcpyDeviceToHost,
+            const uint32_t at = M.row_major == 2 ? bb::bitrev(r, log2u(M.height)) : r;
+            RK_HIP_TRY(ctx, hipMemcpy2DAsync(h_rows + pos, 4, M.d_values + at, (size_t)M.height * 4, 4, M.width, hipMemcpyDeviceToHost,
                                              ctx->stream));
         }
         pos += M.width;

@@ -7,8 +7,12 @@
 // and its recursion VM are NOT here.
 //
 // Device side of one proof:
-//   trace LDE      rows -> columns, iNTT (coset shift fused), expanding NTT, columns -> bit-reversed rows
-//                  (kernels_pcs.hip); the column-major evaluations are kept until the quotient is done
+//   trace LDE      rows -> columns, iNTT (coset shift fused), expanding NTT (kernels_pcs.hip): the LDE stays the way the
+//                  NTT leaves it -- column-major, natural order -- and is committed as rk_matrix layout 2 (committed row r =
+//                  natural index bitrev(r)): the hashing, the opened values, the reduced openings and the quotient all walk
+//                  the natural index with coalesced column loads and only WRITE at bit-reversed positions, so no pass over
+//                  the data exists just to reorder it (the round-2 operator form, rk_pcs_coset_lde_rows, spends 30 % of
+//                  its time transposing back to rows)
 //   commitments    rk_mmcs_commit (mmcs.hip)
 //   quotient       the AIR is translated once into an rk_program (circuit_program.hip): LOCAL / NEXT are taps of the
 //                  column-major LDE (NEXT = one trace row ahead, cyclic), the three selectors are taps of three
@@ -194,6 +198,7 @@ __global__ void add_words_kernel(uint32_t* __restrict__ io, const uint32_t* __re
 // 64-lane group per job
 struct GatherJob {
     uint64_t src;
+    uint64_t stride;     // in words: 1 for a digest or a row of a row-major matrix, the column length for a row of a column-major one
     uint32_t words, dst;
 };
 __global__ void gather_jobs_kernel(uint32_t* __restrict__ dst, const GatherJob* __restrict__ jobs, size_t n_jobs) {
@@ -201,7 +206,7 @@ __global__ void gather_jobs_kernel(uint32_t* __restrict__ dst, const GatherJob* 
     if (j >= n_jobs) return;
     const GatherJob jb = jobs[j];
     const uint32_t* s = reinterpret_cast<const uint32_t*>(jb.src);
-    for (uint32_t w = threadIdx.x & 63; w < jb.words; w += 64) dst[jb.dst + w] = s[w];
+    for (uint32_t w = threadIdx.x & 63; w < jb.words; w += 64) dst[jb.dst + w] = s[(size_t)w * jb.stride];
 }
 
 // ---------------------------------------------------------------- prover state
@@ -235,9 +240,8 @@ struct DevBuf {  // dev_alloc'd block released with the scope
 struct TableState {
     unsigned k = 0, lqd = 0;      // log2 rows, log2 quotient degree
     size_t n = 0, H = 0, w = 0;
-    DevBuf lde;                   // H x w row-major, bit-reversed rows (committed)
-    DevBuf cols;                  // w columns of H natural-order evaluations (until the quotient is done)
-    DevBuf chunks;                // H x (4 qd) row-major: the qd chunk LDEs side by side (as one matrix they hash, open and
+    DevBuf lde;                   // w columns of H natural-order evaluations (rk_matrix layout 2: committed row r at index bitrev(r))
+    DevBuf chunks;                // 4 qd columns of H: the qd chunk LDEs side by side (as one matrix they hash, open and
                                   // reduce exactly like qd matrices of width 4 that follow each other in the batch)
     std::vector<uint32_t> y;      // opened values: local 4w | next 4w | chunks 16 each
 };
@@ -334,12 +338,9 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
             d_trace = staged.u32();
         }
         RK_TRY(s.lde.alloc(ctx, s.H * s.w * 4));
-        uint32_t* cols = nullptr;
-        RK_TRY(rk::pcs_coset_lde_rows(ctx, s.lde.u32(), d_trace, s.n, s.w, &cols));
-        s.cols.ctx = ctx;
-        s.cols.p = cols;
+        RK_TRY(rk::pcs_coset_lde_cols(ctx, s.lde.u32(), d_trace, s.n, s.w));
         if (!tb.on_device) RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host buffer is free again
-        tmats[t] = rk_matrix{s.lde.u32(), (uint32_t)s.H, (uint32_t)s.w, 1};
+        tmats[t] = rk_matrix{s.lde.u32(), (uint32_t)s.H, (uint32_t)s.w, 2};
         Ht = std::max(Ht, s.H);
         log_max = std::max(log_max, s.k + blow);
     }
@@ -363,7 +364,7 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         const unsigned kq = s.k + s.lqd;
         const size_t qd = (size_t)1 << s.lqd, d = s.n << s.lqd, n_qcols = 4 * qd;
         rk_program* pg = tb.air->prog;
-        DevBuf sel, q, qb;
+        DevBuf sel, q;
         if (pg->group_min[0]) {
             RK_TRY(sel.alloc(ctx, 3 * d * 4));
             SelArgs a{};
@@ -387,14 +388,13 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         dom.d_cols[0] = sel.u32();
         dom.group_size[0] = 3;
         dom.col_len[0] = d;
-        dom.d_cols[2] = s.cols.u32();
+        dom.d_cols[2] = s.lde.u32();
         dom.group_size[2] = (uint32_t)s.w;
         dom.col_len[2] = s.H;
         dom.stride_log2[2] = blow - s.lqd;
         dom.globals = tb.public_values;
         dom.n_globals = tb.n_public;
         RK_TRY(rk::program_eval_domain(pg, dom, alpha.c, q.u32()));
-        s.cols.reset();
         sel.reset();
         // the chunks' own LDE: interpolate over H_n, move to the chunk's coset, evaluate on the LDE coset
         RK_TRY(rk::ntt_reverse(ctx, q.u32(), s.n, n_qcols, /*fuse_zk_shift=*/false));
@@ -404,11 +404,9 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
                                (unsigned)n_qcols, ctx->tb);
             RK_TRY(rk::post_launch(ctx, "chunk_shift_kernel"));
         }
-        RK_TRY(qb.alloc(ctx, n_qcols * s.H * 4));
-        RK_TRY(rk::ntt_forward(ctx, qb.u32(), q.u32(), s.n, n_qcols, blow));
-        RK_TRY(s.chunks.alloc(ctx, s.H * n_qcols * 4));
-        RK_TRY(rk::pcs_cols_to_rows_bitrev(ctx, s.chunks.u32(), qb.u32(), s.H, n_qcols));
-        qmats.push_back(rk_matrix{s.chunks.u32(), (uint32_t)s.H, (uint32_t)n_qcols, 1});
+        RK_TRY(s.chunks.alloc(ctx, n_qcols * s.H * 4));
+        RK_TRY(rk::ntt_forward(ctx, s.chunks.u32(), q.u32(), s.n, n_qcols, blow));
+        qmats.push_back(rk_matrix{s.chunks.u32(), (uint32_t)s.H, (uint32_t)n_qcols, 2});
         Hq = std::max(Hq, s.H);
     }
     lap(tm.quotient);
@@ -442,9 +440,9 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
         std::memcpy(pts + 4, zn.c, 16);
         s.y.resize(8 * s.w + ((size_t)16 << s.lqd));
-        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.lde.u32(), s.H, s.w, pts, 2));
+        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.lde.u32(), s.H, s.w, pts, 2, /*cols=*/true));
         RK_TRY(d2h(ctx, s.y.data(), d_ys.p, 8 * s.w * 4));
-        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.lde.u32(), s.H, s.w, 2, pts, s.y.data(), alpha2, num_reduced[lh]));
+        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.lde.u32(), s.H, s.w, 2, pts, s.y.data(), alpha2, num_reduced[lh], /*cols=*/true));
         num_reduced[lh] += 2 * s.w;
     }
     for (uint32_t t = 0; t < n_tables; t++) {  // round 1: every quotient chunk at zeta
@@ -452,9 +450,9 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         const unsigned lh = s.k + blow;
         const size_t wq = (size_t)4 << s.lqd;
         uint32_t* y = s.y.data() + 8 * s.w;
-        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunks.u32(), s.H, wq, zeta.c, 1));
+        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunks.u32(), s.H, wq, zeta.c, 1, /*cols=*/true));
         RK_TRY(d2h(ctx, y, d_ys.p, wq * 16));
-        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunks.u32(), s.H, wq, 1, zeta.c, y, alpha2, num_reduced[lh]));
+        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunks.u32(), s.H, wq, 1, zeta.c, y, alpha2, num_reduced[lh], /*cols=*/true));
         num_reduced[lh] += wq;
     }
     for (const TableState& s : ts) push(s.y.data(), s.y.size());
@@ -505,12 +503,15 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     // ---- queries: all indices first (they depend on the transcript only), then one gather
     std::vector<GatherJob> jobs;
     uint32_t at = 0;
-    auto job = [&](const uint32_t* src, uint32_t words) {
-        jobs.push_back(GatherJob{(uint64_t)(uintptr_t)src, words, at});
+    auto job = [&](const uint32_t* src, uint32_t words, uint64_t stride = 1) {
+        jobs.push_back(GatherJob{(uint64_t)(uintptr_t)src, stride, words, at});
         at += words;
     };
     auto open_batch = [&](const std::vector<rk_matrix>& mats, const uint32_t* nodes, size_t H, uint32_t index) {
-        for (const rk_matrix& m : mats) job(m.d_values + (size_t)(index / (H / m.height)) * m.width, m.width);
+        for (const rk_matrix& m : mats) {   // layout 2: committed row r of a column-major matrix sits at index bitrev(r) of every column
+            const uint32_t r = (uint32_t)(index / (H / m.height));
+            job(m.d_values + bb::bitrev(r, log2u(m.height)), m.width, m.height);
+        }
         for (size_t idx = H + index; idx > 1; idx >>= 1) job(nodes + (idx ^ 1) * p2::OUT, p2::OUT);
     };
     for (uint32_t qi = 0; qi < par.queries; qi++) {

@@ -243,11 +243,12 @@ class HipHal:
         arr = (_lib.RkMatrix * len(mats))()
         for i, (buf, height, width, row_major) in enumerate(mats):
             arr[i].d_values = _ptr(buf)
-            arr[i].height, arr[i].width, arr[i].row_major = int(height), int(width), 1 if row_major else 0
+            arr[i].height, arr[i].width, arr[i].row_major = int(height), int(width), int(row_major)   # 0 / 1 / 2 (True = 1)
         return arr
 
     def mmcs_commit(self, mats):
-        """mats: [(device buffer, height, width, row_major)] in commit order -> (nodes buffer, root[8])"""
+        """mats: [(device buffer, height, width, layout)] in commit order -> (nodes buffer, root[8]); layout 1 / True =
+        row-major, 0 = column-major, 2 = column-major with the committed rows at bit-reversed indices (rk_matrix)"""
         h_max = max(int(m[1]) for m in mats)
         nodes = self.alloc_elem(2 * h_max * 8)
         root = np.zeros(8, dtype=np.uint32)
