@@ -74,8 +74,12 @@ def main():
     print(json.dumps(d))
     print("bench:", bench["value"], bench["ms_per_step"], bench.get("value_with_h2d"), bench["cpu_baseline"]["value"], bench["cpu_baseline"]["value_1_thread"])
     st = list(csv.DictReader(open(os.path.join(p, f"{tag}_final_kernel_stats_inflight1.csv"))))
+    # proofs in the trace: hash_rows_kernel runs 7 times per segment proof (3 groups + check + 3 FRI rounds at 2^20 cycles)
+    n_proofs = max(1, round(sum(int(r["Calls"]) for r in st if short(r["Name"]).startswith("hash_rows_kernel")) / 7))
+    print("proofs in the serial trace:", n_proofs)
     for r in st[:9]:
-        print(short(r["Name"]).ljust(44), r["Calls"].rjust(5), "avg %.1f us" % (float(r["AverageNs"]) / 1e3), "%.3f ms/segment" % (float(r["TotalDurationNs"]) / 1e6 / 12))
+        print(short(r["Name"]).ljust(44), r["Calls"].rjust(5), "avg %.1f us" % (float(r["AverageNs"]) / 1e3),
+              "%.3f ms/segment" % (float(r["TotalDurationNs"]) / 1e6 / n_proofs))
 
 
 if __name__ == "__main__":
