@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak run on one MI355X: for `seconds`, four host threads keep issuing work against one GPU -- sessions under risc0's
-and SP1's parameter sets (the device's contexts are re-parameterised back and forth), streams, the toy circuit
-behind hand-written hooks, its constraint list interpreted and run-time compiled -- every seal verified inside
+and SP1's parameter sets (the device's contexts are re-parameterised back and forth), streams with back-pressure, the
+multi-device work queue on two logical devices (RK_TEST_LOGICAL_DEVICES=2), the toy circuit behind hand-written hooks, its
+constraint list interpreted and run-time compiled, and uni-stark shard proofs (rk_p3_prove_shards: mixed-height tables,
+interpreted and compiled quotient) -- every seal / proof verified inside
 the library (constraint identity where there is a circuit) and a sample of them compared with a second proof
 of the same segment.  Prints one JSON line; exit code 1 on any failure."""
 import json
@@ -14,7 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from raiko_amd import circuit_program as cp, toy_circuit  # noqa: E402
+from raiko_amd import circuit_program as cp, p3, toy_circuit  # noqa: E402
 from raiko_amd.hal import HipHal, SessionStream, make_params, prove_session  # noqa: E402
 from raiko_amd.segment import synthetic_segment  # noqa: E402
 
@@ -29,7 +31,12 @@ def main():
     prog_j = cp.Program(*cp.toy_program(toy.taps, toy.n_accum_mix), toy.taps)
     prog_j.compile(hal)
     stop = time.time() + seconds
-    counts = {"risc0": 0, "sp1": 0, "stream": 0, "toy_hooks": 0, "toy_interpreted": 0, "toy_compiled": 0}
+    counts = {"risc0": 0, "sp1": 0, "stream": 0, "toy_hooks": 0, "toy_interpreted": 0, "toy_compiled": 0, "two_logical_devices": 0,
+              "p3_shards": 0}
+    os.environ["RK_TEST_LOGICAL_DEVICES"] = "2"     # device 1 = a second pool on the same GPU (session.hip)
+    p3_blob = make_params(1, queries=12, pow_bits=6)
+    airs = [p3.fibonacci_air(), p3.cubic_air(6), p3.cubic_air(5)]
+    airs[2].compile(hal)
     errors = []
     lock = threading.Lock()
 
@@ -41,7 +48,7 @@ def main():
         rng = np.random.default_rng(tid)
         try:
             while time.time() < stop:
-                kind = int(rng.integers(0, 6))
+                kind = int(rng.integers(0, 8))
                 po2 = int(rng.integers(6, 13))
                 n = int(rng.integers(1, 6))
                 if kind == 0:
@@ -59,8 +66,27 @@ def main():
                     st = SessionStream(inflight=2)
                     for _ in range(n):
                         st.submit(synthetic_segment(po2, (3, 2, 7), seed=int(rng.integers(1 << 30))))
+                        st.wait(2)
                     assert len(st.close()) == n
                     bump("stream", n)
+                elif kind == 6:
+                    segs = [synthetic_segment(po2, (4, 4, 12), seed=int(rng.integers(1 << 30))) for _ in range(n + 2)]
+                    a = prove_session(segs, inflight=2, upload_ahead=1, verify=True, devices=[0, 1])
+                    if rng.random() < 0.3:
+                        assert np.array_equal(a[-1], prove_session(segs[-1:], inflight=1, verify=False)[0])
+                    bump("two_logical_devices", n + 2)
+                elif kind == 7:
+                    shards = []
+                    for _ in range(n):
+                        k1, k2 = int(rng.integers(2, 9)), int(rng.integers(1, 7))
+                        which = 1 + int(rng.integers(0, 2))
+                        t1 = p3.Table.from_canonical(airs[which], *p3.cubic_trace(k1, airs[which].width, seed=int(rng.integers(1 << 30))))
+                        t2 = p3.Table.from_canonical(airs[0], *p3.fibonacci_trace(k2, int(rng.integers(0, 100)), 3))
+                        shards.append(([t1, t2], p3.to_mont([int(rng.integers(0, 1000))])))
+                    pr = p3.prove_shards(shards, p3_blob, batch=2, verify=True)
+                    if rng.random() < 0.3:
+                        assert p3.verify(shards[0][0], pr[0], shards[0][1], params=p3_blob) == 0
+                    bump("p3_shards", n)
                 else:
                     segs = [toy_circuit.toy_segment(min(po2, 11), (8, 4, 8), seed=int(rng.integers(1 << 30))) for _ in range(n)]
                     if kind == 3:
