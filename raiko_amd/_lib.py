@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraiko_hip.so")
+# RAIKO_HIP_LIB: another build of the same library (tests/asan/run_sanitized.sh points it at the build whose HOST code is
+# compiled with -fsanitize=address,undefined); there is still no fallback -- a path that does not load is an error
+LIB_PATH = os.environ.get("RAIKO_HIP_LIB") or os.path.join(_HERE, "libraiko_hip.so")
 
 
 class HipLibraryError(RuntimeError):
