@@ -128,6 +128,25 @@ def test_shards_in_flight_give_the_same_proofs(hal):
     H.session_release()
 
 
+def test_full_size_tables(hal):
+    """2^20 rows against the oracle (H = 2^21 leaves per tree, 20 FRI rounds), 2^22 rows x 40 columns through the host
+    verifier alone (the oracle would take minutes): the sizes an SP1 shard has (SHARD_SIZE up to 2^22, docs/README_Sp1.md:22)"""
+    blob = hal.set_params(1, queries=20)
+    o.oracle_set_params(1, queries=20)
+    fib = air_of("fib", None)
+    t = [p3.Table.from_canonical(fib, *p3.fibonacci_trace(20, 3, 5))]
+    got = p3.prove(hal, t, p3.to_mont([9]))
+    assert np.array_equal(got, o.oracle_p3_prove(t, p3.to_mont([9])))
+    assert p3.verify(t, got, p3.to_mont([9]), params=blob) == 0
+    air = p3.local_air(40, seed=2)
+    big = [p3.Table.from_canonical(air, *p3.local_trace(air, 22, seed=3)), t[0]]
+    air.compile(hal)
+    pf = p3.prove(hal, big)
+    assert p3.verify(big, pf, params=blob) == 0
+    pf[pf.size // 3] = (int(pf[pf.size // 3]) + 1) % P
+    assert p3.verify(big, pf, params=blob) != 0
+
+
 def test_capacity_and_argument_errors(hal):
     import ctypes as C
     from raiko_amd import _lib
