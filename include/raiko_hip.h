@@ -208,6 +208,16 @@ int rk_pcs_eval_at_many(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde,
  * matrix height, zeroed by the caller) is what the FRI commit phase folds with rk_fri_fold_evals. */
 int rk_pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,
                            const uint32_t* h_points, const uint32_t* h_opened, const uint32_t alpha[4], uint64_t alpha_offset);
+/* The same three steps for hosts that can keep the LDE the way the NTT leaves it -- `width` columns of
+ * height << blowup_log2 evaluations in NATURAL order, i.e. rk_matrix layout 2 (row_major = 2: committed row r at index
+ * bitrev(r) of every column).  rk_mmcs_commit / rk_mmcs_open take that layout as it is; the values returned here are those
+ * of the row-major forms above (same d_out_ext, same d_ro_ext indexed by committed row).  No pass exists only to reorder:
+ * a 2^20 x 256 LDE costs 3.4 ms instead of 5.0 (rk_p3_prove works this way). */
+int rk_pcs_coset_lde_cols(rk_ctx* ctx, uint32_t* d_cols, const uint32_t* d_in_rows, size_t height, size_t width);
+int rk_pcs_eval_at_many_cols(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde_cols, size_t lde_height, size_t width, uint32_t n_points,
+                             const uint32_t* h_points);
+int rk_pcs_reduce_openings_cols(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde_cols, size_t lde_height, size_t width, uint32_t n_points,
+                                const uint32_t* h_points, const uint32_t* h_opened, const uint32_t alpha[4], uint64_t alpha_offset);
 /* `challenger.grind(bits)` of Plonky3's DuplexChallenger (p3-challenger, RECALLED): sponge_state = the challenger's
  * `width` state cells (Montgomery words), input_buffer = its n_input (< rate = width - 8) buffered observations.
  * *witness = the smallest field element w (canonical integer) for which observing w and then sample_bits(bits) gives

@@ -396,6 +396,9 @@ extern "C" {
     pub fn rk_pcs_eval_at(ctx: *mut rk_ctx, d_out_ext: *mut u32, d_lde: *const u32, lde_height: usize, width: usize, z: *const u32) -> c_int;
     pub fn rk_pcs_eval_at_many(ctx: *mut rk_ctx, d_out_ext: *mut u32, d_lde: *const u32, lde_height: usize, width: usize, n_points: u32, h_points: *const u32) -> c_int;
     pub fn rk_pcs_reduce_openings(ctx: *mut rk_ctx, d_ro_ext: *mut u32, d_lde: *const u32, lde_height: usize, width: usize, n_points: u32, h_points: *const u32, h_opened: *const u32, alpha: *const u32, alpha_offset: u64) -> c_int;
+    pub fn rk_pcs_coset_lde_cols(ctx: *mut rk_ctx, d_cols: *mut u32, d_in_rows: *const u32, height: usize, width: usize) -> c_int;
+    pub fn rk_pcs_eval_at_many_cols(ctx: *mut rk_ctx, d_out_ext: *mut u32, d_lde_cols: *const u32, lde_height: usize, width: usize, n_points: u32, h_points: *const u32) -> c_int;
+    pub fn rk_pcs_reduce_openings_cols(ctx: *mut rk_ctx, d_ro_ext: *mut u32, d_lde_cols: *const u32, lde_height: usize, width: usize, n_points: u32, h_points: *const u32, h_opened: *const u32, alpha: *const u32, alpha_offset: u64) -> c_int;
     pub fn rk_duplex_grind(ctx: *mut rk_ctx, sponge_state: *const u32, input_buffer: *const u32, n_input: u32, bits: u32, witness: *mut u32) -> c_int;
     pub fn rk_poly_divide(ctx: *mut rk_ctx, d_polys_ext: *mut u32, count: usize, z: *const u32, h_rem: *mut u32) -> c_int;
     pub fn rk_program_create(steps: *const rk_poly_step, n_steps: usize, ret: u32, taps: *const rk_taps, out: *mut *mut rk_program) -> c_int;

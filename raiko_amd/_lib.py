@@ -200,6 +200,9 @@ SYMBOLS = {
     "rk_fri_fold": (C.c_int, [_vp, _vp, _vp, _sz, u32p]),
     "rk_fri_fold_evals": (C.c_int, [_vp, _vp, _vp, _sz, u32p]),
     "rk_pcs_coset_lde_rows": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
+    "rk_pcs_coset_lde_cols": (C.c_int, [_vp, _vp, _vp, _sz, _sz]),
+    "rk_pcs_eval_at_many_cols": (C.c_int, [_vp, _vp, _vp, _sz, _sz, C.c_uint32, u32p]),
+    "rk_pcs_reduce_openings_cols": (C.c_int, [_vp, _vp, _vp, _sz, _sz, C.c_uint32, u32p, u32p, u32p, C.c_uint64]),
     "rk_pcs_eval_at": (C.c_int, [_vp, _vp, _vp, _sz, _sz, u32p]),
     "rk_pcs_eval_at_many": (C.c_int, [_vp, _vp, _vp, _sz, _sz, C.c_uint32, u32p]),
     "rk_duplex_grind": (C.c_int, [_vp, u32p, u32p, C.c_uint32, C.c_uint32, u32p]),

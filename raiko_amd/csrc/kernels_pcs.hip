@@ -455,6 +455,32 @@ int rk_pcs_eval_at_many(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde,
     return rk::pcs_eval_at(ctx, d_out_ext, d_lde, lde_height, width, h_points, n_points);
     RK_GUARD_END
 }
+int rk_pcs_coset_lde_cols(rk_ctx* ctx, uint32_t* d_cols, const uint32_t* d_in_rows, size_t height, size_t width) {
+    RK_GUARD_BEGIN
+    if (!ctx || !d_cols || !d_in_rows) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::pcs_coset_lde_cols(ctx, d_cols, d_in_rows, height, width);
+    RK_GUARD_END
+}
+int rk_pcs_eval_at_many_cols(rk_ctx* ctx, uint32_t* d_out_ext, const uint32_t* d_lde_cols, size_t lde_height, size_t width, uint32_t n_points,
+                             const uint32_t* h_points) {
+    RK_GUARD_BEGIN
+    if (!ctx || !d_out_ext || !d_lde_cols || !h_points || n_points == 0 || n_points > 4) return RK_ERR_INVALID;
+    for (uint32_t i = 0; i < 4 * n_points; i++)
+        if (h_points[i] >= bb::P) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::pcs_eval_at(ctx, d_out_ext, d_lde_cols, lde_height, width, h_points, n_points, /*cols=*/true);
+    RK_GUARD_END
+}
+int rk_pcs_reduce_openings_cols(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde_cols, size_t lde_height, size_t width, uint32_t n_points,
+                                const uint32_t* h_points, const uint32_t* h_opened, const uint32_t alpha[4], uint64_t alpha_offset) {
+    RK_GUARD_BEGIN
+    if (!ctx || !d_ro_ext || !d_lde_cols || !h_points || !h_opened || !alpha) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rk::pcs_reduce_openings(ctx, d_ro_ext, d_lde_cols, lde_height, width, n_points, h_points, h_opened,
+                                   bb::Ext{{alpha[0], alpha[1], alpha[2], alpha[3]}}, alpha_offset, /*cols=*/true);
+    RK_GUARD_END
+}
 int rk_pcs_reduce_openings(rk_ctx* ctx, uint32_t* d_ro_ext, const uint32_t* d_lde, size_t lde_height, size_t width, uint32_t n_points,
                            const uint32_t* h_points, const uint32_t* h_opened, const uint32_t alpha[4], uint64_t alpha_offset) {
     RK_GUARD_BEGIN

@@ -198,6 +198,24 @@ class HipHal:
         """TwoAdicFriPcs::commit for one matrix: coset LDE (blow-up / shift of the parameter set), bit-reversed rows"""
         self._ck(self._lib.rk_pcs_coset_lde_rows(self._ctx, _ptr(out), _ptr(inp), height, width))
 
+    def pcs_coset_lde_cols(self, out, inp, height: int, width: int):
+        """the same LDE left the way the NTT leaves it: `width` columns of (height << blow-up) natural-order evaluations
+        (rk_matrix layout 2); `inp` is the row-major trace"""
+        self._ck(self._lib.rk_pcs_coset_lde_cols(self._ctx, _ptr(out), _ptr(inp), height, width))
+
+    def pcs_eval_at_many_cols(self, lde_cols, lde_height: int, width: int, points) -> np.ndarray:
+        pts = np.ascontiguousarray(points, dtype=np.uint32).reshape(-1, 4)
+        out = self.alloc_elem(pts.shape[0] * width * 4)
+        self._ck(self._lib.rk_pcs_eval_at_many_cols(self._ctx, _ptr(out), _ptr(lde_cols), lde_height, width, pts.shape[0], _u32p(pts)))
+        return out.to_host().reshape(pts.shape[0], width, 4)
+
+    def pcs_reduce_openings_cols(self, ro, lde_cols, lde_height: int, width: int, points, opened, alpha, alpha_offset: int = 0):
+        pts = np.ascontiguousarray(points, dtype=np.uint32).reshape(-1, 4)
+        ys = np.ascontiguousarray(opened, dtype=np.uint32).reshape(pts.shape[0], width, 4)
+        a = np.ascontiguousarray(alpha, dtype=np.uint32)
+        self._ck(self._lib.rk_pcs_reduce_openings_cols(self._ctx, _ptr(ro), _ptr(lde_cols), lde_height, width, pts.shape[0], _u32p(pts),
+                                                       _u32p(ys), _u32p(a), alpha_offset))
+
     def pcs_eval_at(self, lde, lde_height: int, width: int, z) -> np.ndarray:
         """the opened values p_c(z) of one committed matrix: (width, 4) words"""
         zz = np.ascontiguousarray(z, dtype=np.uint32)

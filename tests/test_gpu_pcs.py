@@ -184,3 +184,41 @@ def test_coset_lde_rows_other_blowups(cfg, blow, k, w):
     ys = np.zeros((w, 4), dtype=np.uint32)
     orc.or_pcs_eval_at(o.ptr(ys), o.ptr(want), n << blow, w, o.ptr(z))
     assert np.array_equal(h.pcs_eval_at(out, n << blow, w, z), ys)
+
+
+@pytest.mark.parametrize("preset,k,w,npts", [(1, 9, 37, 2), (0, 7, 5, 3), (1, 14, 130, 2), (1, 3, 1, 1)])
+def test_column_major_forms_equal_the_row_major_ones(preset, k, w, npts):
+    """rk_pcs_coset_lde_cols / rk_pcs_eval_at_many_cols / rk_pcs_reduce_openings_cols and rk_mmcs_commit on layout 2: the
+    LDE as the NTT leaves it (columns in natural order) gives the same committed rows, the same tree, the same opened values
+    and the same reduced opening as the row-major operators (which are pinned against the oracle above)"""
+    from raiko_amd import hal as H
+    h = H.HipHal(0)
+    try:
+        par = h.set_params(preset)
+        blow = int(par.blowup_log2)
+        n, Hh = 1 << k, (1 << k) << blow
+        rng = np.random.default_rng(100 * k + w)
+        ev = h.copy_from_elem(o.rand_elems(rng, (n, w)))
+        rows, cols = h.alloc_elem(Hh * w), h.alloc_elem(Hh * w)
+        h.pcs_coset_lde_rows(rows, ev, n, w)
+        h.pcs_coset_lde_cols(cols, ev, n, w)
+        R, Cm = rows.to_host().reshape(Hh, w), cols.to_host().reshape(w, Hh)
+        bits = k + blow
+        perm = np.array([int(format(i, "0%db" % bits)[::-1], 2) for i in range(Hh)])
+        assert np.array_equal(Cm[:, perm].T, R)                       # committed row r = natural index bitrev(r)
+        nodes_r, root_r = h.mmcs_commit([(rows, Hh, w, 1)])
+        nodes_c, root_c = h.mmcs_commit([(cols, Hh, w, 2)])
+        assert np.array_equal(root_r, root_c) and np.array_equal(nodes_r.to_host(), nodes_c.to_host())
+        for index in (0, Hh - 1, Hh // 3):
+            a, b = h.mmcs_open([(rows, Hh, w, 1)], nodes_r, index), h.mmcs_open([(cols, Hh, w, 2)], nodes_c, index)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        pts = o.rand_elems(rng, (npts, 4))
+        ys = h.pcs_eval_at_many(rows, Hh, w, pts)
+        assert np.array_equal(h.pcs_eval_at_many_cols(cols, Hh, w, pts), ys)
+        alpha, start = o.rand_elems(rng, (4,)), o.rand_elems(rng, (Hh, 4))
+        ro_r, ro_c = h.copy_from_elem(start), h.copy_from_elem(start)
+        h.pcs_reduce_openings(ro_r, rows, Hh, w, pts, ys, alpha, 11)
+        h.pcs_reduce_openings_cols(ro_c, cols, Hh, w, pts, ys, alpha, 11)
+        assert np.array_equal(ro_r.to_host(), ro_c.to_host())
+    finally:
+        h.close()

@@ -40,6 +40,12 @@ def main():
         t_red = timed(h, lambda: h.pcs_reduce_openings(ro, lde, Hh, w, z, ys, alpha, 0))
         nxt = h.alloc_elem(Hh // 2 * 4)
         t_fold = timed(h, lambda: h.fri_fold_evals(nxt, ro, Hh // 2, alpha))
+        # the column-major forms (rk_matrix layout 2: the LDE as the NTT leaves it)
+        cols = h.alloc_elem(Hh * w)
+        t_lde_c = timed(h, lambda: h.pcs_coset_lde_cols(cols, ev, n, w))
+        t_mmcs_c = timed(h, lambda: h.mmcs_commit([(cols, Hh, w, 2)]))
+        t_eval2_c = timed(h, lambda: h.pcs_eval_at_many_cols(cols, Hh, w, z))
+        t_red_c = timed(h, lambda: h.pcs_reduce_openings_cols(ro, cols, Hh, w, z, ys, alpha, 0))
         gb = lambda b, t: round(b / t / 1e9, 1)
         print(json.dumps({
             "log_height": k, "width": w, "blowup_log2": blow,
@@ -49,6 +55,9 @@ def main():
             "eval_at_2pts_one_pass_ms": round(t_eval2 * 1e3, 3),
             "reduce_openings_2pts_ms": round(t_red * 1e3, 3), "reduce_openings_GBps": gb(Hh * w * 4 + Hh * 32, t_red),
             "fri_fold_evals_ms": round(t_fold * 1e3, 3), "fri_fold_evals_GBps": gb(Hh * 16 * 1.5, t_fold),
+            "cols": {"coset_lde_cols_ms": round(t_lde_c * 1e3, 3), "coset_lde_cols_GBps": gb((n + Hh) * w * 4, t_lde_c),
+                     "mmcs_commit_ms": round(t_mmcs_c * 1e3, 3), "eval_at_2pts_ms": round(t_eval2_c * 1e3, 3),
+                     "reduce_openings_2pts_ms": round(t_red_c * 1e3, 3)},
         }), flush=True)
 
 
