@@ -38,7 +38,22 @@ def main():
     t7 = time.perf_counter()
     X.execute_and_prove(image, segment_limit_po2=20, circuit="trace", pipeline=True, device_witness=False)
     t8 = time.perf_counter()
+    # the same execution as SP1-style shards: one uni-stark proof per 2^20-cycle shard (rk_p3_prove_shards, 16-column trace AIR,
+    # SP1's parameter set: blow-up 2, 100 queries, 16 proof-of-work bits), every proof verified inside
+    from raiko_amd import p3
+    from raiko_amd.hal import make_params
+    blob = make_params(1)
+    shards = X.p3_shards(ex)
+    for tb, _ in shards:
+        tb[0].air.compile(hal)
+    p3.prove_shards(shards[:1], blob, batch=1, verify=False)              # warm: contexts, tables
+    t9 = time.perf_counter()
+    proofs = p3.prove_shards(shards, blob, batch=3, verify=True)
+    t10 = time.perf_counter()
+    p3_part = {"shards": len(shards), "prove_and_verify_s": round(t10 - t9, 3), "proven_cycles_per_s": round(ex.total_cycles / (t10 - t9), 1),
+               "proof_words": [int(pf.size) for pf in proofs]}
     print(json.dumps({"what": "ELF -> receipt through the stand-in trace circuit (4 + 2 + 16 columns)", "cycles": ex.total_cycles,
+                      "as_uni_stark_shards": p3_part,
                       "pipelined_execute_to_receipt_s": round(t7 - t6, 3),
                       "cycles_per_s_pipelined": round(ex.total_cycles / (t7 - t6), 1),
                       "pipelined_host_witness_s": round(t8 - t7, 3),
