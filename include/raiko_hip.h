@@ -557,8 +557,8 @@ int rk_exec_free(rk_exec* ex);
  * `client.prove(&pk, stdin)` (provers/sp1/driver/src/lib.rs:44-57; shard knobs docs/README_Sp1.md:19-32) as far as it
  * exists without SP1's chips -- p3-uni-stark prove / verify over p3-fri's TwoAdicFriPcs with a DuplexChallenger
  * (Plonky3@88ea2b8, Cargo.lock:4889-5127; RECALLED, the crates are outside the reference tree), for one or several
- * tables under shared challenges, the way sp1-core proves the chips of a shard.  NOT here: SP1's chips, its
- * permutation (lookup) argument, its recursion / compress VM.
+ * tables under shared challenges, the way sp1-core proves the chips of a shard, including the permutation (LogUp)
+ * argument that ties the tables together (rk_air_create_lookup below).  NOT here: SP1's chips, its recursion / compress VM.
  *
  * An AIR is a step list, the shape `Air::eval` leaves in a symbolic builder: every step except ASSERT_ZERO pushes one
  * value; a, b name earlier values by their position in that list.
@@ -568,13 +568,17 @@ int rk_exec_free(rk_exec* ex);
  *   IS_FIRST_ROW, IS_LAST_ROW, IS_TRANSITION     the Lagrange selectors (unnormalised, as p3-commit domain.rs has them)
  *   ADD | SUB | MUL a b, NEG a
  *   ASSERT_ZERO a        ConstraintFolder::assert_zero: accumulator = accumulator * alpha + a
+ *   PERM_LOCAL a / PERM_NEXT a   base column a of the table's permutation trace (rk_air_create_lookup), current / next row
+ *   CHALLENGE a          base component a of the permutation challenges [alpha | beta^0 | beta^1 | ...] (4 words each)
+ *   CUMSUM a             base component a of the table's cumulative sum
  * rk_air_create validates, derives the quotient degree from the symbolic degrees (get_log_quotient_degree: a cell and
  * is_first_row / is_last_row count 1, is_transition and constants 0) and translates the list into an rk_program whose
  * taps are the columns of the LDE, so the quotient is evaluated by the same GPU evaluator as risc0's eval_check;
  * rk_air_compile builds the straight-line kernel with hiprtc (optional, about 3x the interpreter). */
 typedef enum {
     RK_AIR_CONST = 0, RK_AIR_LOCAL = 1, RK_AIR_NEXT = 2, RK_AIR_PUBLIC = 3, RK_AIR_IS_FIRST_ROW = 4, RK_AIR_IS_LAST_ROW = 5,
-    RK_AIR_IS_TRANSITION = 6, RK_AIR_ADD = 7, RK_AIR_SUB = 8, RK_AIR_MUL = 9, RK_AIR_NEG = 10, RK_AIR_ASSERT_ZERO = 11
+    RK_AIR_IS_TRANSITION = 6, RK_AIR_ADD = 7, RK_AIR_SUB = 8, RK_AIR_MUL = 9, RK_AIR_NEG = 10, RK_AIR_ASSERT_ZERO = 11,
+    RK_AIR_PERM_LOCAL = 12, RK_AIR_PERM_NEXT = 13, RK_AIR_CHALLENGE = 14, RK_AIR_CUMSUM = 15
 } rk_air_op;
 typedef struct { uint32_t op, a, b; } rk_air_step;
 typedef struct rk_air rk_air;
@@ -587,6 +591,22 @@ typedef struct {
     uint32_t n_fp_slots;           /* live intermediate values (rk_program_info) */
 } rk_air_info;
 int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, rk_air** out);
+/* An AIR whose table takes part in lookups, in the shape sp1-core gives them (stark/permutation.rs, lookup/interaction.rs,
+ * air/builder.rs send / receive; sp1-core is pulled by the reference's Cargo.lock, RECALLED): interaction i says "every
+ * row sends (kind 0) or receives (kind 1) the tuple (bus, local[value_cols]...) `mult` times", mult a main-trace column
+ * or -- mult_is_const -- a canonical constant.  Flat form: per interaction the words kind, bus, mult_is_const, mult,
+ * n_values followed by its n_values column numbers (n_words in all).
+ * The prover (rk_p3_prove) then, after the main traces are committed, draws two extension challenges alpha, beta,
+ * fills the table's permutation trace on the GPU -- one extension column per batch of two interactions holding
+ * sum +-mult / (alpha + beta^0 bus + sum_j beta^(j+1) value_j), and a last column with the running sum of the row totals
+ * (4 base columns each: 4 * (ceil(n / 2) + 1) in all) --, commits those traces as a second batch and observes root and
+ * cumulative sums before the constraint challenge; the verifier also checks that the cumulative sums of all tables add
+ * up to zero (reason 8): every tuple sent is received as often.  The constraints tying the permutation trace to the
+ * main trace are part of `steps`, written over PERM_LOCAL / PERM_NEXT / CHALLENGE / CUMSUM (raiko_amd/p3.py
+ * AirBuilder.send / receive emit them as eval_permutation_constraints does: 4 base asserts per extension identity, the
+ * extension's W baked in).  A proof without any interaction keeps the bytes it had before this entry point existed. */
+int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public,
+                         const uint32_t* interaction_words, uint32_t n_interactions, size_t n_words, rk_air** out);
 int rk_air_destroy(rk_air* air);
 int rk_air_get_info(const rk_air* air, rk_air_info* out);
 int rk_air_compile(rk_air* air, rk_ctx* ctx);
@@ -605,13 +625,16 @@ typedef struct {
  * instance, blowup_log2 = FriConfig::log_blowup, queries, pow_bits; fri_fold_log2 / fri_min_degree are not used -- the
  * PCS folds by two down to a constant).  Every table's quotient degree must fit the blow-up.  Transcript:
  * observe(init_words) -- whatever binds the statement: SP1 observes the verifying key and pc_start there --,
- * observe(trace root), observe(public values of every table), alpha, observe(quotient root), zeta, then the PCS's own
- * challenges.  Proof = u32 words (field elements as Montgomery words):
- *   n_tables | log_height per table | trace root 8 | quotient root 8 |
- *   per table: opened trace row at zeta (4 words per column), at zeta * g, 2^log_quotient_degree chunks x 4 x 4 |
+ * observe(trace root), observe(public values of every table), [lookups: permutation alpha, beta, observe(permutation
+ * root), observe(cumulative sums)], alpha, observe(quotient root), zeta, then the PCS's own challenges.
+ * Proof = u32 words (field elements as Montgomery words):
+ *   n_tables | log_height per table | trace root 8 | [permutation root 8 | cumulative sum 4 per table with lookups] |
+ *   quotient root 8 |
+ *   per table: opened trace row at zeta (4 words per column), at zeta * g, [the permutation trace's, likewise],
+ *   2^log_quotient_degree chunks x 4 x 4 |
  *   n_rounds | n_rounds x 8 commit-phase roots | final polynomial 4 | proof-of-work witness (canonical integer) |
- *   per query: the trace batch (every table's LDE row, then the Merkle path), the quotient batch (every chunk's row,
- *   then the path), then per FRI round the sibling value (4) and its path.
+ *   per query: the trace batch (every table's LDE row, then the Merkle path), [the permutation batch], the quotient
+ *   batch (every chunk's row, then the path), then per FRI round the sibling value (4) and its path.
  * RK_ERR_CAPACITY with *proof_words = the exact size when the buffer is too small.  A trace that breaks its AIR still
  * yields a proof (as in Plonky3's release builds); rk_p3_verify rejects it with reason 3. */
 int rk_p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
@@ -619,7 +642,7 @@ int rk_p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const
 /* p3-uni-stark `verify` on the host (no GPU): params NULL = the SP1 preset; trace / log_height / on_device of the tables
  * are ignored.  0 = accepted, RK_ERR_INVALID for malformed arguments, otherwise a reason: 1 malformed proof (short,
  * trailing or non-canonical words), 2 shape mismatch, 3 constraint identity (OodEvaluationMismatch), 4 proof of work,
- * 5 input opening, 6 commit-phase opening, 7 final polynomial. */
+ * 5 input opening, 6 commit-phase opening, 7 final polynomial, 8 the cumulative sums of the lookups do not cancel. */
 int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
                  const uint32_t* proof, size_t proof_words);
 /* exact proof size for the tables' shapes (log_height, width, air); 0 for shapes rk_p3_prove rejects */
@@ -650,7 +673,7 @@ typedef struct {
 } rk_p3_session_opts;
 int rk_p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t n, size_t* failed_index);
 /* wall-clock per stage of the last rk_p3_prove on this ctx, milliseconds (the stream is drained at every boundary) */
-typedef struct { float lde, commit, quotient, open, fri, query, total; } rk_p3_timing;
+typedef struct { float lde, commit, quotient, open, fri, query, total, perm /* permutation traces + their LDE */; } rk_p3_timing;
 int rk_p3_last_timing(rk_ctx* ctx, rk_p3_timing* out);
 
 /* per-stage device time of the last rk_prove_segment on this ctx, milliseconds (hipEvent) */

@@ -7,13 +7,21 @@
  * p3-commit domain.rs, p3-fri two_adic_pcs.rs / prover.rs / verifier.rs, p3-challenger duplex_challenger.rs at
  * Plonky3@88ea2b8, reference Cargo.lock:4889-5127 -- are outside the reference tree: RECALLED).
  *
- * What is NOT here: SP1's chips, its permutation (lookup) argument and its recursion VM.  An AIR is data -- a list
+ * What is NOT here: SP1's chips and its recursion VM.  The permutation (LogUp) argument that ties the tables of a shard
+ * together IS here in the shape sp1-core gives it (stark/permutation.rs, lookup/interaction.rs, RECALLED): a table lists
+ * interactions -- tuples (bus, values...) sent or received with a multiplicity per row --; after the main traces are
+ * committed two extension challenges alpha, beta are drawn, every table with interactions gets a permutation trace of
+ * ceil(n / 2) + 1 extension columns (one per batch of two interactions: sum of +-mult / (alpha + sum_j beta^j x_j), x_0
+ * the bus; the last column the running sum of the row totals), committed as a second batch; the constraints that tie
+ * it to the main trace are ordinary AIR steps over PERM_LOCAL / PERM_NEXT / CHALLENGE / CUMSUM (the front end writes
+ * them); the verifier additionally checks that the tables' cumulative sums add up to zero.  An AIR is data -- a list
  * of steps over the local row, the next row, public values and the three selectors (or_air_step), the shape an
  * `Air::eval` call leaves in a symbolic builder.
  *
  * Flow (uni-stark prove, per table, with the commitments batched over tables):
  *   observe(init words); commit every trace's coset LDE (bit-reversed rows) in one MMCS; observe(root),
- *   observe(public values); alpha <- sample_ext;
+ *   observe(public values); [with interactions: pa, pb <- sample_ext; permutation traces; commit; observe(root),
+ *   observe(cumulative sums)]; alpha <- sample_ext;
  *   per table: quotient values on the disjoint coset s * H_(N * qd) -- acc = acc * alpha + constraint over the
  *   asserts in order, times 1 / Z_H(x) -- split into qd chunks (rows j, j + qd, ...), each flattened to 4 base
  *   columns; commit every chunk's LDE in one MMCS; observe(root); zeta <- sample_ext;
@@ -21,11 +29,11 @@
  *   values; reduced openings per LDE height; FRI commit phase (arity 2 on evaluations, shorter inputs join when the
  *   sizes meet) down to `blowup` equal values; observe(final); proof of work; queries.
  * Proof = u32 words (field elements as Montgomery words, the form every buffer of this repo uses):
- *   n_tables | log_height per table | trace root 8 | quotient root 8 |
- *   per table: trace_local 4w, trace_next 4w, quotient chunks qd x 4 x 4 |
+ *   n_tables | log_height per table | trace root 8 | [permutation root 8 | cumulative sum 4 per table with interactions] |
+ *   quotient root 8 | per table: trace_local 4w, trace_next 4w, [perm_local 4 * 4P, perm_next 4 * 4P], quotient chunks qd x 4 x 4 |
  *   n_rounds | n_rounds x 8 commit-phase roots | final_poly 4 | pow witness 1 (canonical integer) |
- *   per query: [trace batch: every table's opened LDE row, then the path] [quotient batch: every chunk's row, then
- *   the path] then per FRI round: sibling value 4, path. */
+ *   per query: [trace batch: every table's opened LDE row, then the path] [permutation batch] [quotient batch: every
+ *   chunk's row, then the path] then per FRI round: sibling value 4, path. */
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
@@ -74,8 +82,9 @@ int or_air_log_quotient_degree(const or_air* air) {
     for (size_t s = 0; s < air->n_steps; s++) {
         const or_air_step* st = &air->steps[s];
         switch (st->op) {
-            case OR_AIR_CONST: case OR_AIR_PUBLIC: case OR_AIR_IS_TRANSITION: deg[nv++] = 0; break;
-            case OR_AIR_LOCAL: case OR_AIR_NEXT: case OR_AIR_IS_FIRST_ROW: case OR_AIR_IS_LAST_ROW: deg[nv++] = 1; break;
+            case OR_AIR_CONST: case OR_AIR_PUBLIC: case OR_AIR_IS_TRANSITION: case OR_AIR_CHALLENGE: case OR_AIR_CUMSUM: deg[nv++] = 0; break;
+            case OR_AIR_LOCAL: case OR_AIR_NEXT: case OR_AIR_IS_FIRST_ROW: case OR_AIR_IS_LAST_ROW:
+            case OR_AIR_PERM_LOCAL: case OR_AIR_PERM_NEXT: deg[nv++] = 1; break;
             case OR_AIR_ADD: case OR_AIR_SUB: deg[nv] = deg[st->a] > deg[st->b] ? deg[st->a] : deg[st->b]; nv++; break;
             case OR_AIR_MUL: deg[nv] = deg[st->a] + deg[st->b]; nv++; break;
             case OR_AIR_NEG: deg[nv] = deg[st->a]; nv++; break;
@@ -87,8 +96,23 @@ int or_air_log_quotient_degree(const or_air* air) {
     if (max_deg < 2) max_deg = 2;
     return (int)p3_log2(max_deg - 1);
 }
+/* extension columns of the permutation trace: one per batch of two interactions + the running sum */
+static uint32_t perm_ext_cols(const or_air* air) { return air->n_interactions ? (air->n_interactions + 1) / 2 + 1 : 0; }
+/* powers of beta the challenge vector carries: beta^0 .. beta^K, K = the longest value tuple */
+static uint32_t perm_max_values(const or_air* air) {
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < air->n_interactions; i++) if (air->interactions[i].n_values > k) k = air->interactions[i].n_values;
+    return k;
+}
 static int air_check(const or_air* air, uint32_t width, uint32_t n_public) {
     size_t nv = 0;
+    const uint32_t pw = 4 * perm_ext_cols(air), nch = air->n_interactions ? 4 * (perm_max_values(air) + 2) : 0;
+    for (uint32_t i = 0; i < air->n_interactions; i++) {
+        const or_interaction* it = &air->interactions[i];
+        if (it->kind > 1 || it->bus >= OR_P || it->n_values > 64 || (it->n_values && !it->value_cols)) return -1;
+        if (it->mult_is_const ? it->mult >= OR_P : it->mult >= width) return -1;
+        for (uint32_t j = 0; j < it->n_values; j++) if (it->value_cols[j] >= width) return -1;
+    }
     for (size_t s = 0; s < air->n_steps; s++) {
         const or_air_step* st = &air->steps[s];
         switch (st->op) {
@@ -96,6 +120,9 @@ static int air_check(const or_air* air, uint32_t width, uint32_t n_public) {
             case OR_AIR_LOCAL: case OR_AIR_NEXT: if (st->a >= width) return -1; nv++; break;
             case OR_AIR_PUBLIC: if (st->a >= n_public) return -1; nv++; break;
             case OR_AIR_IS_FIRST_ROW: case OR_AIR_IS_LAST_ROW: case OR_AIR_IS_TRANSITION: nv++; break;
+            case OR_AIR_PERM_LOCAL: case OR_AIR_PERM_NEXT: if (st->a >= pw) return -1; nv++; break;
+            case OR_AIR_CHALLENGE: if (st->a >= nch) return -1; nv++; break;
+            case OR_AIR_CUMSUM: if (st->a >= 4 || !air->n_interactions) return -1; nv++; break;
             case OR_AIR_ADD: case OR_AIR_SUB: case OR_AIR_MUL: if (st->a >= nv || st->b >= nv) return -1; nv++; break;
             case OR_AIR_NEG: if (st->a >= nv) return -1; nv++; break;
             case OR_AIR_ASSERT_ZERO: if (st->a >= nv) return -1; break;
@@ -106,8 +133,9 @@ static int air_check(const or_air* air, uint32_t width, uint32_t n_public) {
 }
 /* folder.rs: `assert_zero(x)`: accumulator = accumulator * alpha + x, in the order the AIR asserts.  One evaluator
  * for both sides: the prover's rows are base-field values embedded in the extension, the verifier's are openings. */
+typedef struct { const fp4 *local, *next; const fp* chal; const fp* cumsum; } perm_view;   /* NULLs for a table without interactions */
 static fp4 air_fold(const or_air* air, const fp4* local, const fp4* next, const fp* pub, fp4 is_first, fp4 is_last,
-                    fp4 is_trans, fp4 alpha, fp4* vals) {
+                    fp4 is_trans, fp4 alpha, fp4* vals, const perm_view* pv) {
     size_t nv = 0;
     fp4 acc = fp4_zero();
     for (size_t s = 0; s < air->n_steps; s++) {
@@ -120,6 +148,10 @@ static fp4 air_fold(const or_air* air, const fp4* local, const fp4* next, const 
             case OR_AIR_IS_FIRST_ROW: vals[nv++] = is_first; break;
             case OR_AIR_IS_LAST_ROW: vals[nv++] = is_last; break;
             case OR_AIR_IS_TRANSITION: vals[nv++] = is_trans; break;
+            case OR_AIR_PERM_LOCAL: vals[nv++] = pv->local[st->a]; break;
+            case OR_AIR_PERM_NEXT: vals[nv++] = pv->next[st->a]; break;
+            case OR_AIR_CHALLENGE: vals[nv++] = fp4_from_fp(pv->chal[st->a]); break;
+            case OR_AIR_CUMSUM: vals[nv++] = fp4_from_fp(pv->cumsum[st->a]); break;
             case OR_AIR_ADD: vals[nv] = fp4_add(vals[st->a], vals[st->b]); nv++; break;
             case OR_AIR_SUB: vals[nv] = fp4_sub(vals[st->a], vals[st->b]); nv++; break;
             case OR_AIR_MUL: vals[nv] = fp4_mul(vals[st->a], vals[st->b]); nv++; break;
@@ -179,7 +211,45 @@ typedef struct {
     fp* chunk_lde[16];            /* qd matrices (N << blowup) x 4 */
     fp4 *y_local, *y_next;        /* opened values */
     fp4 y_chunk[16][4];
+    uint32_t pw;                  /* base columns of the permutation trace (0: none) */
+    fp* perm;                     /* N x pw row-major */
+    fp* perm_lde;                 /* (N << blowup) x pw */
+    fp4 *yp_local, *yp_next;
+    fp cumsum[4];
 } tstate;
+
+/* the challenge vector of the permutation argument: [alpha | beta^0 | ... | beta^K] as base components */
+static void perm_challenges(fp4 pa, fp4 pb, uint32_t K, fp* out) {
+    memcpy(out, pa.c, 16);
+    fp4 cur = fp4_one();
+    for (uint32_t j = 0; j <= K; j++) { memcpy(out + 4 * (j + 1), cur.c, 16); cur = fp4_mul(cur, pb); }
+}
+/* sp1-core generate_permutation_trace (RECALLED): per row and batch of two interactions the sum of +-mult / rlc,
+ * rlc = alpha + sum_j beta^j x_j (x_0 = the bus, then the values); last column = inclusive running sum of the row totals */
+static void perm_trace(const or_air* air, const fp* main, size_t n, size_t w, const fp* chal, fp* perm, fp* cumsum) {
+    const uint32_t nb = (air->n_interactions + 1) / 2, pw = 4 * (nb + 1);
+    const fp4* C = (const fp4*)chal;   /* C[0] = alpha, C[1 + j] = beta^j */
+    fp4 phi = fp4_zero();
+    for (size_t r = 0; r < n; r++) {
+        fp4 row_sum = fp4_zero();
+        for (uint32_t b = 0; b < nb; b++) {
+            fp4 entry = fp4_zero();
+            for (uint32_t i = 2 * b; i < 2 * b + 2 && i < air->n_interactions; i++) {
+                const or_interaction* it = &air->interactions[i];
+                fp4 rlc = fp4_add(C[0], fp4_scale(C[1], fp_from_u32(it->bus)));
+                for (uint32_t j = 0; j < it->n_values; j++) rlc = fp4_add(rlc, fp4_scale(C[2 + j], main[r * w + it->value_cols[j]]));
+                fp m = it->mult_is_const ? fp_from_u32(it->mult) : main[r * w + it->mult];
+                fp4 term = fp4_scale(fp4_inv(rlc), m);
+                entry = it->kind == 0 ? fp4_add(entry, term) : fp4_sub(entry, term);
+            }
+            memcpy(perm + r * pw + 4 * b, entry.c, 16);
+            row_sum = fp4_add(row_sum, entry);
+        }
+        phi = fp4_add(phi, row_sum);
+        memcpy(perm + r * pw + 4 * nb, phi.c, 16);
+    }
+    memcpy(cumsum, phi.c, 16);
+}
 
 /* LagrangeSelectors at a point of the extension (domain.rs selectors_at_point; the prover's selectors_on_coset are
  * the same expressions at base-field points): the trace domain is the subgroup H of order 2^log_n */
@@ -227,6 +297,39 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
     wv_push(&pf, tnodes + 8, 8);
     ch_observe_n(&ch, tnodes + 8, 8);
     for (uint32_t t = 0; t < n_tables; t++) ch_observe_n(&ch, tables[t].public_values, tables[t].n_public);
+
+    /* ---- permutation traces (only when some table lists interactions: proofs without any keep their bytes) */
+    uint32_t n_perm = 0, Hp = 0, Kmax = 0;
+    for (uint32_t t = 0; t < n_tables; t++) if (tables[t].air->n_interactions) {
+        n_perm++;
+        if (perm_max_values(tables[t].air) > Kmax) Kmax = perm_max_values(tables[t].air);
+    }
+    or_matrix* pmats = (or_matrix*)calloc(n_perm + 1, sizeof(or_matrix));
+    uint32_t* pnodes = NULL;
+    fp* pchal = (fp*)calloc(4 * (Kmax + 2), sizeof(fp));
+    if (n_perm) {
+        const fp4 pa = ch_sample_ext(&ch), pb = ch_sample_ext(&ch);
+        perm_challenges(pa, pb, Kmax, pchal);
+        uint32_t pm = 0;
+        for (uint32_t t = 0; t < n_tables; t++) {
+            const or_p3_table* tb = &tables[t];
+            if (!tb->air->n_interactions) continue;
+            size_t n = (size_t)1 << tb->log_height, H = n << blow;
+            ts[t].pw = 4 * perm_ext_cols(tb->air);
+            ts[t].perm = (fp*)malloc(n * ts[t].pw * sizeof(fp));
+            perm_trace(tb->air, tb->trace, n, tb->width, pchal, ts[t].perm, ts[t].cumsum);
+            ts[t].perm_lde = (fp*)malloc(H * ts[t].pw * sizeof(fp));
+            or_pcs_coset_lde_rows(ts[t].perm_lde, ts[t].perm, n, ts[t].pw);
+            pmats[pm].values = ts[t].perm_lde; pmats[pm].height = (uint32_t)H; pmats[pm].width = ts[t].pw; pmats[pm].row_major = 1;
+            pm++;
+            if (H > Hp) Hp = (uint32_t)H;
+        }
+        pnodes = (uint32_t*)malloc((size_t)2 * Hp * 8 * 4);
+        or_mmcs_commit(pmats, n_perm, pnodes);
+        wv_push(&pf, pnodes + 8, 8);
+        ch_observe_n(&ch, pnodes + 8, 8);
+        for (uint32_t t = 0; t < n_tables; t++) if (ts[t].pw) { wv_push(&pf, ts[t].cumsum, 4); ch_observe_n(&ch, ts[t].cumsum, 4); }
+    }
     const fp4 alpha = ch_sample_ext(&ch);
 
     /* ---- quotient: values on s * H_(N qd), split, chunk LDEs, commitment */
@@ -246,6 +349,10 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
             fp4* local = (fp4*)malloc(w * sizeof(fp4));
             fp4* next = (fp4*)malloc(w * sizeof(fp4));
             fp4* vals = (fp4*)malloc((tb->air->n_steps + 1) * sizeof(fp4));
+            const size_t pw = ts[t].pw;
+            fp4* pl = (fp4*)malloc((pw + 1) * sizeof(fp4));
+            fp4* pn = (fp4*)malloc((pw + 1) * sizeof(fp4));
+            perm_view pv = {pl, pn, pchal, ts[t].cumsum};
 #pragma omp for schedule(static)
             for (size_t i = 0; i < nq; i++) {
                 /* get_evaluations_on_domain: the quotient domain's point i is LDE row bitrev(i * (2^blow / qd)) */
@@ -254,12 +361,16 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
                     local[c] = fp4_from_fp(ts[t].lde[r0 * w + c]);
                     next[c] = fp4_from_fp(ts[t].lde[r1 * w + c]);
                 }
+                for (size_t c = 0; c < pw; c++) {
+                    pl[c] = fp4_from_fp(ts[t].perm_lde[r0 * pw + c]);
+                    pn[c] = fp4_from_fp(ts[t].perm_lde[r1 * pw + c]);
+                }
                 fp4 x = fp4_from_fp(fp_mul(shift, fp_pow(gq, i))), f, l, tr, iz;
                 selectors(x, k, &f, &l, &tr, &iz);
-                fp4 q = fp4_mul(air_fold(tb->air, local, next, tb->public_values, f, l, tr, alpha, vals), iz);
+                fp4 q = fp4_mul(air_fold(tb->air, local, next, tb->public_values, f, l, tr, alpha, vals, &pv), iz);
                 memcpy(chunk[i & (qd - 1)] + (i >> lqd) * 4, q.c, 16);   /* split_evals: chunk j = rows j, j + qd, ... */
             }
-            free(vals); free(next); free(local);
+            free(pn); free(pl); free(vals); free(next); free(local);
         }
         for (size_t j = 0; j < qd; j++) {
             /* commit(domain = s g_q^j H_N, evals): shift of the LDE = generator / domain.shift = g_q^-j */
@@ -295,7 +406,18 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
         num_reduced[lh] += 2 * w;
         ts[t].y_local = ys; ts[t].y_next = ys + w;
     }
-    for (uint32_t t = 0; t < n_tables; t++) {          /* round 1: the quotient chunks at zeta */
+    for (uint32_t t = 0; t < n_tables; t++) {          /* round 1 (with interactions): the permutation traces at zeta and zeta * g */
+        if (!ts[t].pw) continue;
+        const unsigned lh = ts[t].log_n + blow;
+        const size_t H = (size_t)1 << lh, w = ts[t].pw;
+        fp4 pts[2]; pts[0] = zeta; pts[1] = fp4_scale(zeta, or_rou_fwd(ts[t].log_n));
+        fp4* ys = (fp4*)malloc(2 * w * sizeof(fp4));
+        for (int j = 0; j < 2; j++) or_pcs_eval_at(ys + j * w, ts[t].perm_lde, H, w, pts[j].c);
+        or_pcs_reduce_openings(ro[lh], ts[t].perm_lde, H, w, 2, pts[0].c, ys[0].c, alpha2.c, num_reduced[lh]);
+        num_reduced[lh] += 2 * w;
+        ts[t].yp_local = ys; ts[t].yp_next = ys + w;
+    }
+    for (uint32_t t = 0; t < n_tables; t++) {          /* last round: the quotient chunks at zeta */
         const unsigned lh = ts[t].log_n + blow;
         const size_t H = (size_t)1 << lh;
         for (size_t j = 0; j < ((size_t)1 << ts[t].lqd); j++) {
@@ -307,6 +429,7 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
     for (uint32_t t = 0; t < n_tables; t++) {
         wv_push(&pf, ts[t].y_local[0].c, 4 * ts[t].width);
         wv_push(&pf, ts[t].y_next[0].c, 4 * ts[t].width);
+        if (ts[t].pw) { wv_push(&pf, ts[t].yp_local[0].c, 4 * ts[t].pw); wv_push(&pf, ts[t].yp_next[0].c, 4 * ts[t].pw); }
         for (size_t j = 0; j < ((size_t)1 << ts[t].lqd); j++) wv_push(&pf, ts[t].y_chunk[j][0].c, 16);
     }
 
@@ -344,6 +467,7 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
     for (unsigned q = 0; q < g_or.queries && rc == 0; q++) {
         uint32_t index = ch_sample_bits(&ch, log_max);
         mmcs_open(tmats, n_tables, tnodes, Ht, index >> (log_max - p3_log2(Ht)), &pf);
+        if (n_perm) mmcs_open(pmats, n_perm, pnodes, Hp, index >> (log_max - p3_log2(Hp)), &pf);
         mmcs_open(qmats, n_chunks, qnodes, Hq, index >> (log_max - p3_log2(Hq)), &pf);
         for (unsigned rd = 0; rd < n_rounds; rd++) {
             uint32_t idx = index >> rd, pair = idx >> 1;
@@ -359,8 +483,10 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
     for (int i = 0; i < 32; i++) free(ro[i]);
     for (uint32_t t = 0; t < n_tables; t++) {
         free(ts[t].lde); free(ts[t].y_local);
+        free(ts[t].perm); free(ts[t].perm_lde); free(ts[t].yp_local);
         for (int j = 0; j < 16; j++) free(ts[t].chunk_lde[j]);
     }
+    free(pchal); free(pnodes); free(pmats);
     free(qnodes); free(tnodes); free(qmats); free(tmats); free(ts);
     if (rc != 0) { free(pf.p); return rc; }
     *proof_out = pf.p; *words_out = pf.n;
@@ -370,7 +496,7 @@ int or_p3_prove(const or_p3_table* tables, uint32_t n_tables, const fp* init, si
 /* ---------------------------------------------------------------- verifier (uni-stark verifier.rs, two_adic_pcs.rs
  * verify, p3-fri verifier.rs).  0 = accept; reason codes: 1 malformed / short / non-canonical word, 2 shape
  * mismatch, 3 constraint identity (OodEvaluationMismatch), 4 proof of work, 5 input opening, 6 commit-phase
- * opening, 7 final polynomial */
+ * opening, 7 final polynomial, 8 the tables' cumulative sums do not add up to zero */
 typedef struct { const uint32_t* p; size_t n, pos; int bad; } rd_t;
 static const uint32_t* rd_take(rd_t* r, size_t n) {
     static const uint32_t zeros[64] = {0};
@@ -402,15 +528,50 @@ int or_p3_verify(const or_p3_table* tables, uint32_t n_tables, const fp* init, s
     if (r.bad) return 1;
     ch_observe_n(&ch, troot, 8);
     for (uint32_t t = 0; t < n_tables; t++) ch_observe_n(&ch, tables[t].public_values, tables[t].n_public);
+    uint32_t n_perm = 0, Kmax = 0, pwid[32];
+    unsigned log_pmax = 0;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        pwid[t] = 4 * perm_ext_cols(tables[t].air);
+        if (!pwid[t]) continue;
+        n_perm++;
+        if (perm_max_values(tables[t].air) > Kmax) Kmax = perm_max_values(tables[t].air);
+        if (log_n[t] + blow > log_pmax) log_pmax = log_n[t] + blow;
+    }
+    const uint32_t* proot = NULL;
+    const fp* cumsum[32];
+    fp pchal[4 * 66];
+    memset(pchal, 0, sizeof pchal);
+    memset(cumsum, 0, sizeof cumsum);
+    if (n_perm) {
+        const fp4 pa = ch_sample_ext(&ch), pb = ch_sample_ext(&ch);
+        perm_challenges(pa, pb, Kmax, pchal);
+        proot = rd_take(&r, 8);
+        if (r.bad) return 1;
+        ch_observe_n(&ch, proot, 8);
+        fp4 total = fp4_zero();
+        for (uint32_t t = 0; t < n_tables; t++) if (pwid[t]) {
+            cumsum[t] = rd_take(&r, 4);
+            if (r.bad) return 1;
+            ch_observe_n(&ch, cumsum[t], 4);
+            total = fp4_add(total, *(const fp4*)cumsum[t]);
+        }
+        if (!fp4_eq(total, fp4_zero())) return 8;
+    }
     const fp4 alpha = ch_sample_ext(&ch);
     const uint32_t* qroot = rd_take(&r, 8);
     if (r.bad) return 1;
     ch_observe_n(&ch, qroot, 8);
     const fp4 zeta = ch_sample_ext(&ch);
-    const fp4 *y_local[32], *y_next[32], *y_chunk[32];
+    const fp4 *y_local[32], *y_next[32], *y_chunk[32], *yp_local[32], *yp_next[32];
     for (uint32_t t = 0; t < n_tables; t++) {
         y_local[t] = (const fp4*)rd_take(&r, 4 * (size_t)tables[t].width);
         y_next[t] = (const fp4*)rd_take(&r, 4 * (size_t)tables[t].width);
+        yp_local[t] = yp_next[t] = NULL;
+        if (pwid[t]) {
+            yp_local[t] = (const fp4*)rd_take(&r, 4 * (size_t)pwid[t]);
+            yp_next[t] = (const fp4*)rd_take(&r, 4 * (size_t)pwid[t]);
+            if (r.bad || !yp_local[t] || !yp_next[t]) return 1;
+        }
         y_chunk[t] = (const fp4*)rd_take(&r, (size_t)16 << lqd[t]);
         if (r.bad || !y_local[t] || !y_next[t] || !y_chunk[t]) return 1;
     }
@@ -438,7 +599,8 @@ int or_p3_verify(const or_p3_table* tables, uint32_t n_tables, const fp* init, s
         fp4 f, l, tr, iz;
         selectors(zeta, k, &f, &l, &tr, &iz);
         fp4* vals = (fp4*)malloc((tables[t].air->n_steps + 1) * sizeof(fp4));
-        fp4 folded = air_fold(tables[t].air, y_local[t], y_next[t], tables[t].public_values, f, l, tr, alpha, vals);
+        perm_view pv = {yp_local[t], yp_next[t], pchal, cumsum[t]};
+        fp4 folded = air_fold(tables[t].air, y_local[t], y_next[t], tables[t].public_values, f, l, tr, alpha, vals, &pv);
         free(vals);
         if (!fp4_eq(fp4_mul(folded, iz), quotient)) return 3;
     }
@@ -464,19 +626,25 @@ int or_p3_verify(const or_p3_table* tables, uint32_t n_tables, const fp* init, s
     for (uint32_t t = 0; t < n_tables; t++) n_chunks += 1u << lqd[t];
     uint32_t *th = (uint32_t*)malloc(n_tables * 4), *tw = (uint32_t*)malloc(n_tables * 4);
     uint32_t *qh = (uint32_t*)malloc(n_chunks * 4), *qw = (uint32_t*)malloc(n_chunks * 4);
-    size_t trow = 0, qrow = 4 * (size_t)n_chunks;
-    for (uint32_t t = 0, m = 0; t < n_tables; t++) {
+    uint32_t ph[32], pwd[32];
+    size_t trow = 0, qrow = 4 * (size_t)n_chunks, prow = 0;
+    for (uint32_t t = 0, m = 0, pm = 0; t < n_tables; t++) {
         th[t] = 1u << (log_n[t] + blow); tw[t] = tables[t].width; trow += tables[t].width;
+        if (pwid[t]) { ph[pm] = th[t]; pwd[pm] = pwid[t]; pm++; prow += pwid[t]; }
         for (uint32_t j = 0; j < (1u << lqd[t]); j++, m++) { qh[m] = th[t]; qw[m] = 4; }
     }
     int rc = 0;
     for (unsigned q = 0; q < g_or.queries && rc == 0; q++) {
         const uint32_t index = ch_sample_bits(&ch, log_max);
-        /* both batches have the global maximum height here (every table is in both) */
+        /* the trace and quotient batches have the global maximum height (every table is in both); the permutation
+         * batch only holds the tables with interactions */
         const uint32_t* trows = rd_take(&r, trow); const uint32_t* tpath = rd_take(&r, (size_t)8 * log_max);
+        const uint32_t *prows = NULL, *ppath = NULL;
+        if (n_perm) { prows = rd_take(&r, prow); ppath = rd_take(&r, (size_t)8 * log_pmax); if (r.bad || !prows || !ppath) { rc = 1; break; } }
         const uint32_t* qrows = rd_take(&r, qrow); const uint32_t* qpath = rd_take(&r, (size_t)8 * log_max);
         if (r.bad || !trows || !tpath || !qrows || !qpath) { rc = 1; break; }
         if (or_mmcs_verify(th, tw, n_tables, index, trows, tpath, troot) != 0) { rc = 5; break; }
+        if (n_perm && or_mmcs_verify(ph, pwd, n_perm, index >> (log_max - log_pmax), prows, ppath, proot) != 0) { rc = 5; break; }
         if (or_mmcs_verify(qh, qw, n_chunks, index, qrows, qpath, qroot) != 0) { rc = 5; break; }
         fp4 rop[32], apow[32]; int used[32];
         for (int i = 0; i < 32; i++) { rop[i] = fp4_zero(); apow[i] = fp4_one(); used[i] = 0; }
@@ -493,6 +661,16 @@ int or_p3_verify(const or_p3_table* tables, uint32_t n_tables, const fp* init, s
             for (uint32_t c = 0; c < tables[t].width; c++) P3_REDUCE(lh, x, zeta, y_local[t][c], trows[at + c]);
             for (uint32_t c = 0; c < tables[t].width; c++) P3_REDUCE(lh, x, zn, y_next[t][c], trows[at + c]);
             at += tables[t].width;
+        }
+        at = 0;
+        for (uint32_t t = 0; t < n_tables; t++) {
+            if (!pwid[t]) continue;
+            const unsigned lh = log_n[t] + blow;
+            const fp x = fp_mul(shift, fp_pow(or_rou_fwd(lh), p3_bitrev(index >> (log_max - lh), lh)));
+            const fp4 zn = fp4_scale(zeta, or_rou_fwd(log_n[t]));
+            for (uint32_t c = 0; c < pwid[t]; c++) P3_REDUCE(lh, x, zeta, yp_local[t][c], prows[at + c]);
+            for (uint32_t c = 0; c < pwid[t]; c++) P3_REDUCE(lh, x, zn, yp_next[t][c], prows[at + c]);
+            at += pwid[t];
         }
         at = 0;
         for (uint32_t t = 0; t < n_tables; t++) {

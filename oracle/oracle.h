@@ -214,9 +214,17 @@ int or_mmcs_verify(const uint32_t* heights, const uint32_t* widths, uint32_t n, 
  * rk_p3_prove / rk_p3_verify.  An AIR is a step list: every step but ASSERT_ZERO pushes one value; a, b name
  * earlier values (CONST: a = canonical integer; LOCAL / NEXT: a = column; PUBLIC: a = index). ---- */
 enum { OR_AIR_CONST = 0, OR_AIR_LOCAL = 1, OR_AIR_NEXT = 2, OR_AIR_PUBLIC = 3, OR_AIR_IS_FIRST_ROW = 4, OR_AIR_IS_LAST_ROW = 5,
-       OR_AIR_IS_TRANSITION = 6, OR_AIR_ADD = 7, OR_AIR_SUB = 8, OR_AIR_MUL = 9, OR_AIR_NEG = 10, OR_AIR_ASSERT_ZERO = 11 };
+       OR_AIR_IS_TRANSITION = 6, OR_AIR_ADD = 7, OR_AIR_SUB = 8, OR_AIR_MUL = 9, OR_AIR_NEG = 10, OR_AIR_ASSERT_ZERO = 11,
+       /* the permutation (LogUp) trace of a table with interactions: base column a of its flattened extension columns on the
+        * current / next row; base component a of the challenge vector [alpha | beta^0 | beta^1 | ...]; component a of the
+        * table's cumulative sum */
+       OR_AIR_PERM_LOCAL = 12, OR_AIR_PERM_NEXT = 13, OR_AIR_CHALLENGE = 14, OR_AIR_CUMSUM = 15 };
 typedef struct { uint32_t op, a, b; } or_air_step;
-typedef struct { const or_air_step* steps; size_t n_steps; } or_air;
+/* one interaction of a table with a bus (sp1-core lookup/interaction.rs, RECALLED): the tuple (bus, values...) is sent
+ * (kind 0) or received (kind 1) `multiplicity` times on every row; values are main-trace columns, the multiplicity a
+ * column or a constant */
+typedef struct { uint32_t kind, bus, mult_is_const, mult, n_values; const uint32_t* value_cols; } or_interaction;
+typedef struct { const or_air_step* steps; size_t n_steps; const or_interaction* interactions; uint32_t n_interactions; } or_air;
 typedef struct {
     const fp* trace;               /* row-major 2^log_height x width (prover only) */
     uint32_t log_height, width;    /* the verifier takes log_height from the proof */

@@ -8,7 +8,6 @@
 #![allow(non_camel_case_types)]
 #![allow(clippy::missing_safety_doc)]
 use std::os::raw::{c_char, c_int, c_void};
-
 pub const RK_ECALL_HALT: c_int = 0;
 pub const RK_ECALL_READ: c_int = 1;
 pub const RK_ECALL_COMMIT: c_int = 2;
@@ -55,6 +54,10 @@ pub const RK_AIR_SUB: rk_air_op = 8;
 pub const RK_AIR_MUL: rk_air_op = 9;
 pub const RK_AIR_NEG: rk_air_op = 10;
 pub const RK_AIR_ASSERT_ZERO: rk_air_op = 11;
+pub const RK_AIR_PERM_LOCAL: rk_air_op = 12;
+pub const RK_AIR_PERM_NEXT: rk_air_op = 13;
+pub const RK_AIR_CHALLENGE: rk_air_op = 14;
+pub const RK_AIR_CUMSUM: rk_air_op = 15;
 
 pub type rk_kclass = c_int;
 pub const RK_KCLASS_HASH_ROWS: rk_kclass = 0;
@@ -330,6 +333,7 @@ pub struct rk_p3_timing {
     pub fri: f32,
     pub query: f32,
     pub total: f32,
+    pub perm: f32,
 }
 
 #[repr(C)]
@@ -440,6 +444,7 @@ extern "C" {
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
     pub fn rk_air_create(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, out: *mut *mut rk_air) -> c_int;
+    pub fn rk_air_create_lookup(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, interaction_words: *const u32, n_interactions: u32, n_words: usize, out: *mut *mut rk_air) -> c_int;
     pub fn rk_air_destroy(air: *mut rk_air) -> c_int;
     pub fn rk_air_get_info(air: *const rk_air, out: *mut rk_air_info) -> c_int;
     pub fn rk_air_compile(air: *mut rk_air, ctx: *mut rk_ctx) -> c_int;

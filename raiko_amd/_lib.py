@@ -142,7 +142,7 @@ class RkP3SessionOpts(C.Structure):
 
 
 class RkP3Timing(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("lde", "commit", "quotient", "open", "fri", "query", "total")]
+    _fields_ = [(n, C.c_float) for n in ("lde", "commit", "quotient", "open", "fri", "query", "total", "perm")]
 
 
 class RkExecOpts(C.Structure):
@@ -248,6 +248,7 @@ SYMBOLS = {
     "rk_program_source": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "rk_program_poly_ext": (C.c_int, [_vp, _u32, u32p, u32p, _sz, u32p, _u32, u32p, _u32, u32p]),
     "rk_air_create": (C.c_int, [_vp, _sz, _u32, _u32, C.POINTER(_vp)]),
+    "rk_air_create_lookup": (C.c_int, [_vp, _sz, _u32, _u32, u32p, _u32, _sz, C.POINTER(_vp)]),
     "rk_air_destroy": (C.c_int, [_vp]),
     "rk_air_get_info": (C.c_int, [_vp, C.POINTER(RkAirInfo)]),
     "rk_air_compile": (C.c_int, [_vp, _vp]),

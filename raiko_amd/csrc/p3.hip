@@ -3,8 +3,8 @@
 // provers/sp1/driver/src/lib.rs:44-57, shard knobs docs/README_Sp1.md:19-32) as far as it exists without SP1's chips:
 // Plonky3's p3-uni-stark prover.rs / verifier.rs on p3-fri's TwoAdicFriPcs with a DuplexChallenger, several tables
 // under shared challenges the way sp1-core proves the chips of a shard (Plonky3@88ea2b8, reference
-// Cargo.lock:4889-5127; the crates are outside the reference tree: RECALLED).  SP1's chips, its permutation argument
-// and its recursion VM are NOT here.
+// Cargo.lock:4889-5127; the crates are outside the reference tree: RECALLED), with sp1-core's permutation (LogUp)
+// argument between the tables (rk_air_create_lookup).  SP1's chips and its recursion VM are NOT here.
 //
 // Device side of one proof:
 //   trace LDE      rows -> columns, iNTT (coset shift fused), expanding NTT (kernels_pcs.hip): the LDE stays the way the
@@ -14,6 +14,9 @@
 //                  the data exists just to reorder it (the round-2 operator form, rk_pcs_coset_lde_rows, spends 30 % of
 //                  its time transposing back to rows)
 //   commitments    rk_mmcs_commit (mmcs.hip)
+//   lookups        perm_entries_kernel (one lane per row: the batches' sum of +-mult / (alpha + sum beta^j x_j), extension
+//                  inverses in registers) writes the permutation trace column-major; the running-sum column is four base
+//                  prefix sums (psum_* kernels: workgroup totals, one carry pass, apply); the same LDE / commit as a trace
 //   quotient       the AIR is translated once into an rk_program (circuit_program.hip): LOCAL / NEXT are taps of the
 //                  column-major LDE (NEXT = one trace row ahead, cyclic), the three selectors are taps of three
 //                  columns written by selector_kernel, the asserts one AND_EQZ chain with Horner-ordered powers of
@@ -39,6 +42,8 @@
 
 struct rk_air {
     std::vector<rk_air_step> steps;
+    std::vector<uint32_t> lookups;   // flat interactions (rk_air_create_lookup); mult / bus constants already Montgomery words
+    uint32_t n_lookups = 0, perm_width = 0, n_chal = 0;   // base columns of the permutation trace, words of the challenge vector
     uint32_t width = 0, n_public = 0;
     rk_air_info info{};
     uint32_t sel_mask = 0;   // bit c: selector column c (is_first_row, is_last_row, is_transition) is named by the list
@@ -90,7 +95,7 @@ struct Challenger {
 };
 
 // ---------------------------------------------------------------- AIR: checks, symbolic degree, host evaluation
-int air_scan(const rk_air_step* steps, size_t n, uint32_t width, uint32_t n_public, rk_air_info* info) {
+int air_scan(const rk_air_step* steps, size_t n, uint32_t width, uint32_t n_public, uint32_t perm_width, uint32_t n_chal, rk_air_info* info) {
     std::vector<uint32_t> deg;
     deg.reserve(n);
     uint32_t max_deg = 0, n_con = 0;
@@ -103,6 +108,9 @@ int air_scan(const rk_air_step* steps, size_t n, uint32_t width, uint32_t n_publ
             case RK_AIR_PUBLIC: if (st.a >= n_public) return RK_ERR_INVALID; deg.push_back(0); break;
             case RK_AIR_IS_FIRST_ROW: case RK_AIR_IS_LAST_ROW: deg.push_back(1); break;
             case RK_AIR_IS_TRANSITION: deg.push_back(0); break;
+            case RK_AIR_PERM_LOCAL: case RK_AIR_PERM_NEXT: if (st.a >= perm_width) return RK_ERR_INVALID; deg.push_back(1); break;
+            case RK_AIR_CHALLENGE: if (st.a >= n_chal) return RK_ERR_INVALID; deg.push_back(0); break;
+            case RK_AIR_CUMSUM: if (st.a >= 4 || perm_width == 0) return RK_ERR_INVALID; deg.push_back(0); break;
             case RK_AIR_ADD: case RK_AIR_SUB:
                 if (st.a >= nv || st.b >= nv) return RK_ERR_INVALID;
                 deg.push_back(std::max(deg[st.a], deg[st.b]));
@@ -129,8 +137,12 @@ int air_scan(const rk_air_step* steps, size_t n, uint32_t width, uint32_t n_publ
 }
 
 // folder.rs on extension elements (the verifier's side): accumulator = accumulator * alpha + x per assert, in order
+struct PermView {   // the verifier's view of a table's lookup argument (all null without one)
+    const Ext *local = nullptr, *next = nullptr;
+    const uint32_t *chal = nullptr, *cumsum = nullptr;
+};
 Ext air_fold(const rk_air& air, const Ext* local, const Ext* next, const uint32_t* pub, const Ext& is_first, const Ext& is_last,
-             const Ext& is_trans, const Ext& alpha, uint32_t wm) {
+             const Ext& is_trans, const Ext& alpha, uint32_t wm, const PermView& pv) {
     std::vector<Ext> v;
     v.reserve(air.steps.size());
     Ext acc = bb::ext_zero();
@@ -143,6 +155,10 @@ Ext air_fold(const rk_air& air, const Ext* local, const Ext* next, const uint32_
             case RK_AIR_IS_FIRST_ROW: v.push_back(is_first); break;
             case RK_AIR_IS_LAST_ROW: v.push_back(is_last); break;
             case RK_AIR_IS_TRANSITION: v.push_back(is_trans); break;
+            case RK_AIR_PERM_LOCAL: v.push_back(pv.local[st.a]); break;
+            case RK_AIR_PERM_NEXT: v.push_back(pv.next[st.a]); break;
+            case RK_AIR_CHALLENGE: v.push_back(bb::ext_from(pv.chal[st.a])); break;
+            case RK_AIR_CUMSUM: v.push_back(bb::ext_from(pv.cumsum[st.a])); break;
             case RK_AIR_ADD: v.push_back(bb::add(v[st.a], v[st.b])); break;
             case RK_AIR_SUB: v.push_back(bb::sub(v[st.a], v[st.b])); break;
             case RK_AIR_MUL: v.push_back(bb::mul(v[st.a], v[st.b], wm)); break;
@@ -194,6 +210,111 @@ __global__ void add_words_kernel(uint32_t* __restrict__ io, const uint32_t* __re
     if (i < n) io[i] = bb::add(io[i], in[i]);
 }
 
+// ---- lookups (sp1-core generate_permutation_trace, RECALLED).  desc = the challenge vector [alpha | beta^0 | beta^1 ..]
+// (4 words each, n_chal words) followed by the flat interactions (kind, bus, mult_is_const, mult, n_values, columns...;
+// constants as Montgomery words).  One lane per row of the row-major main trace; out = 4 (nb + 1) columns of n words:
+// the nb batch entries, then the row totals (the prefix sums turn those into the running sum in place).
+struct PermArgs {
+    uint32_t* out;
+    const uint32_t* trace;
+    const uint32_t* desc;
+    size_t n, w;
+    uint32_t n_chal, n_lookups, wm;
+};
+__global__ void perm_entries_kernel(PermArgs a) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const uint32_t* row = a.trace + r * a.w;
+    const uint32_t* ch = a.desc;
+    const uint32_t* d = a.desc + a.n_chal;
+    const Ext alpha{{ch[0], ch[1], ch[2], ch[3]}};
+    Ext total = bb::ext_zero(), entry = bb::ext_zero();
+    const uint32_t nb = (a.n_lookups + 1) / 2;
+    for (uint32_t i = 0; i < a.n_lookups; i++) {
+        const uint32_t kind = d[0], bus = d[1], is_const = d[2], mult = d[3], nv = d[4];
+        Ext rlc = bb::add(alpha, bb::scale(Ext{{ch[4], ch[5], ch[6], ch[7]}}, bus));
+        for (uint32_t j = 0; j < nv; j++) {
+            const uint32_t* b = ch + 8 + 4 * j;
+            rlc = bb::add(rlc, bb::scale(Ext{{b[0], b[1], b[2], b[3]}}, row[d[5 + j]]));
+        }
+        const uint32_t m = is_const ? mult : row[mult];
+        const Ext term = bb::scale(bb::inv(rlc, a.wm), kind == 0 ? m : bb::neg(m));
+        entry = bb::add(entry, term);
+        d += 5 + nv;
+        if ((i & 1u) || i + 1 == a.n_lookups) {
+            const uint32_t b = i >> 1;
+            for (int k = 0; k < 4; k++) a.out[(size_t)(4 * b + k) * a.n + r] = entry.c[k];
+            total = bb::add(total, entry);
+            entry = bb::ext_zero();
+        }
+    }
+    for (int k = 0; k < 4; k++) a.out[(size_t)(4 * nb + k) * a.n + r] = total.c[k];
+}
+
+// inclusive prefix sums of `cols` columns of n words (blockIdx.y = column), in place: workgroup totals, one carry pass
+// per column, apply
+constexpr int PS_TPB = 256, PS_CH = 8, PS_BLOCK = PS_TPB * PS_CH;
+__device__ uint32_t psum_block_scan(uint32_t v, uint32_t* sh) {   // inclusive, across the workgroup
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < PS_TPB; d <<= 1) {
+        const uint32_t o = t >= d ? sh[t - d] : 0u;
+        __syncthreads();
+        if (t >= d) {
+            v = bb::add(o, v);
+            sh[t] = v;
+        }
+        __syncthreads();
+    }
+    return v;
+}
+__global__ void psum_totals_kernel(uint32_t* __restrict__ totals, const uint32_t* __restrict__ io, size_t n, size_t n_blocks) {
+    __shared__ uint32_t sh[PS_TPB];
+    const uint32_t* col = io + (size_t)blockIdx.y * n;
+    const size_t base = (size_t)blockIdx.x * PS_BLOCK;
+    uint32_t acc = 0;
+    for (int j = 0; j < PS_CH; j++) {   // lane t takes elements t, t + 256, ...: coalesced; only the sum matters here
+        const size_t i = base + (size_t)j * PS_TPB + threadIdx.x;
+        if (i < n) acc = bb::add(acc, col[i]);
+    }
+    acc = psum_block_scan(acc, sh);
+    if (threadIdx.x == PS_TPB - 1) totals[(size_t)blockIdx.y * n_blocks + blockIdx.x] = acc;
+}
+__global__ void psum_carry_kernel(uint32_t* totals, size_t n_blocks) {   // totals[b] <- sum of the blocks before b
+    __shared__ uint32_t sh[PS_TPB];
+    uint32_t* t = totals + (size_t)blockIdx.x * n_blocks;
+    const size_t per = (n_blocks + PS_TPB - 1) / PS_TPB;
+    const size_t lo0 = (size_t)threadIdx.x * per, lo = lo0 < n_blocks ? lo0 : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    uint32_t acc = 0;
+    for (size_t i = lo; i < hi; i++) acc = bb::add(acc, t[i]);
+    const uint32_t incl = psum_block_scan(acc, sh);
+    uint32_t run = bb::sub(incl, acc);
+    for (size_t i = lo; i < hi; i++) {
+        const uint32_t v = t[i];
+        t[i] = run;
+        run = bb::add(run, v);
+    }
+}
+__global__ void psum_apply_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ totals, size_t n, size_t n_blocks) {
+    __shared__ uint32_t sh[PS_TPB];
+    uint32_t* col = io + (size_t)blockIdx.y * n;
+    const size_t base = (size_t)blockIdx.x * PS_BLOCK + (size_t)threadIdx.x * PS_CH;   // lane t: 8 consecutive words (two 16 B loads)
+    uint32_t v[PS_CH];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < PS_CH; j++) {
+        v[j] = base + j < n ? col[base + j] : 0u;
+        acc = bb::add(acc, v[j]);
+        v[j] = acc;
+    }
+    const uint32_t incl = psum_block_scan(acc, sh);
+    const uint32_t carry = bb::add(bb::sub(incl, acc), totals[(size_t)blockIdx.y * n_blocks + blockIdx.x]);
+#pragma unroll
+    for (int j = 0; j < PS_CH; j++)
+        if (base + j < n) col[base + j] = bb::add(v[j], carry);
+}
+
 // every opened row / digest of a proof's query phase: job = (source address, words, destination offset); one
 // 64-lane group per job
 struct GatherJob {
@@ -243,7 +364,12 @@ struct TableState {
     DevBuf lde;                   // w columns of H natural-order evaluations (rk_matrix layout 2: committed row r at index bitrev(r))
     DevBuf chunks;                // 4 qd columns of H: the qd chunk LDEs side by side (as one matrix they hash, open and
                                   // reduce exactly like qd matrices of width 4 that follow each other in the batch)
-    std::vector<uint32_t> y;      // opened values: local 4w | next 4w | chunks 16 each
+    std::vector<uint32_t> y;      // opened values: local 4w | next 4w | [perm local 4pw | perm next 4pw] | chunks 16 each
+    size_t pw = 0;                // base columns of the permutation trace (0: the table has no lookups)
+    DevBuf staged;                // a host trace's copy in HBM, kept for the permutation trace
+    const uint32_t* d_trace = nullptr;
+    DevBuf perm;                  // pw columns of H, laid out like lde
+    uint32_t cumsum[4] = {0, 0, 0, 0};
 };
 
 double now_ms() {
@@ -251,16 +377,19 @@ double now_ms() {
 }
 
 size_t proof_bound(const rk_params& p, const rk_p3_table* t, uint32_t n, const uint32_t* lqd) {
-    size_t words = 1 + n + 16, log_max = 0, row_t = 0, row_q = 0;
+    size_t words = 1 + n + 16, log_max = 0, log_pmax = 0, row_t = 0, row_q = 0, row_p = 0;
     for (uint32_t i = 0; i < n; i++) {
-        words += 8 * (size_t)t[i].width + ((size_t)16 << lqd[i]);
+        const size_t pw = t[i].air->perm_width;
+        words += 8 * (size_t)t[i].width + 8 * pw + (pw ? 4 : 0) + ((size_t)16 << lqd[i]);
         log_max = std::max<size_t>(log_max, t[i].log_height + p.blowup_log2);
+        if (pw) log_pmax = std::max<size_t>(log_pmax, t[i].log_height + p.blowup_log2);
         row_t += t[i].width;
+        row_p += pw;
         row_q += (size_t)4 << lqd[i];
     }
     const size_t rounds = log_max - p.blowup_log2;
-    words += 1 + 8 * rounds + 4 + 1;
-    size_t per_query = row_t + row_q + 2 * 8 * log_max;
+    words += 1 + 8 * rounds + 4 + 1 + (row_p ? 8 : 0);
+    size_t per_query = row_t + row_q + 2 * 8 * log_max + (row_p ? row_p + 8 * log_pmax : 0);
     for (size_t r = 0; r < rounds; r++) per_query += 4 + 8 * (log_max - 1 - r);
     return words + per_query * p.queries;
 }
@@ -330,16 +459,17 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         s.H = s.n << blow;
         s.w = tb.width;
         pf.push_back(tb.log_height);
-        DevBuf staged;
-        const uint32_t* d_trace = tb.trace;
+        s.pw = tb.air->perm_width;
+        s.d_trace = tb.trace;
         if (!tb.on_device) {
-            RK_TRY(staged.alloc(ctx, s.n * s.w * 4));
-            RK_HIP_TRY(ctx, hipMemcpyAsync(staged.p, tb.trace, s.n * s.w * 4, hipMemcpyHostToDevice, ctx->stream));
-            d_trace = staged.u32();
+            RK_TRY(s.staged.alloc(ctx, s.n * s.w * 4));
+            RK_HIP_TRY(ctx, hipMemcpyAsync(s.staged.p, tb.trace, s.n * s.w * 4, hipMemcpyHostToDevice, ctx->stream));
+            s.d_trace = s.staged.u32();
         }
         RK_TRY(s.lde.alloc(ctx, s.H * s.w * 4));
-        RK_TRY(rk::pcs_coset_lde_cols(ctx, s.lde.u32(), d_trace, s.n, s.w));
+        RK_TRY(rk::pcs_coset_lde_cols(ctx, s.lde.u32(), s.d_trace, s.n, s.w));
         if (!tb.on_device) RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host buffer is free again
+        if (!s.pw) s.staged.reset();   // only the lookups read the rows again
         tmats[t] = rk_matrix{s.lde.u32(), (uint32_t)s.H, (uint32_t)s.w, 2};
         Ht = std::max(Ht, s.H);
         log_max = std::max(log_max, s.k + blow);
@@ -352,8 +482,75 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     push(root, 8);
     ch.observe(root, 8);
     for (uint32_t t = 0; t < n_tables; t++) ch.observe(tables[t].public_values, tables[t].n_public);
-    const Ext alpha = ch.sample_ext();
     lap(tm.commit);
+
+    // ---- lookups: permutation traces, their LDE and commitment (nothing of this without interactions)
+    std::vector<rk_matrix> pmats;
+    DevBuf pnodes;
+    size_t Hp = 0;
+    std::vector<uint32_t> pchal;   // [alpha | beta^0 | .. | beta^K]: every table reads a prefix
+    {
+        uint32_t n_chal = 0;
+        for (uint32_t t = 0; t < n_tables; t++) n_chal = std::max(n_chal, tables[t].air->n_chal);
+        if (n_chal) {
+            const Ext pa = ch.sample_ext(), pb = ch.sample_ext();
+            pchal.resize(n_chal);
+            std::memcpy(pchal.data(), pa.c, 16);
+            Ext cur = bb::ext_one();
+            for (uint32_t j = 1; 4 * j < n_chal; j++) {
+                std::memcpy(&pchal[4 * j], cur.c, 16);
+                cur = bb::mul(cur, pb, ctx->sys.wm);
+            }
+        }
+        for (uint32_t t = 0; t < n_tables && n_chal; t++) {
+            TableState& s = ts[t];
+            if (!s.pw) continue;
+            const rk_air& air = *tables[t].air;
+            std::vector<uint32_t> desc(pchal.begin(), pchal.begin() + air.n_chal);
+            desc.insert(desc.end(), air.lookups.begin(), air.lookups.end());
+            DevBuf d_desc, cols, totals;
+            RK_TRY(d_desc.alloc(ctx, desc.size() * 4));
+            RK_TRY(rk::upload(ctx, d_desc.p, desc.data(), desc.size() * 4));
+            RK_TRY(cols.alloc(ctx, s.n * s.pw * 4));
+            PermArgs a{cols.u32(), s.d_trace, d_desc.u32(), s.n, s.w, air.n_chal, air.n_lookups, ctx->sys.wm};
+            hipLaunchKernelGGL(perm_entries_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+            RK_TRY(rk::post_launch(ctx, "perm_entries_kernel"));
+            s.staged.reset();
+            // the running sum: four base prefix sums over the row totals, in place
+            const size_t nblk = (s.n + PS_BLOCK - 1) / PS_BLOCK;
+            uint32_t* phi = cols.u32() + (s.pw - 4) * s.n;
+            RK_TRY(totals.alloc(ctx, 4 * nblk * 4));
+            hipLaunchKernelGGL(psum_totals_kernel, dim3((unsigned)nblk, 4), dim3(PS_TPB), 0, ctx->stream, totals.u32(), (const uint32_t*)phi, s.n, nblk);
+            RK_TRY(rk::post_launch(ctx, "psum_totals_kernel"));
+            hipLaunchKernelGGL(psum_carry_kernel, dim3(4), dim3(PS_TPB), 0, ctx->stream, totals.u32(), nblk);
+            RK_TRY(rk::post_launch(ctx, "psum_carry_kernel"));
+            hipLaunchKernelGGL(psum_apply_kernel, dim3((unsigned)nblk, 4), dim3(PS_TPB), 0, ctx->stream, phi, (const uint32_t*)totals.u32(), s.n, nblk);
+            RK_TRY(rk::post_launch(ctx, "psum_apply_kernel"));
+            for (int k = 0; k < 4; k++)
+                RK_HIP_TRY(ctx, hipMemcpyAsync(&s.cumsum[k], phi + (size_t)k * s.n + (s.n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+            // the same LDE as a trace's, from columns
+            RK_TRY(rk::ntt_reverse(ctx, cols.u32(), s.n, s.pw, /*fuse_zk_shift=*/true));
+            RK_TRY(s.perm.alloc(ctx, s.H * s.pw * 4));
+            RK_TRY(rk::ntt_forward(ctx, s.perm.u32(), cols.u32(), s.n, s.pw, blow));
+            pmats.push_back(rk_matrix{s.perm.u32(), (uint32_t)s.H, (uint32_t)s.pw, 2});
+            Hp = std::max(Hp, s.H);
+        }
+        if (!pmats.empty()) {
+            lap(tm.perm);
+            RK_TRY(pnodes.alloc(ctx, 2 * Hp * p2::OUT * 4));
+            RK_TRY(rk_mmcs_commit(ctx, pmats.data(), (uint32_t)pmats.size(), pnodes.u32(), root));
+            RK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the cumulative sums have landed
+            push(root, 8);
+            ch.observe(root, 8);
+            for (const TableState& s : ts)
+                if (s.pw) {
+                    push(s.cumsum, 4);
+                    ch.observe(s.cumsum, 4);
+                }
+            lap(tm.commit);
+        }
+    }
+    const Ext alpha = ch.sample_ext();
 
     // ---- quotients
     std::vector<rk_matrix> qmats;
@@ -394,6 +591,18 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         dom.stride_log2[2] = blow - s.lqd;
         dom.globals = tb.public_values;
         dom.n_globals = tb.n_public;
+        std::vector<uint32_t> globals;   // lookups: public values | challenges | cumulative sum
+        if (s.pw) {
+            dom.d_cols[1] = s.perm.u32();
+            dom.group_size[1] = (uint32_t)s.pw;
+            dom.col_len[1] = s.H;
+            dom.stride_log2[1] = blow - s.lqd;
+            globals.assign(tb.public_values, tb.public_values + tb.n_public);
+            globals.insert(globals.end(), pchal.begin(), pchal.begin() + tb.air->n_chal);
+            globals.insert(globals.end(), s.cumsum, s.cumsum + 4);
+            dom.globals = globals.data();
+            dom.n_globals = (uint32_t)globals.size();
+        }
         RK_TRY(rk::program_eval_domain(pg, dom, alpha.c, q.u32()));
         sel.reset();
         // the chunks' own LDE: interpolate over H_n, move to the chunk's coset, evaluate on the LDE coset
@@ -425,7 +634,7 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     DevBuf d_ys;
     {
         size_t wmax = 4;
-        for (const TableState& s : ts) wmax = std::max(wmax, std::max(s.w, (size_t)4 << s.lqd));
+        for (const TableState& s : ts) wmax = std::max(std::max(wmax, s.pw), std::max(s.w, (size_t)4 << s.lqd));
         RK_TRY(d_ys.alloc(ctx, 2 * wmax * 16));
     }
     for (uint32_t t = 0; t < n_tables; t++) {  // round 0: every trace at zeta and zeta * g
@@ -439,17 +648,31 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         std::memcpy(pts, zeta.c, 16);
         const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
         std::memcpy(pts + 4, zn.c, 16);
-        s.y.resize(8 * s.w + ((size_t)16 << s.lqd));
+        s.y.resize(8 * s.w + 8 * s.pw + ((size_t)16 << s.lqd));
         RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.lde.u32(), s.H, s.w, pts, 2, /*cols=*/true));
         RK_TRY(d2h(ctx, s.y.data(), d_ys.p, 8 * s.w * 4));
         RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.lde.u32(), s.H, s.w, 2, pts, s.y.data(), alpha2, num_reduced[lh], /*cols=*/true));
         num_reduced[lh] += 2 * s.w;
     }
-    for (uint32_t t = 0; t < n_tables; t++) {  // round 1: every quotient chunk at zeta
+    for (uint32_t t = 0; t < n_tables; t++) {  // round 1 (lookups): every permutation trace at zeta and zeta * g
+        TableState& s = ts[t];
+        if (!s.pw) continue;
+        const unsigned lh = s.k + blow;
+        uint32_t pts[8];
+        std::memcpy(pts, zeta.c, 16);
+        const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
+        std::memcpy(pts + 4, zn.c, 16);
+        uint32_t* y = s.y.data() + 8 * s.w;
+        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.perm.u32(), s.H, s.pw, pts, 2, /*cols=*/true));
+        RK_TRY(d2h(ctx, y, d_ys.p, 8 * s.pw * 4));
+        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.perm.u32(), s.H, s.pw, 2, pts, y, alpha2, num_reduced[lh], /*cols=*/true));
+        num_reduced[lh] += 2 * s.pw;
+    }
+    for (uint32_t t = 0; t < n_tables; t++) {  // last round: every quotient chunk at zeta
         TableState& s = ts[t];
         const unsigned lh = s.k + blow;
         const size_t wq = (size_t)4 << s.lqd;
-        uint32_t* y = s.y.data() + 8 * s.w;
+        uint32_t* y = s.y.data() + 8 * s.w + 8 * s.pw;
         RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunks.u32(), s.H, wq, zeta.c, 1, /*cols=*/true));
         RK_TRY(d2h(ctx, y, d_ys.p, wq * 16));
         RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunks.u32(), s.H, wq, 1, zeta.c, y, alpha2, num_reduced[lh], /*cols=*/true));
@@ -517,6 +740,7 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     for (uint32_t qi = 0; qi < par.queries; qi++) {
         const uint32_t index = ch.sample_bits(log_max);
         open_batch(tmats, tnodes.u32(), Ht, index >> (log_max - log2u(Ht)));
+        if (!pmats.empty()) open_batch(pmats, pnodes.u32(), Hp, index >> (log_max - log2u(Hp)));
         open_batch(qmats, qnodes.u32(), Hq, index >> (log_max - log2u(Hq)));
         for (unsigned rd = 0; rd < n_rounds; rd++) {
             const uint32_t idx = index >> rd, pair = idx >> 1;
@@ -574,7 +798,8 @@ Selectors selectors_at(const Ext& x, unsigned log_n, uint32_t root27m, uint32_t 
 Ext load_ext(const uint32_t* p) { return Ext{{p[0], p[1], p[2], p[3]}}; }
 
 // 0 accept; 1 malformed / short / trailing / non-canonical word, 2 shape mismatch, 3 constraint identity
-// (OodEvaluationMismatch), 4 proof of work, 5 input opening, 6 commit-phase opening, 7 final polynomial
+// (OodEvaluationMismatch), 4 proof of work, 5 input opening, 6 commit-phase opening, 7 final polynomial, 8 the
+// lookups' cumulative sums do not cancel
 int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init, size_t n_init,
               const uint32_t* proof, size_t words) {
     rk_params def;
@@ -608,15 +833,54 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     if (!troot) return 1;
     ch.observe(troot, 8);
     for (uint32_t t = 0; t < n_tables; t++) ch.observe(tables[t].public_values, tables[t].n_public);
+    // lookups: the permutation challenges, the second commitment, the cumulative sums (which must cancel)
+    uint32_t n_chal = 0, n_perm = 0, pwid[MAX_TABLES];
+    unsigned log_pmax = 0;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        pwid[t] = tables[t].air->perm_width;
+        n_chal = std::max(n_chal, tables[t].air->n_chal);
+        if (!pwid[t]) continue;
+        n_perm++;
+        log_pmax = std::max(log_pmax, log_n[t] + blow);
+    }
+    std::vector<uint32_t> pchal(n_chal);
+    const uint32_t* proot = nullptr;
+    const uint32_t* cumsum[MAX_TABLES] = {nullptr};
+    if (n_perm) {
+        const Ext pa = ch.sample_ext(), pb = ch.sample_ext();
+        std::memcpy(pchal.data(), pa.c, 16);
+        Ext cur = bb::ext_one();
+        for (uint32_t j = 1; 4 * j < n_chal; j++) {
+            std::memcpy(&pchal[4 * j], cur.c, 16);
+            cur = bb::mul(cur, pb, wm);
+        }
+        proot = r.take(8);
+        if (!proot) return 1;
+        ch.observe(proot, 8);
+        Ext total = bb::ext_zero();
+        for (uint32_t t = 0; t < n_tables; t++) {
+            if (!pwid[t]) continue;
+            cumsum[t] = r.take(4);
+            if (!cumsum[t]) return 1;
+            ch.observe(cumsum[t], 4);
+            total = bb::add(total, load_ext(cumsum[t]));
+        }
+        if (!bb::eq(total, bb::ext_zero())) return 8;
+    }
     const Ext alpha = ch.sample_ext();
     const uint32_t* qroot = r.take(8);
     if (!qroot) return 1;
     ch.observe(qroot, 8);
     const Ext zeta = ch.sample_ext();
-    const uint32_t *y_local[MAX_TABLES], *y_next[MAX_TABLES], *y_chunk[MAX_TABLES];
+    const uint32_t *y_local[MAX_TABLES], *y_next[MAX_TABLES], *y_chunk[MAX_TABLES], *yp_local[MAX_TABLES], *yp_next[MAX_TABLES];
     for (uint32_t t = 0; t < n_tables; t++) {
         y_local[t] = r.take(4 * (size_t)tables[t].width);
         y_next[t] = r.take(4 * (size_t)tables[t].width);
+        yp_local[t] = yp_next[t] = nullptr;
+        if (pwid[t]) {
+            yp_local[t] = r.take(4 * (size_t)pwid[t]);
+            yp_next[t] = r.take(4 * (size_t)pwid[t]);
+        }
         y_chunk[t] = r.take((size_t)16 << lqd[t]);
         if (r.bad) return 1;
     }
@@ -642,8 +906,9 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
             }
         }
         const Selectors s = selectors_at(zeta, log_n[t], sys.root27m, wm);
+        const PermView pv{(const Ext*)yp_local[t], (const Ext*)yp_next[t], pchal.data(), cumsum[t]};
         const Ext folded = air_fold(*tables[t].air, (const Ext*)y_local[t], (const Ext*)y_next[t], tables[t].public_values, s.is_first,
-                                    s.is_last, s.is_trans, alpha, wm);
+                                    s.is_last, s.is_trans, alpha, wm, pv);
         if (!bb::eq(bb::mul(folded, s.inv_zeroifier, wm), quotient)) return 3;
     }
     const Ext alpha2 = ch.sample_ext();
@@ -665,12 +930,17 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     ch.observe(fp, 4);
     if (!ch.check_witness(sys.pow_bits, *wit)) return 4;
 
-    std::vector<uint32_t> th(n_tables), tw(n_tables), qh, qw;
-    size_t trow = 0;
+    std::vector<uint32_t> th(n_tables), tw(n_tables), qh, qw, ph, pwd;
+    size_t trow = 0, prow = 0;
     for (uint32_t t = 0; t < n_tables; t++) {
         th[t] = 1u << (log_n[t] + blow);
         tw[t] = tables[t].width;
         trow += tables[t].width;
+        if (pwid[t]) {
+            ph.push_back(th[t]);
+            pwd.push_back(pwid[t]);
+            prow += pwid[t];
+        }
         for (uint32_t j = 0; j < (1u << lqd[t]); j++) {
             qh.push_back(th[t]);
             qw.push_back(4);
@@ -678,13 +948,17 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     }
     const size_t qrow = 4 * qh.size();
     auto check_query = [&](uint32_t index, Reader r) -> int {
-        // every table is in both batches: both trees have the global maximum height
+        // every table is in the trace and the quotient batch: both trees have the global maximum height; the permutation
+        // batch only holds the tables with lookups
         const uint32_t* trows = r.take(trow);
         const uint32_t* tpath = r.take(8 * (size_t)log_max);
+        const uint32_t* prows = n_perm ? r.take(prow) : nullptr;
+        const uint32_t* ppath = n_perm ? r.take(8 * (size_t)log_pmax) : nullptr;
         const uint32_t* qrows = r.take(qrow);
         const uint32_t* qpath = r.take(8 * (size_t)log_max);
         if (r.bad) return 1;
         if (rk_mmcs_verify(&par, th.data(), tw.data(), n_tables, index, trows, tpath, troot) != 0) return 5;
+        if (n_perm && rk_mmcs_verify(&par, ph.data(), pwd.data(), n_perm, index >> (log_max - log_pmax), prows, ppath, proot) != 0) return 5;
         if (rk_mmcs_verify(&par, qh.data(), qw.data(), (uint32_t)qh.size(), index, qrows, qpath, qroot) != 0) return 5;
         Ext rop[ntt::LAMBDA + 1], apow[ntt::LAMBDA + 1];
         bool used[ntt::LAMBDA + 1] = {false};
@@ -704,6 +978,16 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
             for (uint32_t c = 0; c < tables[t].width; c++) reduce(lh, x, zeta, load_ext(y_local[t] + 4 * c), trows[at + c]);
             for (uint32_t c = 0; c < tables[t].width; c++) reduce(lh, x, zn, load_ext(y_next[t] + 4 * c), trows[at + c]);
             at += tables[t].width;
+        }
+        at = 0;
+        for (uint32_t t = 0; t < n_tables; t++) {
+            if (!pwid[t]) continue;
+            const unsigned lh = log_n[t] + blow;
+            const uint32_t x = bb::mul(shiftm, bb::pow(gen(lh), bb::bitrev(index >> (log_max - lh), lh)));
+            const Ext zn = bb::scale(zeta, gen(log_n[t]));
+            for (uint32_t c = 0; c < pwid[t]; c++) reduce(lh, x, zeta, load_ext(yp_local[t] + 4 * c), prows[at + c]);
+            for (uint32_t c = 0; c < pwid[t]; c++) reduce(lh, x, zn, load_ext(yp_next[t] + 4 * c), prows[at + c]);
+            at += pwid[t];
         }
         at = 0;
         for (uint32_t t = 0; t < n_tables; t++) {
@@ -738,7 +1022,7 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     };
     // the query positions come from the transcript one after the other; the queries themselves are independent and of
     // one size, so they are checked on a few threads (100 queries cost ~40 ms of Poseidon2 on one core)
-    size_t per_query = trow + qrow + 16 * (size_t)log_max;
+    size_t per_query = trow + qrow + 16 * (size_t)log_max + (n_perm ? prow + 8 * (size_t)log_pmax : 0);
     for (uint32_t rd = 0; rd < n_rounds; rd++) per_query += 4 + 8 * (size_t)(log_max - 1 - rd);
     const size_t q0 = r.pos;
     if (q0 + per_query * sys.queries != words) return 1;   // short or trailing words
@@ -956,21 +1240,53 @@ int rk_p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size
 }
 
 int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, rk_air** out) {
+    return rk_air_create_lookup(steps, n_steps, width, n_public, nullptr, 0, 0, out);
+}
+int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, const uint32_t* iw,
+                         uint32_t n_interactions, size_t n_words, rk_air** out) {
     RK_GUARD_BEGIN
     if (!out) return RK_ERR_INVALID;
     *out = nullptr;
     if (!steps || n_steps == 0 || n_steps > ((size_t)1 << 27) || width == 0 || width > (1u << 16) || n_public > (1u << 20)) return RK_ERR_INVALID;
+    if (n_interactions > 4096 || (n_interactions && !iw) || (!n_interactions && n_words)) return RK_ERR_INVALID;
     std::unique_ptr<rk_air> air(new rk_air);
-    RK_TRY(air_scan(steps, n_steps, width, n_public, &air->info));
+    {   // the interactions: kind, bus, mult_is_const, mult, n_values, columns...
+        size_t at = 0;
+        uint32_t max_values = 0;
+        for (uint32_t i = 0; i < n_interactions; i++) {
+            if (at + 5 > n_words) return RK_ERR_INVALID;
+            const uint32_t kind = iw[at], bus = iw[at + 1], is_const = iw[at + 2], mult = iw[at + 3], nv = iw[at + 4];
+            if (kind > 1 || bus >= bb::P || is_const > 1 || nv > 64 || at + 5 + nv > n_words) return RK_ERR_INVALID;
+            if (is_const ? mult >= bb::P : mult >= width) return RK_ERR_INVALID;
+            air->lookups.insert(air->lookups.end(), {kind, bb::encode(bus), is_const, is_const ? bb::encode(mult) : mult, nv});
+            for (uint32_t j = 0; j < nv; j++) {
+                if (iw[at + 5 + j] >= width) return RK_ERR_INVALID;
+                air->lookups.push_back(iw[at + 5 + j]);
+            }
+            max_values = std::max(max_values, nv);
+            at += 5 + nv;
+        }
+        if (at != n_words) return RK_ERR_INVALID;
+        air->n_lookups = n_interactions;
+        if (n_interactions) {
+            air->perm_width = 4 * ((n_interactions + 1) / 2 + 1);
+            air->n_chal = 4 * (max_values + 2);
+        }
+    }
+    const uint32_t pw = air->perm_width, n_chal = air->n_chal;
+    RK_TRY(air_scan(steps, n_steps, width, n_public, pw, n_chal, &air->info));
     air->steps.assign(steps, steps + n_steps);
     air->width = width;
     air->n_public = n_public;
     // the list as an rk_program: taps 0..2 = the selector columns (group 0), 3 + c = LOCAL c, 3 + width + c = NEXT c
-    // (group 2); PUBLIC = GET_GLOBAL of the proof's globals; NEG a = 0 - a; the asserts one AND_EQZ chain
+    // (group 2), then PERM_LOCAL / PERM_NEXT c (group 1); PUBLIC / CHALLENGE / CUMSUM = GET_GLOBAL of the proof's globals
+    // (public values | challenges | cumulative sum); NEG a = 0 - a; the asserts one AND_EQZ chain
     std::vector<rk::Tap> taps;
     for (uint32_t c = 0; c < 3; c++) taps.push_back(rk::Tap{0, c, 0});
     for (uint32_t c = 0; c < width; c++) taps.push_back(rk::Tap{2, c, 0});
     for (uint32_t c = 0; c < width; c++) taps.push_back(rk::Tap{2, c, NEXT_BACK});
+    for (uint32_t c = 0; c < pw; c++) taps.push_back(rk::Tap{1, c, 0});
+    for (uint32_t c = 0; c < pw; c++) taps.push_back(rk::Tap{1, c, NEXT_BACK});
     std::vector<rk_poly_step> ps;
     ps.reserve(n_steps + 2);
     std::vector<uint32_t> fp_of;   // AIR value -> position in the program's field-value list
@@ -985,6 +1301,10 @@ int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint
             case RK_AIR_LOCAL: ps.push_back(rk_poly_step{RK_STEP_GET, 3 + st.a, 0, 0}); fp_of.push_back(n_fp++); break;
             case RK_AIR_NEXT: ps.push_back(rk_poly_step{RK_STEP_GET, 3 + width + st.a, 0, 0}); fp_of.push_back(n_fp++); break;
             case RK_AIR_PUBLIC: ps.push_back(rk_poly_step{RK_STEP_GET_GLOBAL, 0, st.a, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_PERM_LOCAL: ps.push_back(rk_poly_step{RK_STEP_GET, 3 + 2 * width + st.a, 0, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_PERM_NEXT: ps.push_back(rk_poly_step{RK_STEP_GET, 3 + 2 * width + pw + st.a, 0, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_CHALLENGE: ps.push_back(rk_poly_step{RK_STEP_GET_GLOBAL, 0, n_public + st.a, 0}); fp_of.push_back(n_fp++); break;
+            case RK_AIR_CUMSUM: ps.push_back(rk_poly_step{RK_STEP_GET_GLOBAL, 0, n_public + n_chal + st.a, 0}); fp_of.push_back(n_fp++); break;
             case RK_AIR_IS_FIRST_ROW: case RK_AIR_IS_LAST_ROW: case RK_AIR_IS_TRANSITION:
                 air->sel_mask |= 1u << (st.op - RK_AIR_IS_FIRST_ROW);
                 ps.push_back(rk_poly_step{RK_STEP_GET, st.op - RK_AIR_IS_FIRST_ROW, 0, 0});

@@ -21,6 +21,11 @@ from . import _lib
 P = 2013265921
 
 CONST, LOCAL, NEXT, PUBLIC, IS_FIRST_ROW, IS_LAST_ROW, IS_TRANSITION, ADD, SUB, MUL, NEG, ASSERT_ZERO = range(12)
+# the permutation (LogUp) argument's leaves: a base column of the permutation trace (this / next row), a base
+# component of the challenge vector [alpha | beta^0 | beta^1 | ...], a base component of the table's cumulative sum
+PERM_LOCAL, PERM_NEXT, CHALLENGE, CUMSUM = 12, 13, 14, 15
+SEND, RECEIVE = 0, 1
+EXT_W = 11          # x^4 - 11: the quartic extension of the SP1 / Plonky3 preset (risc0's is x^4 + 11: ext_w = P - 11)
 
 
 class Expr:
@@ -52,6 +57,53 @@ class Expr:
         return self.b._push(NEG, self.idx, 0)
 
 
+class ExtExpr:
+    """an element of the quartic extension as four base expressions (the evaluator works on base values; a constraint
+    over the extension is its four components)"""
+    __slots__ = ("c", "w")
+
+    def __init__(self, c, w=EXT_W):
+        self.c, self.w = list(c), w
+
+    def __add__(self, o):
+        return ExtExpr([x + y for x, y in zip(self.c, o.c)], self.w)
+
+    def __sub__(self, o):
+        return ExtExpr([x - y for x, y in zip(self.c, o.c)], self.w)
+
+    def scale(self, e):
+        return ExtExpr([x * e for x in self.c], self.w)
+
+    def __mul__(self, o):
+        a, b = self.c, o.c
+        out = []
+        for k in range(4):
+            lo = [a[i] * b[k - i] for i in range(k + 1)]
+            hi = [a[i] * b[k + 4 - i] for i in range(k + 1, 4)]
+            t = lo[0]
+            for x in lo[1:]:
+                t = t + x
+            if hi:
+                h = hi[0]
+                for x in hi[1:]:
+                    h = h + x
+                t = t + h * self.w
+            out.append(t)
+        return ExtExpr(out, self.w)
+
+
+class Interaction:
+    """one side of a lookup: the tuple (bus, local[value_cols]...) sent (kind SEND) or received (RECEIVE) `mult` times
+    per row -- mult a column of the main trace, or a constant when mult_is_const (sp1-core lookup/interaction.rs, RECALLED)"""
+
+    def __init__(self, kind, bus, value_cols, mult, mult_is_const=False):
+        self.kind, self.bus, self.value_cols = int(kind), int(bus), [int(c) for c in value_cols]
+        self.mult, self.mult_is_const = int(mult), bool(mult_is_const)
+
+    def words(self):
+        return [self.kind, self.bus, 1 if self.mult_is_const else 0, self.mult, len(self.value_cols)]
+
+
 class _When:
     def __init__(self, b, cond):
         self.b, self.cond = b, cond
@@ -66,17 +118,36 @@ class _When:
 class Air:
     """steps: (n, 3) uint32 array of (op, a, b)"""
 
-    def __init__(self, steps, width, n_public):
+    def __init__(self, steps, width, n_public, interactions=()):
         self.steps = np.ascontiguousarray(steps, dtype=np.uint32).reshape(-1, 3)
         self.width, self.n_public = int(width), int(n_public)
+        self.interactions = list(interactions)
         self._handle = None
+
+    @property
+    def perm_width(self):
+        """base columns of the permutation trace: 4 x (one extension column per batch of two interactions + the running sum)"""
+        n = len(self.interactions)
+        return 4 * ((n + 1) // 2 + 1) if n else 0
+
+    def interaction_words(self):
+        """the flat form rk_air_create_lookup takes: 5 header words per interaction, then its value columns"""
+        out = []
+        for it in self.interactions:
+            out += it.words() + it.value_cols
+        return np.array(out, dtype=np.uint32)
 
     def handle(self):
         """the rk_air behind this list (rk_air_create validates it and translates it for the GPU evaluator)"""
         if self._handle is None:
             lib = _lib.load()
             h = C.c_void_p()
-            _lib.check(None, lib.rk_air_create(self.steps.ctypes.data, self.steps.shape[0], self.width, self.n_public, C.byref(h)))
+            if self.interactions:
+                iw = self.interaction_words()
+                _lib.check(None, lib.rk_air_create_lookup(self.steps.ctypes.data, self.steps.shape[0], self.width, self.n_public,
+                                                          iw.ctypes.data_as(_lib.u32p), len(self.interactions), iw.size, C.byref(h)))
+            else:
+                _lib.check(None, lib.rk_air_create(self.steps.ctypes.data, self.steps.shape[0], self.width, self.n_public, C.byref(h)))
             self._handle = h
         return self._handle
 
@@ -106,9 +177,9 @@ class Air:
         is_transition, constants, public values: 0)"""
         deg, mx = [], 0
         for op, a, b in self.steps.tolist():
-            if op in (CONST, PUBLIC, IS_TRANSITION):
+            if op in (CONST, PUBLIC, IS_TRANSITION, CHALLENGE, CUMSUM):
                 deg.append(0)
-            elif op in (LOCAL, NEXT, IS_FIRST_ROW, IS_LAST_ROW):
+            elif op in (LOCAL, NEXT, IS_FIRST_ROW, IS_LAST_ROW, PERM_LOCAL, PERM_NEXT):
                 deg.append(1)
             elif op in (ADD, SUB):
                 deg.append(max(deg[a], deg[b]))
@@ -122,7 +193,9 @@ class Air:
         return (d - 1).bit_length()
 
     def check_trace(self, trace, public_values=()):
-        """every constraint on every row of a canonical-integer trace (rows wrap around); -> list of (row, constraint)"""
+        """every constraint on every row of a canonical-integer trace (rows wrap around); -> list of (row, constraint).
+        Main-trace constraints only: the asserts over the permutation trace of an AIR with lookups are skipped (they
+        are checked by proving)."""
         t = np.asarray(trace, dtype=object)
         n = t.shape[0]
         bad = []
@@ -143,26 +216,28 @@ class Air:
                     vals.append(1 if r == n - 1 else 0)
                 elif op == IS_TRANSITION:
                     vals.append(0 if r == n - 1 else 1)
-                elif op == ADD:
-                    vals.append((vals[a] + vals[b]) % P)
-                elif op == SUB:
-                    vals.append((vals[a] - vals[b]) % P)
-                elif op == MUL:
-                    vals.append(vals[a] * vals[b] % P)
+                elif op in (PERM_LOCAL, PERM_NEXT, CHALLENGE, CUMSUM):
+                    vals.append(None)
+                elif op in (ADD, SUB, MUL):
+                    x, y = vals[a], vals[b]
+                    vals.append(None if x is None or y is None else (x + y) % P if op == ADD else (x - y) % P if op == SUB else x * y % P)
                 elif op == NEG:
-                    vals.append(-vals[a] % P)
+                    vals.append(None if vals[a] is None else -vals[a] % P)
                 else:
-                    if vals[a] % P:
+                    if vals[a] is not None and vals[a] % P:
                         bad.append((r, k))
                     k += 1
         return bad
 
 
 class AirBuilder:
-    def __init__(self, width, n_public=0):
-        self.width, self.n_public = width, n_public
+    def __init__(self, width, n_public=0, ext_w=EXT_W):
+        """ext_w: the W of the parameter set's extension x^4 - W the proofs will be made under (it is written into the
+        lookup constraints; an AIR without interactions does not depend on it)"""
+        self.width, self.n_public, self.ext_w = width, n_public, ext_w % P
         self.steps, self.nv = [], 0
         self._memo = {}
+        self.interactions = []
 
     def _push(self, op, a=0, b=0):
         key = (op, a, b)
@@ -214,8 +289,67 @@ class AirBuilder:
     def assert_eq(self, x, y):
         self.assert_zero(x - y)
 
+    # ---- lookups
+    def send(self, bus, value_cols, mult=1, mult_is_const=True):
+        """this table sends (bus, local[value_cols]...) `mult` times per row; mult names a column unless mult_is_const"""
+        self.interactions.append(Interaction(SEND, bus, value_cols, mult % P if mult_is_const else mult, mult_is_const))
+
+    def receive(self, bus, value_cols, mult=1, mult_is_const=True):
+        self.interactions.append(Interaction(RECEIVE, bus, value_cols, mult % P if mult_is_const else mult, mult_is_const))
+
+    def _ext_leaf(self, op, at):
+        return ExtExpr([self._push(op, 4 * at + k) for k in range(4)], self.ext_w)
+
+    def _assert_ext_zero(self, cond, x):
+        for c in x.c:
+            self.assert_zero(c if cond is None else cond * c)
+
+    def _perm_constraints(self):
+        """sp1-core stark/permutation.rs eval_permutation_constraints (RECALLED), over base components:
+        per batch  entry * prod rlc_i = sum_i +-mult_i * prod_(j != i) rlc_j,  rlc = alpha + beta^0 bus + sum_j beta^(j+1) x_j;
+        phi[0] = sum entries[0];  phi' = phi + sum entries'  on transitions;  phi[last] = the cumulative sum"""
+        its = self.interactions
+        nb = (len(its) + 1) // 2
+        alpha = self._ext_leaf(CHALLENGE, 0)
+
+        def rlc(it):
+            acc = alpha + self._ext_leaf(CHALLENGE, 1).scale(self.const(it.bus))
+            for j, col in enumerate(it.value_cols):
+                acc = acc + self._ext_leaf(CHALLENGE, 2 + j).scale(self.local(col))
+            return acc
+
+        def signed_mult(it):
+            m = self.const(it.mult) if it.mult_is_const else self.local(it.mult)
+            return m if it.kind == SEND else -m
+
+        entries_l = [self._ext_leaf(PERM_LOCAL, b) for b in range(nb)]
+        entries_n = [self._ext_leaf(PERM_NEXT, b) for b in range(nb)]
+        for b in range(nb):
+            pair = its[2 * b: 2 * b + 2]
+            r = [rlc(it) for it in pair]
+            if len(pair) == 2:
+                lhs = entries_l[b] * r[0] * r[1]
+                rhs = r[1].scale(signed_mult(pair[0])) + r[0].scale(signed_mult(pair[1]))
+                self._assert_ext_zero(None, lhs - rhs)
+            else:
+                lhs = entries_l[b] * r[0]
+                m = signed_mult(pair[0])
+                self.assert_zero(lhs.c[0] - m)
+                for k in range(1, 4):
+                    self.assert_zero(lhs.c[k])
+        phi_l, phi_n = self._ext_leaf(PERM_LOCAL, nb), self._ext_leaf(PERM_NEXT, nb)
+        sum_l, sum_n = entries_l[0], entries_n[0]
+        for b in range(1, nb):
+            sum_l, sum_n = sum_l + entries_l[b], sum_n + entries_n[b]
+        self._assert_ext_zero(self.is_first_row(), phi_l - sum_l)
+        self._assert_ext_zero(self.is_transition(), phi_n - phi_l - sum_n)
+        self._assert_ext_zero(self.is_last_row(), phi_l - self._ext_leaf(CUMSUM, 0))
+
     def build(self):
-        return Air(np.array(self.steps, dtype=np.uint32), self.width, self.n_public)
+        if self.interactions and not getattr(self, "_perm_done", False):
+            self._perm_constraints()
+            self._perm_done = True
+        return Air(np.array(self.steps, dtype=np.uint32), self.width, self.n_public, self.interactions)
 
 
 _R_MOD_P = (1 << 32) % P
@@ -454,3 +588,62 @@ def local_trace(air, log_n, seed=8):
         i, j, l, m = (int(v) for v in air.picks[k])
         c[half + k] = (c[i] * c[j] % P * c[l] + c[m]) % P
     return np.ascontiguousarray(c.T).astype(np.uint32), []
+
+
+# ---------------------------------------------------------------------------------------------- lookups between tables
+BUS_RANGE, BUS_ADD, BUS_MUL = 1, 2, 3
+
+
+def lookup_demo_airs(ext_w=EXT_W):
+    """Four tables tied by lookups the way SP1's cpu chip is tied to its ALU and range chips:
+      cpu    (a, b, sum, prod, is_real): sends (ADD: a, b, sum), (MUL: a, b, prod) and (RANGE: a), each is_real times --
+             three interactions, so one batch of two and a single one, tuples of 3 and 1 values
+      add    (a, b, c, mult): c = a + b; receives (ADD: a, b, c) mult times
+      mul    (a, b, c, mult): c = a * b; receives (MUL: a, b, c) mult times
+      range  (v, mult): v counts up from 0; receives (RANGE: v) mult times"""
+    cpu = AirBuilder(5, 0, ext_w)
+    is_real = cpu.local(4)
+    cpu.assert_zero(is_real * (is_real - 1))
+    cpu.send(BUS_ADD, [0, 1, 2], mult=4, mult_is_const=False)
+    cpu.send(BUS_MUL, [0, 1, 3], mult=4, mult_is_const=False)
+    cpu.send(BUS_RANGE, [0], mult=4, mult_is_const=False)
+    add = AirBuilder(4, 0, ext_w)
+    add.assert_eq(add.local(2), add.local(0) + add.local(1))
+    add.receive(BUS_ADD, [0, 1, 2], mult=3, mult_is_const=False)
+    mul = AirBuilder(4, 0, ext_w)
+    mul.assert_eq(mul.local(2), mul.local(0) * mul.local(1))
+    mul.receive(BUS_MUL, [0, 1, 2], mult=3, mult_is_const=False)
+    rng = AirBuilder(2, 0, ext_w)
+    rng.when_first_row().assert_zero(rng.local(0))
+    rng.when_transition().assert_eq(rng.next(0), rng.local(0) + 1)
+    rng.receive(BUS_RANGE, [0], mult=1, mult_is_const=False)
+    return cpu.build(), add.build(), mul.build(), rng.build()
+
+
+def _dedupe(rows, log_n, width):
+    """distinct rows with their counts as a last column, zero-padded to 2^log_n rows"""
+    uniq, cnt = np.unique(rows, axis=0, return_counts=True)
+    assert len(uniq) <= 1 << log_n
+    t = np.zeros((1 << log_n, width + 1), dtype=np.uint64)
+    t[: len(uniq), :width] = uniq
+    t[: len(uniq), width] = cnt
+    return t
+
+
+def lookup_demo_tables(log_cpu, log_range=4, seed=0, ext_w=EXT_W, airs=None):
+    """canonical traces for lookup_demo_airs: 2^log_cpu cpu rows of which about 3/4 are real; operands below 2^log_range"""
+    cpu_air, add_air, mul_air, rng_air = airs or lookup_demo_airs(ext_w)
+    n = 1 << log_cpu
+    g = np.random.default_rng(seed)
+    a = g.integers(0, 1 << log_range, size=n).astype(np.uint64)
+    b = g.integers(0, P, size=n).astype(np.uint64)
+    b[: n // 2] = g.integers(0, 3, size=n // 2)          # repeated tuples: multiplicities above 1
+    real = (g.integers(0, 4, size=n) > 0).astype(np.uint64)
+    cpu = np.stack([a, b, (a + b) % P, a * b % P, real], axis=1)
+    live = cpu[real == 1]
+    log_alu = max(1, int(len(live)).bit_length())
+    add = _dedupe(live[:, [0, 1, 2]], log_alu, 3)
+    mul = _dedupe(live[:, [0, 1, 3]], log_alu, 3)
+    rng = np.stack([np.arange(1 << log_range, dtype=np.uint64), np.bincount(live[:, 0].astype(np.int64), minlength=1 << log_range).astype(np.uint64)], axis=1)
+    return [Table.from_canonical(cpu_air, cpu), Table.from_canonical(add_air, add), Table.from_canonical(mul_air, mul),
+            Table.from_canonical(rng_air, rng)]

@@ -60,8 +60,14 @@ class OrMatrix(C.Structure):
     _fields_ = [("values", C.c_void_p), ("height", C.c_uint32), ("width", C.c_uint32), ("row_major", C.c_uint32)]
 
 
+class OrInteraction(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("bus", C.c_uint32), ("mult_is_const", C.c_uint32), ("mult", C.c_uint32),
+                ("n_values", C.c_uint32), ("value_cols", C.c_void_p)]
+
+
 class OrAir(C.Structure):
-    _fields_ = [("steps", C.c_void_p), ("n_steps", C.c_size_t)]
+    _fields_ = [("steps", C.c_void_p), ("n_steps", C.c_size_t), ("interactions", C.POINTER(OrInteraction)),
+                ("n_interactions", C.c_uint32)]
 
 
 class OrP3Table(C.Structure):
@@ -324,6 +330,16 @@ def _or_p3_tables(tables):
     for i, t in enumerate(tables):
         steps = np.ascontiguousarray(t.air.steps, dtype=np.uint32)
         air = OrAir(steps=steps.ctypes.data, n_steps=steps.shape[0])
+        its = getattr(t.air, "interactions", [])
+        if its:
+            ia = (OrInteraction * len(its))()
+            for k, it in enumerate(its):
+                cols = np.array(it.value_cols, dtype=np.uint32)
+                keep.append(cols)
+                ia[k] = OrInteraction(it.kind, it.bus, 1 if it.mult_is_const else 0, it.mult,
+                                      len(it.value_cols), cols.ctypes.data)
+            keep.append(ia)
+            air.interactions, air.n_interactions = ia, len(its)
         pv = np.ascontiguousarray(t.public_values, dtype=np.uint32)
         keep += [steps, air, pv]
         if t.trace is not None:

@@ -23,33 +23,62 @@ P3_CASES = {
     "sp1_tiny_beside_tall": (1, dict(queries=5, pow_bits=2), [("fib", 1, None), ("wide", 11, 7)], [2, 3]),
     "sp1_width_301": (1, dict(queries=3, pow_bits=2), [("wide", 6, 301)], []),
     "risc0_empty_air": (0, dict(queries=4), [("empty", 4, 3), ("fib", 5, None)], [8]),
+    # lookups between tables (the permutation argument): "lookup" expands to the four tables of p3.lookup_demo_airs
+    # (cpu / add / mul / range; arg = log2 of the range table); "selfperm" is one table whose seven interactions cancel
+    # among themselves (tuples of 0, 1 and 8 values, constant and column multiplicities: four batches)
+    "sp1_lookup_k6": (1, dict(queries=6, pow_bits=3), [("lookup", 6, 4)], [1, 2]),
+    "sp1_lookup_beside_plain": (1, dict(queries=5, pow_bits=2), [("fib", 9, None), ("lookup", 5, 3), ("cubic", 4, 5)], []),
+    "risc0_lookup_k7_blow2": (0, dict(queries=4, pow_bits=2, blowup_log2=2), [("lookup", 7, 5)], [3]),
+    "sp1_selfperm_k5": (1, dict(queries=5, pow_bits=2), [("selfperm", 5, 10), ("fib", 3, None)], [4]),
 }
+
+EXT_W = {0: p3.P - 11, 1: 11}     # the W of the presets' extension x^4 - W (risc0: x^4 + 11)
 
 _AIRS = {}
 
 
-def air_of(name, arg):
-    key = (name, arg)
+def selfperm_air(width, ext_w):
+    b = p3.AirBuilder(width, 0, ext_w)
+    eight = list(range(8))
+    b.send(5, eight, mult=2)
+    b.receive(5, eight, mult=1)
+    b.receive(5, eight, mult=1)
+    b.send(6, [3], mult=8, mult_is_const=False)
+    b.receive(6, [3], mult=8, mult_is_const=False)
+    b.send(7, [], mult=5)
+    b.receive(7, [], mult=5)
+    return b.build()
+
+
+def air_of(name, arg, preset=1):
+    key = (name, arg, preset if name in ("lookup", "selfperm") else None)
     if key not in _AIRS:
         if name == "empty":      # `width` columns, nothing asserted: a valid AIR whose quotient is zero
             b = p3.AirBuilder(arg)
             b.local(0)
             _AIRS[key] = b.build()
+        elif name == "lookup":
+            _AIRS[key] = p3.lookup_demo_airs(EXT_W[preset])
+        elif name == "selfperm":
+            _AIRS[key] = selfperm_air(arg, EXT_W[preset])
         else:
             _AIRS[key] = p3.fibonacci_air() if name == "fib" else p3.cubic_air(arg) if name == "cubic" else p3.wide_air(arg)
     return _AIRS[key]
 
 
 def tables_of(case):
-    _, _, specs, _ = P3_CASES[case]
+    preset, _, specs, _ = P3_CASES[case]
     out = []
     for i, (name, k, arg) in enumerate(specs):
-        air = air_of(name, arg)
+        air = air_of(name, arg, preset)
+        if name == "lookup":
+            out += p3.lookup_demo_tables(k, arg, seed=40 + i, airs=air)
+            continue
         if name == "fib":
             tr, pv = p3.fibonacci_trace(k, 1 + i, 2)
         elif name == "cubic":
             tr, pv = p3.cubic_trace(k, arg, seed=10 + i)
-        elif name == "empty":
+        elif name in ("empty", "selfperm"):
             tr, pv = np.random.default_rng(30 + i).integers(0, p3.P, size=(1 << k, arg)), []
         else:
             tr, pv = p3.wide_trace(air, k, seed=20 + i)

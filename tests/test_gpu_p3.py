@@ -59,6 +59,40 @@ def test_generated_kernel_gives_the_same_proof(hal):
     _AIRS.clear()
 
 
+def test_lookup_proofs_generated_kernel_device_traces_and_size(hal):
+    """the permutation argument beyond the seeded cases: the hiprtc kernel reads the permutation columns, challenges and
+    cumulative sums like the interpreter; device-resident main traces; a cpu table of 2^14 rows (prefix sums across
+    several workgroups) still byte-equal to the oracle; unbalanced lookups are proven but refused with reason 8"""
+    case = "sp1_lookup_beside_plain"
+    preset, over, _, _ = P3_CASES[case]
+    blob = hal.set_params(preset, **over)
+    o.oracle_set_params(preset, **over)
+    tables, init = tables_of(case), init_of(case)
+    for t in tables:
+        t.air.compile(hal)
+    jit = p3.prove(hal, tables, init)
+    assert sha(jit) == GOLD[case]["sha256"]
+    bufs = [hal.copy_from_elem(t.trace) for t in tables]
+    dev = [(H._ptr(b), t.log_height) for b, t in zip(bufs, tables)]
+    assert sha(p3.prove(hal, tables, init, device_traces=dev)) == GOLD[case]["sha256"]
+    for b, t in zip(bufs, tables):
+        assert np.array_equal(b.to_host().reshape(t.trace.shape), t.trace)
+    from p3_cases import _AIRS
+    _AIRS.clear()
+    airs = p3.lookup_demo_airs()
+    big = p3.lookup_demo_tables(14, 8, seed=5, airs=airs)
+    got = p3.prove(hal, big, init)
+    assert np.array_equal(got, o.oracle_p3_prove(big, init))
+    assert p3.verify(big, got, init, params=blob) == 0
+    assert p3.last_timing(hal)["perm"] > 0
+    tr = o.from_mont(big[3].trace).astype(np.uint64)
+    tr[9, 1] += 1
+    off = big[:3] + [p3.Table.from_canonical(airs[3], tr)]
+    pf = p3.prove(hal, off, init)
+    assert np.array_equal(pf, o.oracle_p3_prove(off, init))
+    assert p3.verify(off, pf, init, params=blob) == 8 == o.oracle_p3_verify(off, pf, init)
+
+
 def test_device_resident_traces(hal):
     case = "sp1_mixed_fib8_cubic4"
     preset, over, _, _ = P3_CASES[case]

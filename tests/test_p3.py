@@ -81,8 +81,97 @@ def test_air_create_rejects_malformed_lists():
     assert create([(p3.LOCAL, 0, 0), (p3.ADD, 0, 1), (p3.ASSERT_ZERO, 1, 0)]) == -1   # operand not yet pushed
     assert create([(p3.LOCAL, 0, 0), (p3.ASSERT_ZERO, 1, 0)]) == -1
     assert create([(p3.CONST, P, 0), (p3.ASSERT_ZERO, 0, 0)]) == -1          # not canonical
-    assert create([(12, 0, 0)]) == -1                                        # unknown op
+    assert create([(16, 0, 0)]) == -1                                        # unknown op
+    for op in (p3.PERM_LOCAL, p3.PERM_NEXT, p3.CHALLENGE, p3.CUMSUM):       # leaves of a lookup argument the AIR does not have
+        assert create([(op, 0, 0)]) == -1
     assert create([(p3.LOCAL, 0, 0)]) == 0                                   # no constraint at all is a valid (empty) AIR
+
+
+def test_lookup_air_create_rejects_malformed_interactions():
+    lib = _lib.load()
+    import ctypes as C
+    steps = np.array([(p3.LOCAL, 0, 0)], dtype=np.uint32)
+
+    def create(words, n, width=3, steps=steps):
+        w = np.array(words, dtype=np.uint32)
+        h = C.c_void_p()
+        rc = lib.rk_air_create_lookup(steps.ctypes.data, steps.shape[0], width, 0, w.ctypes.data_as(_lib.u32p), n, w.size, C.byref(h))
+        if rc == 0:
+            lib.rk_air_destroy(h)
+        return rc
+
+    assert create([0, 1, 1, 1, 2, 0, 1], 1) == 0
+    assert create([2, 1, 1, 1, 2, 0, 1], 1) == -1            # kind
+    assert create([0, P, 1, 1, 2, 0, 1], 1) == -1            # bus not canonical
+    assert create([0, 1, 1, P, 2, 0, 1], 1) == -1            # constant multiplicity not canonical
+    assert create([0, 1, 0, 3, 2, 0, 1], 1) == -1            # multiplicity column out of range
+    assert create([0, 1, 1, 1, 2, 0, 3], 1) == -1            # value column out of range
+    assert create([0, 1, 1, 1, 2, 0], 1) == -1               # short
+    assert create([0, 1, 1, 1, 2, 0, 1, 0], 1) == -1         # trailing words
+    assert create([0, 1, 1, 1, 65] + [0] * 65, 1) == -1      # tuple too long
+    assert create([0, 1, 1, 1, 2, 0, 1], 2) == -1            # count and words disagree
+    # the permutation leaves are range-checked against what the interactions give: 1 interaction = 8 base columns,
+    # a tuple of 2 = alpha, beta^0..beta^2 = 16 challenge words
+    for op, lim in ((p3.PERM_LOCAL, 8), (p3.PERM_NEXT, 8), (p3.CHALLENGE, 16), (p3.CUMSUM, 4)):
+        ok = np.array([(op, lim - 1, 0)], dtype=np.uint32)
+        bad = np.array([(op, lim, 0)], dtype=np.uint32)
+        assert create([0, 1, 1, 1, 2, 0, 1], 1, steps=ok) == 0 and create([0, 1, 1, 1, 2, 0, 1], 1, steps=bad) == -1
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_lookups_that_do_not_balance_are_rejected_by_both_verifiers(params, preset):
+    """the permutation argument's own failure modes: a multiplicity that is off by one, a tuple nobody receives
+    (cumulative sums do not cancel: reason 8); cumulative sums forged so that they cancel, a permutation column that is not
+    the one the constraints describe (constraint identity: reason 3)"""
+    from p3_cases import EXT_W
+    over = dict(queries=5, pow_bits=2)
+    params(preset, **over)
+    blob = hal.make_params(preset, **over)
+    airs = p3.lookup_demo_airs(EXT_W[preset])
+    tables, init = p3.lookup_demo_tables(5, 3, seed=2, airs=airs), p3.to_mont([6])
+    pf = o.oracle_p3_prove(tables, init)
+    assert o.oracle_p3_verify(tables, pf, init) == 0 == p3.verify(tables, pf, init, params=blob)
+
+    def both(tabs):
+        q = o.oracle_p3_prove(tabs, init)
+        a, b = o.oracle_p3_verify(tabs, q, init), p3.verify(tabs, q, init, params=blob)
+        assert a == b
+        return a
+
+    def with_cell(t, row, col, delta):
+        tr = o.from_mont(tables[t].trace).astype(np.uint64)
+        tr[row, col] = (int(tr[row, col]) + delta) % P
+        return tables[:t] + [p3.Table.from_canonical(tables[t].air, tr)] + tables[t + 1:]
+
+    assert both(with_cell(3, 2, 1, 1)) == 8          # the range table claims one more lookup than was made
+    assert both(with_cell(1, 0, 3, P - 1)) == 8      # the add table one fewer
+    cpu = o.from_mont(tables[0].trace)
+    live = int(np.flatnonzero(cpu[:, 4] == 1)[0])
+    assert both(with_cell(0, live, 2, 1)) == 8       # the cpu sends (a, b, a + b + 1): nobody receives that tuple
+    # forged sums: +d on one table, -d on another keeps the total at zero, but phi[last] = cumsum fails (and every later challenge moves)
+    at = 1 + len(tables) + 8 + 8                     # header | trace root | permutation root | the cumulative sums
+    s = pf.copy()
+    s[at] = (int(s[at]) + 5) % P
+    s[at + 4] = (int(s[at + 4]) - 5) % P
+    assert o.oracle_p3_verify(tables, s, init) == 3 == p3.verify(tables, s, init, params=blob)
+    s = pf.copy()
+    s[at] = (int(s[at]) + 5) % P
+    assert o.oracle_p3_verify(tables, s, init) == 8 == p3.verify(tables, s, init, params=blob)
+    # the same tables under an AIR whose lookup constraints were built for the other extension do not verify
+    wrong = p3.lookup_demo_airs(EXT_W[1 - preset])
+    wt = [p3.Table(a, t.trace, t.public_values) for a, t in zip(wrong, tables)]
+    assert both(wt) == 3
+    # random damage anywhere: the same verdict from both
+    rng = np.random.default_rng(preset + 10)
+    seen = set()
+    for k in range(200):
+        s = pf.copy()
+        i = int(rng.integers(0, s.size))
+        s[i] = (int(s[i]) + 1 + int(rng.integers(0, 9))) % P
+        got, want = p3.verify(tables, s, init, params=blob), o.oracle_p3_verify(tables, s, init)
+        assert got == want != 0, (k, i, got, want)
+        seen.add(got)
+    assert {5, 6} <= seen
 
 
 @pytest.mark.parametrize("preset", [0, 1])
