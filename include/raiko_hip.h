@@ -595,7 +595,8 @@ int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint
  * air/builder.rs send / receive; sp1-core is pulled by the reference's Cargo.lock, RECALLED): interaction i says "every
  * row sends (kind 0) or receives (kind 1) the tuple (bus, local[value_cols]...) `mult` times", mult a main-trace column
  * or -- mult_is_const -- a canonical constant.  Flat form: per interaction the words kind, bus, mult_is_const, mult,
- * n_values followed by its n_values column numbers (n_words in all).
+ * n_values followed by its n_values column numbers (n_words in all); at most 64 values per tuple and 120 distinct
+ * columns over all interactions of a table.
  * The prover (rk_p3_prove) then, after the main traces are committed, draws two extension challenges alpha, beta,
  * fills the table's permutation trace on the GPU -- one extension column per batch of two interactions holding
  * sum +-mult / (alpha + beta^0 bus + sum_j beta^(j+1) value_j), and a last column with the running sum of the row totals

@@ -42,7 +42,8 @@
 
 struct rk_air {
     std::vector<rk_air_step> steps;
-    std::vector<uint32_t> lookups;   // flat interactions (rk_air_create_lookup); mult / bus constants already Montgomery words
+    std::vector<uint32_t> lookups;   // flat interactions (rk_air_create_lookup): constants as Montgomery words, columns as slots of `used`
+    std::vector<uint32_t> used;      // the distinct main-trace columns the interactions read
     uint32_t n_lookups = 0, perm_width = 0, n_chal = 0;   // base columns of the permutation trace, words of the challenge vector
     uint32_t width = 0, n_public = 0;
     rk_air_info info{};
@@ -211,20 +212,38 @@ __global__ void add_words_kernel(uint32_t* __restrict__ io, const uint32_t* __re
 }
 
 // ---- lookups (sp1-core generate_permutation_trace, RECALLED).  desc = the challenge vector [alpha | beta^0 | beta^1 ..]
-// (4 words each, n_chal words) followed by the flat interactions (kind, bus, mult_is_const, mult, n_values, columns...;
-// constants as Montgomery words).  One lane per row of the row-major main trace; out = 4 (nb + 1) columns of n words:
-// the nb batch entries, then the row totals (the prefix sums turn those into the running sum in place).
+// (4 words each, n_chal words), the flat interactions (kind, bus, mult_is_const, mult, n_values, slots...; constants as
+// Montgomery words; columns renumbered to slots of the `used` list), then the n_used distinct main-trace columns the
+// interactions read.  A workgroup takes PERM_ROWS rows of the row-major trace: first every wave stages the used
+// columns of its rows in LDS -- one row per load instruction, the lanes along the used columns, so a row's cache lines
+// are fetched once instead of once per interaction --, then one lane per row walks the interactions out of LDS
+// (slot-major: conflict-free).  out = 4 (nb + 1) columns of n words: the nb batch entries, then the row totals (the
+// prefix sums turn those into the running sum in place).
+constexpr int PERM_ROWS = 256, PERM_LD = PERM_ROWS + 1;   // odd slot stride: the staging writes (lanes along slots) and the reads (lanes along rows) both spread over the banks
 struct PermArgs {
     uint32_t* out;
     const uint32_t* trace;
     const uint32_t* desc;
     size_t n, w;
-    uint32_t n_chal, n_lookups, wm;
+    uint32_t n_chal, n_lookups, wm, n_used, desc_words;
 };
-__global__ void perm_entries_kernel(PermArgs a) {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(PERM_ROWS) perm_entries_kernel(PermArgs a) {
+    extern __shared__ uint32_t tile[];   // n_used x PERM_LD
+    const size_t r0 = (size_t)blockIdx.x * PERM_ROWS;
+    const uint32_t* used = a.desc + a.desc_words;
+    {
+        const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (unsigned i = 0; i < 64; i++) {
+            const unsigned lr = wave * 64 + i;
+            if (r0 + lr >= a.n) break;
+            const uint32_t* row = a.trace + (r0 + lr) * a.w;
+            for (uint32_t u = lane; u < a.n_used; u += 64) tile[u * PERM_LD + lr] = row[used[u]];
+        }
+    }
+    __syncthreads();
+    const size_t r = r0 + threadIdx.x;
     if (r >= a.n) return;
-    const uint32_t* row = a.trace + r * a.w;
+    const uint32_t* row = tile + threadIdx.x;
     const uint32_t* ch = a.desc;
     const uint32_t* d = a.desc + a.n_chal;
     const Ext alpha{{ch[0], ch[1], ch[2], ch[3]}};
@@ -235,9 +254,9 @@ __global__ void perm_entries_kernel(PermArgs a) {
         Ext rlc = bb::add(alpha, bb::scale(Ext{{ch[4], ch[5], ch[6], ch[7]}}, bus));
         for (uint32_t j = 0; j < nv; j++) {
             const uint32_t* b = ch + 8 + 4 * j;
-            rlc = bb::add(rlc, bb::scale(Ext{{b[0], b[1], b[2], b[3]}}, row[d[5 + j]]));
+            rlc = bb::add(rlc, bb::scale(Ext{{b[0], b[1], b[2], b[3]}}, row[d[5 + j] * PERM_LD]));
         }
-        const uint32_t m = is_const ? mult : row[mult];
+        const uint32_t m = is_const ? mult : row[mult * PERM_LD];
         const Ext term = bb::scale(bb::inv(rlc, a.wm), kind == 0 ? m : bb::neg(m));
         entry = bb::add(entry, term);
         d += 5 + nv;
@@ -508,12 +527,17 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
             const rk_air& air = *tables[t].air;
             std::vector<uint32_t> desc(pchal.begin(), pchal.begin() + air.n_chal);
             desc.insert(desc.end(), air.lookups.begin(), air.lookups.end());
+            const uint32_t desc_words = (uint32_t)desc.size();
+            desc.insert(desc.end(), air.used.begin(), air.used.end());
             DevBuf d_desc, cols, totals;
             RK_TRY(d_desc.alloc(ctx, desc.size() * 4));
             RK_TRY(rk::upload(ctx, d_desc.p, desc.data(), desc.size() * 4));
             RK_TRY(cols.alloc(ctx, s.n * s.pw * 4));
-            PermArgs a{cols.u32(), s.d_trace, d_desc.u32(), s.n, s.w, air.n_chal, air.n_lookups, ctx->sys.wm};
-            hipLaunchKernelGGL(perm_entries_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+            PermArgs a{cols.u32(), s.d_trace, d_desc.u32(), s.n, s.w, air.n_chal, air.n_lookups, ctx->sys.wm, (uint32_t)air.used.size(), desc_words};
+            const size_t lds = std::max<size_t>(air.used.size(), 1) * PERM_LD * 4;
+            if (lds > 64 * 1024)
+                RK_HIP_TRY(ctx, hipFuncSetAttribute((const void*)perm_entries_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(perm_entries_kernel, dim3((unsigned)((s.n + PERM_ROWS - 1) / PERM_ROWS)), dim3(PERM_ROWS), lds, ctx->stream, a);
             RK_TRY(rk::post_launch(ctx, "perm_entries_kernel"));
             s.staged.reset();
             // the running sum: four base prefix sums over the row totals, in place
@@ -1258,15 +1282,24 @@ int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t widt
             const uint32_t kind = iw[at], bus = iw[at + 1], is_const = iw[at + 2], mult = iw[at + 3], nv = iw[at + 4];
             if (kind > 1 || bus >= bb::P || is_const > 1 || nv > 64 || at + 5 + nv > n_words) return RK_ERR_INVALID;
             if (is_const ? mult >= bb::P : mult >= width) return RK_ERR_INVALID;
-            air->lookups.insert(air->lookups.end(), {kind, bb::encode(bus), is_const, is_const ? bb::encode(mult) : mult, nv});
+            auto slot = [&](uint32_t col) {
+                auto it = std::find(air->used.begin(), air->used.end(), col);
+                if (it == air->used.end()) {
+                    air->used.push_back(col);
+                    return (uint32_t)air->used.size() - 1;
+                }
+                return (uint32_t)(it - air->used.begin());
+            };
+            air->lookups.insert(air->lookups.end(), {kind, bb::encode(bus), is_const, is_const ? bb::encode(mult) : slot(mult), nv});
             for (uint32_t j = 0; j < nv; j++) {
                 if (iw[at + 5 + j] >= width) return RK_ERR_INVALID;
-                air->lookups.push_back(iw[at + 5 + j]);
+                air->lookups.push_back(slot(iw[at + 5 + j]));
             }
             max_values = std::max(max_values, nv);
             at += 5 + nv;
         }
         if (at != n_words) return RK_ERR_INVALID;
+        if (air->used.size() > 120) return RK_ERR_INVALID;   // the staged tile (120 x 257 words of LDS)
         air->n_lookups = n_interactions;
         if (n_interactions) {
             air->perm_width = 4 * ((n_interactions + 1) / 2 + 1);

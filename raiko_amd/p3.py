@@ -558,20 +558,27 @@ def wide_trace(air, log_n, seed=4):
     return t.astype(np.uint32), []
 
 
-def local_air(width, seed=7):
+def local_air(width, seed=7, lookups=0, ext_w=EXT_W):
     """A chip-shaped AIR for benchmarks whose trace is filled column-wise (no row-to-row recurrence except a counter):
     columns [0, width/2) are inputs -- column 0 counts rows (first row 0, next = local + 1), the others are free --,
-    column width/2 + k = in_i * in_j * in_l + in_m for seeded picks: degree 3, two quotient chunks, 5 ops a constraint."""
+    column width/2 + k = in_i * in_j * in_l + in_m for seeded picks: degree 3, two quotient chunks, 5 ops a constraint.
+    lookups = L: the table also sends L tuples of three columns and receives the same L (sends first, so no batch of two
+    cancels: L + 1 extension columns of permutation trace whose cumulative sum is zero for any trace)."""
     assert width >= 4 and width % 2 == 0
     half = width // 2
     rng = np.random.default_rng(seed)
-    b = AirBuilder(width, 0)
+    b = AirBuilder(width, 0, ext_w)
     b.when_first_row().assert_zero(b.local(0))
     b.when_transition().assert_eq(b.next(0), b.local(0) + 1)
     picks = rng.integers(0, half, size=(half, 4))
     for k in range(half):
         i, j, l, m = (int(v) for v in picks[k])
         b.assert_eq(b.local(half + k), b.local(i) * b.local(j) * b.local(l) + b.local(m))
+    tuples = [[int(v) for v in rng.integers(0, width, size=3)] for _ in range(lookups)]
+    for k, cols in enumerate(tuples):
+        b.send(10 + k, cols)
+    for k, cols in enumerate(tuples):
+        b.receive(10 + k, cols)
     air = b.build()
     air.picks = picks
     return air

@@ -30,6 +30,8 @@ P3_CASES = {
     "sp1_lookup_beside_plain": (1, dict(queries=5, pow_bits=2), [("fib", 9, None), ("lookup", 5, 3), ("cubic", 4, 5)], []),
     "risc0_lookup_k7_blow2": (0, dict(queries=4, pow_bits=2, blowup_log2=2), [("lookup", 7, 5)], [3]),
     "sp1_selfperm_k5": (1, dict(queries=5, pow_bits=2), [("selfperm", 5, 10), ("fib", 3, None)], [4]),
+    # two tuples of 60 values: 120 distinct columns staged per row (the limit), 248 challenge words, 9 rows more than a workgroup takes
+    "sp1_wide_tuples_k9": (1, dict(queries=3, pow_bits=1), [("widetuple", 9, 130)], []),
 }
 
 EXT_W = {0: p3.P - 11, 1: 11}     # the W of the presets' extension x^4 - W (risc0: x^4 + 11)
@@ -50,8 +52,18 @@ def selfperm_air(width, ext_w):
     return b.build()
 
 
+def widetuple_air(width, ext_w):
+    b = p3.AirBuilder(width, 0, ext_w)
+    lo, hi = list(range(60)), list(range(60, 120))
+    b.send(9, lo)
+    b.send(10, hi)
+    b.receive(9, lo)
+    b.receive(10, hi)
+    return b.build()
+
+
 def air_of(name, arg, preset=1):
-    key = (name, arg, preset if name in ("lookup", "selfperm") else None)
+    key = (name, arg, preset if name in ("lookup", "selfperm", "widetuple") else None)
     if key not in _AIRS:
         if name == "empty":      # `width` columns, nothing asserted: a valid AIR whose quotient is zero
             b = p3.AirBuilder(arg)
@@ -61,6 +73,8 @@ def air_of(name, arg, preset=1):
             _AIRS[key] = p3.lookup_demo_airs(EXT_W[preset])
         elif name == "selfperm":
             _AIRS[key] = selfperm_air(arg, EXT_W[preset])
+        elif name == "widetuple":
+            _AIRS[key] = widetuple_air(arg, EXT_W[preset])
         else:
             _AIRS[key] = p3.fibonacci_air() if name == "fib" else p3.cubic_air(arg) if name == "cubic" else p3.wide_air(arg)
     return _AIRS[key]
@@ -78,7 +92,7 @@ def tables_of(case):
             tr, pv = p3.fibonacci_trace(k, 1 + i, 2)
         elif name == "cubic":
             tr, pv = p3.cubic_trace(k, arg, seed=10 + i)
-        elif name in ("empty", "selfperm"):
+        elif name in ("empty", "selfperm", "widetuple"):
             tr, pv = np.random.default_rng(30 + i).integers(0, p3.P, size=(1 << k, arg)), []
         else:
             tr, pv = p3.wide_trace(air, k, seed=20 + i)

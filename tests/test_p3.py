@@ -110,6 +110,9 @@ def test_lookup_air_create_rejects_malformed_interactions():
     assert create([0, 1, 1, 1, 2, 0, 1, 0], 1) == -1         # trailing words
     assert create([0, 1, 1, 1, 65] + [0] * 65, 1) == -1      # tuple too long
     assert create([0, 1, 1, 1, 2, 0, 1], 2) == -1            # count and words disagree
+    wide = [w for k in range(2) for w in [0, 1, 1, 1, 60] + list(range(60 * k, 60 * k + 60))]
+    assert create(wide, 2, width=200) == 0                   # 120 distinct columns: the limit
+    assert create(wide + [0, 1, 1, 1, 1, 120], 3, width=200) == -1
     # the permutation leaves are range-checked against what the interactions give: 1 interaction = 8 base columns,
     # a tuple of 2 = alpha, beta^0..beta^2 = 16 challenge words
     for op, lim in ((p3.PERM_LOCAL, 8), (p3.PERM_NEXT, 8), (p3.CHALLENGE, 16), (p3.CUMSUM, 4)):

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--shards", type=int, default=0, help="also prove this many copies of the shape as independent shards through "
                                                           "rk_p3_prove_shards with --batch of them in flight (SP1's SHARD_BATCH_SIZE)")
     ap.add_argument("--batch", type=int, default=3)
+    ap.add_argument("--lookups", type=int, default=0, help="every table sends and receives this many tuples (2x interactions): "
+                                                           "the permutation argument's cost on top of the plain proof")
     args = ap.parse_args()
     print(json.dumps(run(args)), flush=True)
 
@@ -55,7 +57,7 @@ def run(args):
     cells = 0
     for i, spec in enumerate(args.shape.split(",")):
         k, w = (int(v) for v in spec.split("x"))
-        air = p3.local_air(w, seed=7 + i)
+        air = p3.local_air(w, seed=7 + i, lookups=getattr(args, 'lookups', 0))
         t = p3.Table(air, None, [])
         t.log_height = k
         if args.jit:
@@ -76,7 +78,7 @@ def run(args):
         tm = p3.last_timing(hal)
         if best is None or wall < best[0]:
             best = (wall, tm)
-    out = {"shape": args.shape, "preset": args.preset, "jit": args.jit, "trace_cells": int(cells), "wall_ms": round(best[0], 3),
+    out = {"shape": args.shape, "lookups": getattr(args, "lookups", 0), "perm_width": [t.air.perm_width for t in tables], "preset": args.preset, "jit": args.jit, "trace_cells": int(cells), "wall_ms": round(best[0], 3),
            "stages_ms": {k: round(v, 3) for k, v in best[1].items()}, "proof_words": int(pf.size),
            "cells_per_s": round(cells / best[0] * 1e3, 1), "ops_per_point": [t.air.info()["n_ops"] for t in tables],
            "setup_s": round(setup_s, 2)}
