@@ -546,6 +546,16 @@ int rk_exec_profile(const rk_exec* ex, uint32_t* pcs, uint64_t* cycles, size_t c
 #define RK_TRACE_CODE_COLS 2
 #define RK_TRACE_DATA_COLS 16
 int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t* data);
+/* The two tables the data columns look values up in when the segment is proven as a uni-stark shard with lookups
+ * (rk_air_create_lookup; raiko_amd/executor.py p3_trace_air(lookups=True)) -- what SP1's cpu chip has in its program and
+ * range chips.  Row-major Montgomery words, ready to be an rk_p3_table's trace:
+ *   range_table    65536 x 2: (v, how often v occurs among the ten 16-bit limbs -- pc, next pc, rs1, rs2, rd value -- of
+ *                  the executed cycles)
+ *   program_table  rows x 5: (pc lo, pc hi, instruction lo, instruction hi, cycles spent there), the distinct pairs in
+ *                  ascending order, zero-padded to a power of two >= 2
+ * *program_rows: in = the capacity of program_table in rows, out = the rows needed (RK_ERR_CAPACITY when it did not fit,
+ * nothing written: call again).  Needs rk_exec_opts.record_trace. */
+int rk_exec_lookup_tables(const rk_exec* ex, uint32_t index, uint32_t* range_table, uint32_t* program_table, size_t* program_rows);
 /* the same columns written on the GPU into device buffers (2 and 16 columns of 2^po2 words), asynchronously on the
  * ctx stream: only the executed cycles (28 bytes each) cross PCIe; the trace has been copied when the call returns.
  * Hand the buffers to rk_prove_segment / a session as on_device inputs after rk_sync(ctx). */

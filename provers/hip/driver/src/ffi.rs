@@ -440,6 +440,7 @@ extern "C" {
     pub fn rk_exec_journal(ex: *const rk_exec, out: *mut u8, capacity: usize, len: *mut usize) -> c_int;
     pub fn rk_exec_profile(ex: *const rk_exec, pcs: *mut u32, cycles: *mut u64, capacity: usize, n: *mut usize) -> c_int;
     pub fn rk_exec_witness(ex: *const rk_exec, index: u32, code: *mut u32, data: *mut u32) -> c_int;
+    pub fn rk_exec_lookup_tables(ex: *const rk_exec, index: u32, range_table: *mut u32, program_table: *mut u32, program_rows: *mut usize) -> c_int;
     pub fn rk_exec_witness_device(ctx: *mut rk_ctx, ex: *const rk_exec, index: u32, d_code: *mut u32, d_data: *mut u32) -> c_int;
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;

@@ -106,6 +106,8 @@ class RkSessionOpts(C.Structure):
 
 
 RK_ERR_INVALID = -1
+RK_ERR_CAPACITY = -5
+RK_ERR_INTERNAL = -6
 RK_ERR_VERIFY = -7
 RK_ERR_CALLBACK = -8
 
@@ -237,6 +239,7 @@ SYMBOLS = {
     "rk_exec_journal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rk_exec_profile": (C.c_int, [C.c_void_p, u32p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rk_exec_witness": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
+    "rk_exec_lookup_tables": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, C.POINTER(C.c_size_t)]),
     "rk_exec_witness_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rk_exec_error": (C.c_char_p, [C.c_void_p]),
     "rk_exec_free": (C.c_int, [C.c_void_p]),

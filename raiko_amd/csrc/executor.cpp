@@ -537,6 +537,55 @@ int rk_exec_witness(const rk_exec* ex, uint32_t index, uint32_t* code, uint32_t*
     return RK_OK;
     RK_GUARD_END
 }
+int rk_exec_lookup_tables(const rk_exec* ex, uint32_t index, uint32_t* range_table, uint32_t* program_table, size_t* program_rows) {
+    RK_GUARD_BEGIN
+    if (!ex || !range_table || !program_rows || index >= ex->segments.size() || index >= ex->traces.size()) return RK_ERR_INVALID;
+    const std::vector<TraceRow>& tr = ex->traces[index];
+    if (tr.size() != ex->segments[index].cycles) return RK_ERR_INTERNAL;
+    // one pass over the executed cycles: how often each (pc, instruction) pair ran, how often each 16-bit value occurs
+    // among the ten limbs a row sends to the range table
+    std::vector<uint32_t> hist((size_t)1 << 16, 0);
+    std::unordered_map<uint64_t, uint32_t> seen;
+    seen.reserve(1 << 12);
+    uint64_t last_key = ~(uint64_t)0;
+    uint32_t* last = nullptr;
+    for (const TraceRow& r : tr) {
+        const uint64_t key = (uint64_t)r.pc << 32 | r.ins;
+        if (key != last_key) {
+            last = &seen[key];     // references into an unordered_map stay valid across rehashing
+            last_key = key;
+        }
+        ++*last;
+        for (uint32_t v : {r.pc, r.next, r.a, r.b, r.res}) {
+            hist[v & 0xffffu]++;
+            hist[v >> 16]++;
+        }
+    }
+    size_t rows = 2;
+    while (rows < seen.size()) rows <<= 1;
+    const size_t capacity = *program_rows;
+    *program_rows = rows;
+    if (!program_table || capacity < rows) return RK_ERR_CAPACITY;
+    auto mont = [](uint32_t canon) { return bb::mul(canon, bb::R2); };
+    for (uint32_t v = 0; v < (1u << 16); v++) {
+        range_table[2 * (size_t)v] = mont(v);
+        range_table[2 * (size_t)v + 1] = mont(hist[v]);
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> sorted(seen.begin(), seen.end());
+    std::sort(sorted.begin(), sorted.end());
+    std::memset(program_table, 0, rows * 5 * sizeof(uint32_t));
+    for (size_t i = 0; i < sorted.size(); i++) {
+        const uint32_t pc = (uint32_t)(sorted[i].first >> 32), ins = (uint32_t)sorted[i].first;
+        uint32_t* row = program_table + 5 * i;
+        row[0] = mont(pc & 0xffffu);
+        row[1] = mont(pc >> 16);
+        row[2] = mont(ins & 0xffffu);
+        row[3] = mont(ins >> 16);
+        row[4] = mont(sorted[i].second);
+    }
+    return RK_OK;
+    RK_GUARD_END
+}
 int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data) {
     RK_GUARD_BEGIN
     if (!ctx || !ex || !d_code || !d_data || index >= ex->segments.size() || index >= ex->traces.size()) return RK_ERR_INVALID;

@@ -45,6 +45,9 @@ class Execution:
     witness: Optional[list] = None
     # with profile: [(pc, cycles)], most expensive first (rk_exec_profile)
     profile: Optional[list] = None
+    # with record_trace: per segment (program table (rows, 5), range table (65536, 2)), row-major Montgomery words
+    # (rk_exec_lookup_tables): what p3_shards(lookups=True) puts beside the cpu table
+    lookup_tables: Optional[list] = None
 
 
 class ExecutorError(RuntimeError):
@@ -92,6 +95,17 @@ def execute(elf: bytes, input_words: Sequence[int] = (), segment_limit_po2: int 
                 _lib.check(None, lib.rk_exec_witness(handle, sg.index, code.ctypes.data_as(_lib.u32p), data.ctypes.data_as(_lib.u32p)))
                 witness.append((code, data))
         ex = Execution(segs, buf.raw[: n.value], summ.exit_code, int(summ.total_cycles), int(summ.input_words_read), witness)
+        if record_trace:   # rk_exec_lookup_tables: the program / range tables of the uni-stark form with lookups
+            ex.lookup_tables = []
+            for sg in segs:
+                rng = np.zeros((1 << 16, 2), dtype=np.uint32)
+                rows = C.c_size_t(0)
+                st2 = lib.rk_exec_lookup_tables(handle, sg.index, rng.ctypes.data_as(_lib.u32p), None, C.byref(rows))
+                if st2 != _lib.RK_ERR_CAPACITY:
+                    _lib.check(None, st2 or _lib.RK_ERR_INTERNAL)
+                prog = np.zeros((rows.value, 5), dtype=np.uint32)
+                _lib.check(None, lib.rk_exec_lookup_tables(handle, sg.index, rng.ctypes.data_as(_lib.u32p), prog.ctypes.data_as(_lib.u32p), C.byref(rows)))
+                ex.lookup_tables.append((prog, rng))
         if profile:
             cnt = C.c_size_t(0)
             lib.rk_exec_profile(handle, None, None, 0, C.byref(cnt))
@@ -269,13 +283,24 @@ def execute_and_prove(elf: bytes, input_words: Sequence[int] = (), segment_limit
 
 
 # ---- the same execution proven the way SP1 proves one: shards of a uni-stark proof system (rk_p3_*) ----------------
-def p3_trace_air():
+BUS_PROGRAM, BUS_RANGE16 = 1, 2
+RANGE_LIMB_COLS = (0, 1, 2, 3, 8, 9, 10, 11, 12, 13)     # pc, next pc, rs1, rs2, rd value: lo / hi limbs
+
+
+def p3_trace_air(lookups=False, ext_w=None):
     """The stand-in trace circuit as an AIR over rk_exec_witness's 16 data columns (raiko_amd/p3.py; the risc0-shaped form
     is circuit_program.trace_program): flags are bits, a `seq` row advances pc by 4 with the stated carry, the next row
     starts where this one went, padding is final and does nothing, the first / last pc are the public ones
-    (public values: start lo / hi, end lo / hi).  Degree 2: one quotient chunk.  NOT a zkVM: the pc chain only."""
+    (public values: start lo / hi, end lo / hi).  Degree 2: one quotient chunk.  NOT a zkVM: the pc chain only.
+    lookups: every active row also sends (PROGRAM: pc lo, pc hi, instruction lo, instruction hi) and one (RANGE16: limb)
+    per 16-bit limb column -- the way SP1's cpu chip is tied to its program and range chips (p3_program_air,
+    p3_range_air receive them): 11 interactions, degree 3."""
     from . import p3
-    b = p3.AirBuilder(TRACE_DATA_COLS, 4)
+    b = p3.AirBuilder(TRACE_DATA_COLS, 4, p3.EXT_W if ext_w is None else ext_w)
+    if lookups:
+        b.send(BUS_PROGRAM, [0, 1, 4, 5], mult=15, mult_is_const=False)
+        for c in RANGE_LIMB_COLS:
+            b.send(BUS_RANGE16, [c], mult=15, mult_is_const=False)
     pc_lo, pc_hi, nx_lo, nx_hi = (b.local(c) for c in range(4))
     seq, carry, wr, active = b.local(6), b.local(7), b.local(14), b.local(15)
     for v in (seq, carry, wr, active):
@@ -297,23 +322,68 @@ def p3_trace_air():
     return b.build()
 
 
-def p3_shards(ex: Execution, air=None):
+def p3_program_air(ext_w=None):
+    """(pc lo, pc hi, instruction lo, instruction hi, multiplicity): receives the cpu table's PROGRAM tuples -- SP1's
+    ProgramChip, whose first four columns SP1 commits once per ELF (preprocessed); here they travel in the main trace"""
+    from . import p3
+    b = p3.AirBuilder(5, 0, p3.EXT_W if ext_w is None else ext_w)
+    b.receive(BUS_PROGRAM, [0, 1, 2, 3], mult=4, mult_is_const=False)
+    return b.build()
+
+
+def p3_range_air(ext_w=None):
+    """(v, multiplicity), v counting up from 0 one per row: at 2^16 rows the table of all 16-bit values; receives the
+    RANGE16 tuples (a verifier pins its log_height to 16 -- the proof carries the heights)"""
+    from . import p3
+    b = p3.AirBuilder(2, 0, p3.EXT_W if ext_w is None else ext_w)
+    b.when_first_row().assert_zero(b.local(0))
+    b.when_transition().assert_eq(b.next(0), b.local(0) + 1)
+    b.receive(BUS_RANGE16, [0], mult=1, mult_is_const=False)
+    return b.build()
+
+
+def p3_shards(ex: Execution, air=None, lookups=False, ext_w=None):
     """one shard per executed segment: table = the segment's 16 witness columns as a row-major trace, public values = its
-    first and last pc, transcript seed = the machine-state digests before and after it -> [(tables, init words)]"""
+    first and last pc, transcript seed = the machine-state digests before and after it -> [(tables, init words)].
+    lookups: three tables per shard -- cpu (p3_trace_air(lookups=True)), program (the distinct (pc, instruction) pairs the
+    shard executed with how often), range (2^16 rows with how often each 16-bit value occurs among the cpu limbs)."""
     from . import p3
     if ex.witness is None:
         raise ValueError("execute(..., record_trace=True) first")
-    air = air or p3_trace_air()
+    air = air or p3_trace_air(lookups, ext_w)
+    prog_air, range_air = (p3_program_air(ext_w), p3_range_air(ext_w)) if lookups else (None, None)
     mont = lambda v: (int(v) << 32) % P
     out = []
     for s, (_code, data) in zip(ex.segments, ex.witness):
         pub = np.array([mont(v) for v in (s.start_pc & 0xFFFF, s.start_pc >> 16, s.end_pc & 0xFFFF, s.end_pc >> 16)], dtype=np.uint32)
-        table = p3.Table(air, np.ascontiguousarray(data.T), pub)
-        out.append(([table], np.array(list(s.pre_state) + list(s.post_state), dtype=np.uint32)))
+        tables = [p3.Table(air, np.ascontiguousarray(data.T), pub)]
+        native = getattr(ex, "lookup_tables", None)
+        if lookups and native is not None:       # the native generator's tables (rk_exec_lookup_tables)
+            prog, rng = native[len(out)]
+            tables += [p3.Table(prog_air, prog), p3.Table(range_air, rng)]
+        elif lookups:                            # the same tables from the witness columns in numpy
+            rows = p3.from_mont(data).astype(np.uint64)                                # canonical, column-major
+            rows = rows[:, rows[15] == 1]                                              # the active rows
+            key = (rows[1] << 16 | rows[0]) << 32 | (rows[5] << 16 | rows[4])          # pc, instruction
+            uniq, cnt = np.unique(key, return_counts=True)
+            n_prog = max(2, 1 << int(len(uniq) - 1).bit_length())
+            prog = np.zeros((n_prog, 5), dtype=np.uint64)
+            prog[: len(uniq), 0] = (uniq >> 32) & 0xFFFF
+            prog[: len(uniq), 1] = uniq >> 48
+            prog[: len(uniq), 2] = uniq & 0xFFFF
+            prog[: len(uniq), 3] = (uniq >> 16) & 0xFFFF
+            prog[: len(uniq), 4] = cnt
+            limbs = rows[list(RANGE_LIMB_COLS)].reshape(-1)
+            if limbs.size and int(limbs.max()) >= 1 << 16:
+                raise ValueError("a limb outside 16 bits: the range argument cannot balance")
+            rng = np.stack([np.arange(1 << 16, dtype=np.uint64), np.bincount(limbs.astype(np.int64), minlength=1 << 16).astype(np.uint64)], axis=1)
+            tables += [p3.Table.from_canonical(prog_air, prog), p3.Table.from_canonical(range_air, rng)]
+        out.append((tables, np.array(list(s.pre_state) + list(s.post_state), dtype=np.uint32)))
     return out
 
 
-def execute_and_prove_p3(elf: bytes, input_words: Sequence[int] = (), shard_po2: int = 16, params=None, device: int = 0, batch: int = 3):
+def execute_and_prove_p3(elf: bytes, input_words: Sequence[int] = (), shard_po2: int = 16, params=None, device: int = 0, batch: int = 3,
+                         lookups=False):
     """ELF -> executed shards -> one uni-stark proof per shard through rk_p3_prove_shards (every proof verified inside):
     the shape of `client.prove(&pk, stdin)` on the SP1 side (provers/sp1/driver/src/lib.rs:44-57; SHARD_SIZE / SHARD_BATCH_SIZE,
     docs/README_Sp1.md:19-32) with the stand-in trace AIR in place of SP1's chips.  -> (Execution, shards, proofs)"""
@@ -321,6 +391,6 @@ def execute_and_prove_p3(elf: bytes, input_words: Sequence[int] = (), shard_po2:
     from .hal import make_params
     params = params if params is not None else make_params(1)
     ex = execute(elf, input_words, segment_limit_po2=shard_po2, record_trace=True)
-    shards = p3_shards(ex)
+    shards = p3_shards(ex, lookups=lookups, ext_w=int(params.ext_w))
     proofs = p3.prove_shards(shards, params, device=device, batch=batch, verify=True)
     return ex, shards, proofs

@@ -359,6 +359,13 @@ def to_mont(x):
     return (np.asarray(x, dtype=np.uint64) % P * _R_MOD_P % P).astype(np.uint32)
 
 
+_RINV_MOD_P = pow(1 << 32, -1, P)
+
+
+def from_mont(x):
+    return (np.asarray(x, dtype=np.uint64) % P * _RINV_MOD_P % P).astype(np.uint32)
+
+
 class Table:
     """one table of a proof: a row-major trace (Montgomery words, as every buffer of the ABI), its AIR, its public values"""
 

@@ -275,5 +275,26 @@ def test_trace_air_accepts_executions_and_the_oracle_proves_them():
         forged[100, 0] = (int(forged[100, 0]) + 1) % o.P          # a pc that the previous row did not go to
         ft = [p3.Table(air, forged, tables[0].public_values)]
         assert o.oracle_p3_verify(ft, o.oracle_p3_prove(ft, init), init) == 3
+        # the same shard as three tables tied by lookups: cpu sends (pc, instruction) to a program table and its ten
+        # 16-bit limbs to a range table of 2^16 rows
+        lk = X.p3_shards(ex, lookups=True)
+        assert len(lk) == len(shards)
+        # the native generator (rk_exec_lookup_tables) and the numpy restatement over the witness columns give the same tables
+        native, ex.lookup_tables = ex.lookup_tables, None
+        for (ta, _), (tb, _) in zip(lk, X.p3_shards(ex, lookups=True)):
+            assert all(np.array_equal(a.trace, b.trace) for a, b in zip(ta, tb))
+        ex.lookup_tables = native
+        t3, init3 = lk[0]
+        assert [t.air.width for t in t3] == [16, 5, 2] and t3[2].log_height == 16 and len(t3[0].air.interactions) == 11
+        prog = o.from_mont(t3[1].trace).astype(np.int64)
+        assert int(prog[:, 4].sum()) == ex.segments[0].cycles == int(o.from_mont(t3[2].trace)[:, 1].astype(np.int64).sum()) // 10
+        o.oracle_set_params(1, queries=3, pow_bits=2)
+        pf = o.oracle_p3_prove(t3, init3)
+        blob = __import__("raiko_amd.hal", fromlist=["make_params"]).make_params(1, queries=3, pow_bits=2)
+        assert o.oracle_p3_verify(t3, pf, init3) == 0 == p3.verify(t3, pf, init3, params=blob)
+        lying = o.from_mont(t3[0].trace).astype(np.uint64)
+        lying[50, 8] = 70000                                       # an rs1 "limb" above 16 bits: nothing in the range table to receive it
+        bad = [p3.Table.from_canonical(t3[0].air, lying, o.from_mont(t3[0].public_values))] + t3[1:]
+        assert o.oracle_p3_verify(bad, o.oracle_p3_prove(bad, init3), init3) == 8
     finally:
         o.oracle_set_params()

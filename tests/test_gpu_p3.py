@@ -232,4 +232,15 @@ def test_elf_to_shard_proofs(hal):
     with pytest.raises(RkError) as ei:
         p3.prove_shards(bad, blob, batch=2, verify=True)
     assert ei.value.status == -7 and ei.value.segment == 2
+    # the same execution with the shard's tables tied by lookups (cpu -> program, cpu -> 16-bit range table)
+    ex3, lk, lproofs = X.execute_and_prove_p3(image, shard_po2=13, params=blob, batch=2, lookups=True)
+    assert len(lproofs) == 5 and [len(t) for t, _ in lk] == [3] * 5
+    assert np.array_equal(lproofs[4], o.oracle_p3_prove(*lk[4]))
+    lying = o.from_mont(lk[1][0][0].trace).astype(np.uint64)
+    lying[7, 4] ^= 1                                                   # an instruction word the program table does not hold
+    bad = list(lk)
+    bad[1] = ([p3.Table.from_canonical(lk[1][0][0].air, lying, o.from_mont(lk[1][0][0].public_values))] + lk[1][0][1:], lk[1][1])
+    with pytest.raises(RkError) as ei:
+        p3.prove_shards(bad, blob, batch=2, verify=True)
+    assert ei.value.status == -7 and ei.value.segment == 1
     H.session_release()
