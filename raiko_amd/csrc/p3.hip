@@ -655,52 +655,52 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     const Ext alpha2 = ch.sample_ext();
     DevBuf ro[ntt::LAMBDA + 1];
     uint64_t num_reduced[ntt::LAMBDA + 1] = {0};
+    // every opened value first (no host round trip between the launches), ONE download, then the reduced openings, which
+    // need the opened values on the host: a shard of a dozen tables waits once instead of three dozen times
+    struct Opening {
+        TableState* s;
+        const uint32_t* mat;
+        size_t w, n_points, y_at, d_at;   // y_at: words into s->y; d_at: words into the device buffer
+    };
+    std::vector<Opening> openings;
+    size_t y_words = 0;
+    for (TableState& s : ts) s.y.resize(8 * s.w + 8 * s.pw + ((size_t)16 << s.lqd));
+    auto add_opening = [&](TableState& s, const uint32_t* mat, size_t w, size_t n_points, size_t y_at) {
+        openings.push_back(Opening{&s, mat, w, n_points, y_at, y_words});
+        y_words += 4 * w * n_points;
+    };
+    for (TableState& s : ts) add_opening(s, s.lde.u32(), s.w, 2, 0);                       // round 0: every trace at zeta and zeta * g
+    for (TableState& s : ts)
+        if (s.pw) add_opening(s, s.perm.u32(), s.pw, 2, 8 * s.w);                          // round 1 (lookups): the permutation traces, likewise
+    for (TableState& s : ts) add_opening(s, s.chunks.u32(), (size_t)4 << s.lqd, 1, 8 * s.w + 8 * s.pw);   // last round: every quotient chunk at zeta
     DevBuf d_ys;
-    {
-        size_t wmax = 4;
-        for (const TableState& s : ts) wmax = std::max(std::max(wmax, s.pw), std::max(s.w, (size_t)4 << s.lqd));
-        RK_TRY(d_ys.alloc(ctx, 2 * wmax * 16));
+    RK_TRY(d_ys.alloc(ctx, y_words * 4));
+    auto points_of = [&](const TableState& s, uint32_t pts[8]) {
+        std::memcpy(pts, zeta.c, 16);
+        const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
+        std::memcpy(pts + 4, zn.c, 16);
+    };
+    for (const Opening& o : openings) {
+        uint32_t pts[8];
+        points_of(*o.s, pts);
+        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32() + o.d_at, o.mat, o.s->H, o.w, pts, o.n_points, /*cols=*/true));
     }
-    for (uint32_t t = 0; t < n_tables; t++) {  // round 0: every trace at zeta and zeta * g
-        TableState& s = ts[t];
+    {
+        std::vector<uint32_t> h_ys(y_words);
+        RK_TRY(d2h(ctx, h_ys.data(), d_ys.p, y_words * 4));
+        for (const Opening& o : openings) std::memcpy(o.s->y.data() + o.y_at, &h_ys[o.d_at], 4 * o.w * o.n_points * 4);
+    }
+    for (const Opening& o : openings) {
+        TableState& s = *o.s;
         const unsigned lh = s.k + blow;
         if (!ro[lh].p) {
             RK_TRY(ro[lh].alloc(ctx, s.H * 16));
             RK_HIP_TRY(ctx, hipMemsetAsync(ro[lh].p, 0, s.H * 16, ctx->stream));
         }
         uint32_t pts[8];
-        std::memcpy(pts, zeta.c, 16);
-        const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
-        std::memcpy(pts + 4, zn.c, 16);
-        s.y.resize(8 * s.w + 8 * s.pw + ((size_t)16 << s.lqd));
-        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.lde.u32(), s.H, s.w, pts, 2, /*cols=*/true));
-        RK_TRY(d2h(ctx, s.y.data(), d_ys.p, 8 * s.w * 4));
-        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.lde.u32(), s.H, s.w, 2, pts, s.y.data(), alpha2, num_reduced[lh], /*cols=*/true));
-        num_reduced[lh] += 2 * s.w;
-    }
-    for (uint32_t t = 0; t < n_tables; t++) {  // round 1 (lookups): every permutation trace at zeta and zeta * g
-        TableState& s = ts[t];
-        if (!s.pw) continue;
-        const unsigned lh = s.k + blow;
-        uint32_t pts[8];
-        std::memcpy(pts, zeta.c, 16);
-        const Ext zn = bb::scale(zeta, bb::pow(ctx->sys.root27m, (uint64_t)1 << (27 - s.k)));
-        std::memcpy(pts + 4, zn.c, 16);
-        uint32_t* y = s.y.data() + 8 * s.w;
-        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.perm.u32(), s.H, s.pw, pts, 2, /*cols=*/true));
-        RK_TRY(d2h(ctx, y, d_ys.p, 8 * s.pw * 4));
-        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.perm.u32(), s.H, s.pw, 2, pts, y, alpha2, num_reduced[lh], /*cols=*/true));
-        num_reduced[lh] += 2 * s.pw;
-    }
-    for (uint32_t t = 0; t < n_tables; t++) {  // last round: every quotient chunk at zeta
-        TableState& s = ts[t];
-        const unsigned lh = s.k + blow;
-        const size_t wq = (size_t)4 << s.lqd;
-        uint32_t* y = s.y.data() + 8 * s.w + 8 * s.pw;
-        RK_TRY(rk::pcs_eval_at(ctx, d_ys.u32(), s.chunks.u32(), s.H, wq, zeta.c, 1, /*cols=*/true));
-        RK_TRY(d2h(ctx, y, d_ys.p, wq * 16));
-        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), s.chunks.u32(), s.H, wq, 1, zeta.c, y, alpha2, num_reduced[lh], /*cols=*/true));
-        num_reduced[lh] += wq;
+        points_of(s, pts);
+        RK_TRY(rk::pcs_reduce_openings(ctx, ro[lh].u32(), o.mat, s.H, o.w, o.n_points, pts, s.y.data() + o.y_at, alpha2, num_reduced[lh], /*cols=*/true));
+        num_reduced[lh] += o.n_points * o.w;
     }
     for (const TableState& s : ts) push(s.y.data(), s.y.size());
     lap(tm.open);
