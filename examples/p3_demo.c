@@ -2,8 +2,11 @@
  * (columns left, right; public values a, b, x; first row = (a, b), next.left = right, next.right = left + right,
  * last row's right = x) -- handed over as a step list, proven on the GPU under SP1's parameter set and checked by the
  * host verifier; then the same with a wrong public value (the verifier refuses: reason 3, the constraint identity) and
- * with a changed proof word.  What a host on the SP1 side of raiko (provers/sp1/driver/src/lib.rs:44-57) would call
- * per shard, with its chips' AIRs in place of this one.
+ * with a changed proof word.  Then two tables tied by a lookup (rk_air_create_lookup): a user table sends (x, y) pairs, a
+ * table of squares (v, v * v, multiplicity) receives them -- the library writes the permutation constraints, fills the
+ * permutation traces on the GPU and the verifier checks that the cumulative sums cancel; one multiplicity off by one and
+ * it answers 8.  What a host on the SP1 side of raiko (provers/sp1/driver/src/lib.rs:44-57) would call per shard, with
+ * its chips' AIRs and interactions in place of these.
  *
  *   gcc -O2 -I include examples/p3_demo.c -o p3_demo -L raiko_amd -lraiko_hip -Wl,-rpath,$PWD/raiko_amd
  *   ./p3_demo [log2 rows]
@@ -103,6 +106,56 @@ int main(int argc, char** argv) {
     printf("changed proof word: verifier %d\n", v);
     if (v == 0) return 1;
     printf("fibonacci proven and verified\n");
+
+    /* ---- a lookup between two tables */
+    const rk_air_step sq_steps[] = {   /* squares table: v counts up from 0, sq = v * v */
+        {RK_AIR_LOCAL, 0, 0}, {RK_AIR_LOCAL, 1, 0}, {RK_AIR_NEXT, 0, 0}, {RK_AIR_IS_FIRST_ROW, 0, 0}, {RK_AIR_IS_TRANSITION, 0, 0},
+        {RK_AIR_MUL, 3, 0}, {RK_AIR_ASSERT_ZERO, 5, 0},                                           /* first row: v = 0   */
+        {RK_AIR_CONST, 1, 0}, {RK_AIR_ADD, 0, 6}, {RK_AIR_SUB, 2, 7}, {RK_AIR_MUL, 4, 8}, {RK_AIR_ASSERT_ZERO, 9, 0},   /* next v = v + 1 */
+        {RK_AIR_MUL, 0, 0}, {RK_AIR_SUB, 1, 10}, {RK_AIR_ASSERT_ZERO, 11, 0},                      /* sq = v * v         */
+    };
+    /* interactions: kind (0 send / 1 receive), bus, mult_is_const, mult, n_values, columns */
+    const uint32_t user_ix[] = {0, 9, 1, 1, 2, 0, 1};     /* every row sends (bus 9: x, y) once          */
+    const uint32_t sq_ix[] = {1, 9, 0, 2, 2, 0, 1};       /* receives (bus 9: v, sq) column-2 times      */
+    rk_air *user_air = NULL, *sq_air = NULL;
+    CHECK(rk_air_create_lookup(NULL, 0, 2, 0, user_ix, 1, 7, par.ext_w, &user_air));   /* no constraints of its own */
+    CHECK(rk_air_create_lookup(sq_steps, sizeof sq_steps / sizeof sq_steps[0], 3, 0, sq_ix, 1, 7, par.ext_w, &sq_air));
+    enum { LOG_USER = 9, LOG_SQ = 6 };
+    uint32_t* user = (uint32_t*)malloc(((size_t)2 << LOG_USER) * 4);
+    uint32_t* sq = (uint32_t*)calloc((size_t)3 << LOG_SQ, 4);
+    uint32_t count[1 << LOG_SQ] = {0};
+    for (size_t i = 0; i < ((size_t)1 << LOG_USER); i++) {
+        const uint32_t x = (uint32_t)((i * 2654435761u) >> 7) & ((1u << LOG_SQ) - 1);
+        user[2 * i] = mont(x);
+        user[2 * i + 1] = mont((uint64_t)x * x);
+        count[x]++;
+    }
+    for (uint32_t vv = 0; vv < (1u << LOG_SQ); vv++) {
+        sq[3 * vv] = mont(vv);
+        sq[3 * vv + 1] = mont((uint64_t)vv * vv);
+        sq[3 * vv + 2] = mont(count[vv]);
+    }
+    rk_p3_table pair[2];
+    memset(pair, 0, sizeof pair);
+    pair[0].trace = user, pair[0].log_height = LOG_USER, pair[0].width = 2, pair[0].air = user_air;
+    pair[1].trace = sq, pair[1].log_height = LOG_SQ, pair[1].width = 3, pair[1].air = sq_air;
+    const size_t cap2 = rk_p3_proof_bound_words(&par, pair, 2);
+    uint32_t* proof2 = (uint32_t*)malloc(cap2 * 4);
+    CHECK(rk_p3_prove(ctx, pair, 2, statement, 2, proof2, cap2, &words));
+    v = rk_p3_verify(&par, pair, 2, statement, 2, proof2, words);
+    printf("lookup: 2^%d pairs looked up in a table of 2^%d squares, proof of %zu words, verifier: %d\n", LOG_USER, LOG_SQ, words, v);
+    if (v != 0) return 1;
+    sq[3 * 5 + 2] = mont(count[5] + 1);   /* the table claims one more lookup of 5 than was made */
+    CHECK(rk_p3_prove(ctx, pair, 2, statement, 2, proof2, cap2, &words));
+    v = rk_p3_verify(&par, pair, 2, statement, 2, proof2, words);
+    printf("one multiplicity off by one: verifier %d\n", v);
+    if (v != 8) return 1;
+    printf("lookup proven and verified\n");
+    rk_air_destroy(user_air);
+    rk_air_destroy(sq_air);
+    free(proof2);
+    free(sq);
+    free(user);
     rk_air_destroy(air);
     rk_ctx_destroy(ctx);
     free(proof);

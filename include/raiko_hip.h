@@ -613,11 +613,17 @@ int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint
  * (4 base columns each: 4 * (ceil(n / 2) + 1) in all) --, commits those traces as a second batch and observes root and
  * cumulative sums before the constraint challenge; the verifier also checks that the cumulative sums of all tables add
  * up to zero (reason 8): every tuple sent is received as often.  The constraints tying the permutation trace to the
- * main trace are part of `steps`, written over PERM_LOCAL / PERM_NEXT / CHALLENGE / CUMSUM (raiko_amd/p3.py
- * AirBuilder.send / receive emit them as eval_permutation_constraints does: 4 base asserts per extension identity, the
- * extension's W baked in).  A proof without any interaction keeps the bytes it had before this entry point existed. */
+ * main trace are AIR steps over PERM_LOCAL / PERM_NEXT / CHALLENGE / CUMSUM -- sp1-core's eval_permutation_constraints,
+ * every extension identity as four base asserts: per batch entry * prod rlc_i = sum_i +-mult_i * prod_(j != i) rlc_j,
+ * phi[0] = sum entries[0], phi' = phi + sum entries' on transitions, phi[last] = cumulative sum.  ext_w != 0: `steps`
+ * holds the table's own constraints only (what a chip's Air::eval emits) and the library appends those steps for the
+ * extension x^4 - ext_w (the canonical W of the parameter set the proofs will be made under: 11 for SP1's); ext_w = 0:
+ * `steps` already contains them (raiko_amd/p3.py AirBuilder can write them itself).  rk_air_get_steps reads the full
+ * list back.  A proof without any interaction keeps the bytes it had before this entry point existed. */
 int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public,
-                         const uint32_t* interaction_words, uint32_t n_interactions, size_t n_words, rk_air** out);
+                         const uint32_t* interaction_words, uint32_t n_interactions, size_t n_words, uint32_t ext_w, rk_air** out);
+/* the AIR's complete step list (with the appended lookup constraints); RK_ERR_CAPACITY with *n_steps set when it does not fit */
+int rk_air_get_steps(const rk_air* air, rk_air_step* out, size_t capacity, size_t* n_steps);
 int rk_air_destroy(rk_air* air);
 int rk_air_get_info(const rk_air* air, rk_air_info* out);
 int rk_air_compile(rk_air* air, rk_ctx* ctx);

@@ -445,7 +445,8 @@ extern "C" {
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
     pub fn rk_air_create(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, out: *mut *mut rk_air) -> c_int;
-    pub fn rk_air_create_lookup(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, interaction_words: *const u32, n_interactions: u32, n_words: usize, out: *mut *mut rk_air) -> c_int;
+    pub fn rk_air_create_lookup(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, interaction_words: *const u32, n_interactions: u32, n_words: usize, ext_w: u32, out: *mut *mut rk_air) -> c_int;
+    pub fn rk_air_get_steps(air: *const rk_air, out: *mut rk_air_step, capacity: usize, n_steps: *mut usize) -> c_int;
     pub fn rk_air_destroy(air: *mut rk_air) -> c_int;
     pub fn rk_air_get_info(air: *const rk_air, out: *mut rk_air_info) -> c_int;
     pub fn rk_air_compile(air: *mut rk_air, ctx: *mut rk_ctx) -> c_int;

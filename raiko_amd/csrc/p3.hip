@@ -30,6 +30,7 @@
 #include "internal.hpp"
 #include "circuit_program.hpp"
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -39,6 +40,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <tuple>
 
 struct rk_air {
     std::vector<rk_air_step> steps;
@@ -136,6 +138,89 @@ int air_scan(const rk_air_step* steps, size_t n, uint32_t width, uint32_t n_publ
     info->log_quotient_degree = log2u(std::max(max_deg, 2u) - 1);
     return RK_OK;
 }
+
+// sp1-core eval_permutation_constraints (RECALLED) written into a step list over base values: every extension identity
+// is four base asserts (the evaluator works on base columns; W is baked in).  `raw` = the caller's interactions as given
+// (canonical constants, column numbers).  Appended to `steps`, whose values so far number `nv`.  Equal values are shared.
+struct PermStepGen {
+    std::vector<rk_air_step>& steps;
+    uint32_t nv, w;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> memo;
+    using E = std::array<uint32_t, 4>;
+    uint32_t push(uint32_t op, uint32_t a = 0, uint32_t b = 0) {
+        const auto key = std::make_tuple(op, a, b);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        steps.push_back(rk_air_step{op, a, b});
+        memo.emplace(key, nv);
+        return nv++;
+    }
+    void assert_zero(uint32_t v) { steps.push_back(rk_air_step{RK_AIR_ASSERT_ZERO, v, 0}); }
+    E leaf(uint32_t op, uint32_t at) { return E{push(op, 4 * at), push(op, 4 * at + 1), push(op, 4 * at + 2), push(op, 4 * at + 3)}; }
+    E add(const E& x, const E& y) { return E{push(RK_AIR_ADD, x[0], y[0]), push(RK_AIR_ADD, x[1], y[1]), push(RK_AIR_ADD, x[2], y[2]), push(RK_AIR_ADD, x[3], y[3])}; }
+    E sub(const E& x, const E& y) { return E{push(RK_AIR_SUB, x[0], y[0]), push(RK_AIR_SUB, x[1], y[1]), push(RK_AIR_SUB, x[2], y[2]), push(RK_AIR_SUB, x[3], y[3])}; }
+    E scale(const E& x, uint32_t e) { return E{push(RK_AIR_MUL, x[0], e), push(RK_AIR_MUL, x[1], e), push(RK_AIR_MUL, x[2], e), push(RK_AIR_MUL, x[3], e)}; }
+    E mul(const E& x, const E& y) {   // modulo t^4 - W
+        E out;
+        for (int k = 0; k < 4; k++) {
+            uint32_t t = push(RK_AIR_MUL, x[0], y[k]);
+            for (int i = 1; i <= k; i++) t = push(RK_AIR_ADD, t, push(RK_AIR_MUL, x[i], y[k - i]));
+            if (k < 3) {
+                uint32_t h = push(RK_AIR_MUL, x[k + 1], y[3]);
+                for (int i = k + 2; i < 4; i++) h = push(RK_AIR_ADD, h, push(RK_AIR_MUL, x[i], y[k + 4 - i]));
+                t = push(RK_AIR_ADD, t, push(RK_AIR_MUL, h, push(RK_AIR_CONST, w)));
+            }
+            out[k] = t;
+        }
+        return out;
+    }
+    void assert_ext_zero(int32_t cond, const E& x) {
+        for (int k = 0; k < 4; k++) assert_zero(cond < 0 ? x[k] : push(RK_AIR_MUL, (uint32_t)cond, x[k]));
+    }
+    void run(const uint32_t* raw, uint32_t n_lookups) {
+        struct Ix {
+            uint32_t kind, bus, is_const, mult, nv;
+            const uint32_t* cols;
+        };
+        std::vector<Ix> its;
+        for (uint32_t i = 0; i < n_lookups; i++) {
+            its.push_back(Ix{raw[0], raw[1], raw[2], raw[3], raw[4], raw + 5});
+            raw += 5 + raw[4];
+        }
+        const uint32_t nb = (n_lookups + 1) / 2;
+        const E alpha = leaf(RK_AIR_CHALLENGE, 0);
+        auto rlc = [&](const Ix& it) {
+            E acc = add(alpha, scale(leaf(RK_AIR_CHALLENGE, 1), push(RK_AIR_CONST, it.bus)));
+            for (uint32_t j = 0; j < it.nv; j++) acc = add(acc, scale(leaf(RK_AIR_CHALLENGE, 2 + j), push(RK_AIR_LOCAL, it.cols[j])));
+            return acc;
+        };
+        auto signed_mult = [&](const Ix& it) {
+            const uint32_t m = it.is_const ? push(RK_AIR_CONST, it.mult) : push(RK_AIR_LOCAL, it.mult);
+            return it.kind == 0 ? m : push(RK_AIR_NEG, m);
+        };
+        std::vector<E> el, en;
+        for (uint32_t b = 0; b < nb; b++) el.push_back(leaf(RK_AIR_PERM_LOCAL, b));
+        for (uint32_t b = 0; b < nb; b++) en.push_back(leaf(RK_AIR_PERM_NEXT, b));
+        for (uint32_t b = 0; b < nb; b++) {
+            if (2 * b + 1 < n_lookups) {   // entry * rlc0 * rlc1 = m0 * rlc1 + m1 * rlc0
+                const E r0 = rlc(its[2 * b]), r1 = rlc(its[2 * b + 1]);
+                const E lhs = mul(mul(el[b], r0), r1);
+                const E rhs = add(scale(r1, signed_mult(its[2 * b])), scale(r0, signed_mult(its[2 * b + 1])));
+                assert_ext_zero(-1, sub(lhs, rhs));
+            } else {                       // entry * rlc = m
+                const E lhs = mul(el[b], rlc(its[2 * b]));
+                assert_zero(push(RK_AIR_SUB, lhs[0], signed_mult(its[2 * b])));
+                for (int k = 1; k < 4; k++) assert_zero(lhs[k]);
+            }
+        }
+        const E phi_l = leaf(RK_AIR_PERM_LOCAL, nb), phi_n = leaf(RK_AIR_PERM_NEXT, nb);
+        E sum_l = el[0], sum_n = en[0];
+        for (uint32_t b = 1; b < nb; b++) sum_l = add(sum_l, el[b]), sum_n = add(sum_n, en[b]);
+        assert_ext_zero((int32_t)push(RK_AIR_IS_FIRST_ROW), sub(phi_l, sum_l));
+        assert_ext_zero((int32_t)push(RK_AIR_IS_TRANSITION), sub(sub(phi_n, phi_l), sum_n));
+        assert_ext_zero((int32_t)push(RK_AIR_IS_LAST_ROW), sub(phi_l, leaf(RK_AIR_CUMSUM, 0)));
+    }
+};
 
 // folder.rs on extension elements (the verifier's side): accumulator = accumulator * alpha + x per assert, in order
 struct PermView {   // the verifier's view of a table's lookup argument (all null without one)
@@ -1264,15 +1349,19 @@ int rk_p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size
 }
 
 int rk_air_create(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, rk_air** out) {
-    return rk_air_create_lookup(steps, n_steps, width, n_public, nullptr, 0, 0, out);
+    return rk_air_create_lookup(steps, n_steps, width, n_public, nullptr, 0, 0, 0, out);
 }
-int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t width, uint32_t n_public, const uint32_t* iw,
-                         uint32_t n_interactions, size_t n_words, rk_air** out) {
+int rk_air_create_lookup(const rk_air_step* steps_in, size_t n_steps_in, uint32_t width, uint32_t n_public, const uint32_t* iw,
+                         uint32_t n_interactions, size_t n_words, uint32_t ext_w, rk_air** out) {
     RK_GUARD_BEGIN
     if (!out) return RK_ERR_INVALID;
     *out = nullptr;
-    if (!steps || n_steps == 0 || n_steps > ((size_t)1 << 27) || width == 0 || width > (1u << 16) || n_public > (1u << 20)) return RK_ERR_INVALID;
+    const rk_air_step* steps = steps_in;
+    size_t n_steps = n_steps_in;
+    // a table that only takes part in lookups has no constraints of its own: an empty list is fine when the library writes the rest
+    if (((!steps || n_steps == 0) && !(ext_w && n_steps == 0)) || n_steps > ((size_t)1 << 27) || width == 0 || width > (1u << 16) || n_public > (1u << 20)) return RK_ERR_INVALID;
     if (n_interactions > 4096 || (n_interactions && !iw) || (!n_interactions && n_words)) return RK_ERR_INVALID;
+    if (ext_w >= bb::P || (ext_w && !n_interactions)) return RK_ERR_INVALID;
     std::unique_ptr<rk_air> air(new rk_air);
     {   // the interactions: kind, bus, mult_is_const, mult, n_values, columns...
         size_t at = 0;
@@ -1307,6 +1396,17 @@ int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t widt
         }
     }
     const uint32_t pw = air->perm_width, n_chal = air->n_chal;
+    std::vector<rk_air_step> extended;
+    if (ext_w) {   // the caller's list holds the main constraints only: append eval_permutation_constraints for x^4 - ext_w
+        if (n_steps) RK_TRY(air_scan(steps, n_steps, width, n_public, 0, 0, &air->info));   // ... and may not name the permutation trace itself
+        if (n_steps) extended.assign(steps, steps + n_steps);
+        uint32_t nv = 0;
+        for (const rk_air_step& st : extended) nv += st.op != RK_AIR_ASSERT_ZERO;
+        PermStepGen gen{extended, nv, ext_w, {}};
+        gen.run(iw, n_interactions);
+        steps = extended.data();
+        n_steps = extended.size();
+    }
     RK_TRY(air_scan(steps, n_steps, width, n_public, pw, n_chal, &air->info));
     air->steps.assign(steps, steps + n_steps);
     air->width = width;
@@ -1368,6 +1468,13 @@ int rk_air_create_lookup(const rk_air_step* steps, size_t n_steps, uint32_t widt
     *out = air.release();
     return RK_OK;
     RK_GUARD_END
+}
+int rk_air_get_steps(const rk_air* air, rk_air_step* out, size_t capacity, size_t* n_steps) {
+    if (!air || !n_steps) return RK_ERR_INVALID;
+    *n_steps = air->steps.size();
+    if (!out || capacity < air->steps.size()) return RK_ERR_CAPACITY;
+    std::memcpy(out, air->steps.data(), air->steps.size() * sizeof(rk_air_step));
+    return RK_OK;
 }
 int rk_air_destroy(rk_air* air) {
     RK_GUARD_BEGIN

@@ -118,11 +118,27 @@ class _When:
 class Air:
     """steps: (n, 3) uint32 array of (op, a, b)"""
 
-    def __init__(self, steps, width, n_public, interactions=()):
+    def __init__(self, steps, width, n_public, interactions=(), append_lookup_constraints_w=0):
+        """append_lookup_constraints_w = W: `steps` holds the table's own constraints only and rk_air_create_lookup appends
+        the permutation constraints for the extension x^4 - W (self.steps is then read back from the library)"""
         self.steps = np.ascontiguousarray(steps, dtype=np.uint32).reshape(-1, 3)
         self.width, self.n_public = int(width), int(n_public)
         self.interactions = list(interactions)
         self._handle = None
+        if append_lookup_constraints_w:
+            assert self.interactions
+            lib = _lib.load()
+            h = C.c_void_p()
+            iw = self.interaction_words()
+            _lib.check(None, lib.rk_air_create_lookup(self.steps.ctypes.data if self.steps.size else None, self.steps.shape[0], self.width,
+                                                      self.n_public, iw.ctypes.data_as(_lib.u32p), len(self.interactions), iw.size,
+                                                      int(append_lookup_constraints_w) % P, C.byref(h)))
+            self._handle = h
+            n = C.c_size_t(0)
+            lib.rk_air_get_steps(h, None, 0, C.byref(n))
+            full = np.zeros((n.value, 3), dtype=np.uint32)
+            _lib.check(None, lib.rk_air_get_steps(h, full.ctypes.data, n.value, C.byref(n)))
+            self.steps = full
 
     @property
     def perm_width(self):
@@ -145,7 +161,7 @@ class Air:
             if self.interactions:
                 iw = self.interaction_words()
                 _lib.check(None, lib.rk_air_create_lookup(self.steps.ctypes.data, self.steps.shape[0], self.width, self.n_public,
-                                                          iw.ctypes.data_as(_lib.u32p), len(self.interactions), iw.size, C.byref(h)))
+                                                          iw.ctypes.data_as(_lib.u32p), len(self.interactions), iw.size, 0, C.byref(h)))
             else:
                 _lib.check(None, lib.rk_air_create(self.steps.ctypes.data, self.steps.shape[0], self.width, self.n_public, C.byref(h)))
             self._handle = h
@@ -345,7 +361,14 @@ class AirBuilder:
         self._assert_ext_zero(self.is_transition(), phi_n - phi_l - sum_n)
         self._assert_ext_zero(self.is_last_row(), phi_l - self._ext_leaf(CUMSUM, 0))
 
-    def build(self):
+    def build(self, library_constraints=False):
+        """library_constraints: leave the permutation constraints of an AIR with lookups to rk_air_create_lookup (what a
+        binding that only has a chip's own Air::eval would do) instead of writing them here -- the same polynomial
+        identities either way, hence the same proofs"""
+        if self.interactions and library_constraints:
+            assert not getattr(self, "_perm_done", False)
+            return Air(np.array(self.steps, dtype=np.uint32).reshape(-1, 3), self.width, self.n_public, self.interactions,
+                       append_lookup_constraints_w=self.ext_w)
         if self.interactions and not getattr(self, "_perm_done", False):
             self._perm_constraints()
             self._perm_done = True

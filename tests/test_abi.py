@@ -161,3 +161,5 @@ def test_plain_c_caller_proves_an_air(tmp_path):
         r = subprocess.run([exe, k], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout, r.stderr)
         assert "verifier: 0" in r.stdout and "wrong public value: verifier 3" in r.stdout and "fibonacci proven and verified" in r.stdout
+        # two tables tied by a lookup, the permutation constraints written by the library (rk_air_create_lookup with ext_w)
+        assert "squares, proof of" in r.stdout and "one multiplicity off by one: verifier 8" in r.stdout and "lookup proven and verified" in r.stdout

@@ -92,10 +92,10 @@ def test_lookup_air_create_rejects_malformed_interactions():
     import ctypes as C
     steps = np.array([(p3.LOCAL, 0, 0)], dtype=np.uint32)
 
-    def create(words, n, width=3, steps=steps):
+    def create(words, n, width=3, steps=steps, ext_w=0):
         w = np.array(words, dtype=np.uint32)
         h = C.c_void_p()
-        rc = lib.rk_air_create_lookup(steps.ctypes.data, steps.shape[0], width, 0, w.ctypes.data_as(_lib.u32p), n, w.size, C.byref(h))
+        rc = lib.rk_air_create_lookup(steps.ctypes.data, steps.shape[0], width, 0, w.ctypes.data_as(_lib.u32p), n, w.size, ext_w, C.byref(h))
         if rc == 0:
             lib.rk_air_destroy(h)
         return rc
@@ -119,6 +119,63 @@ def test_lookup_air_create_rejects_malformed_interactions():
         ok = np.array([(op, lim - 1, 0)], dtype=np.uint32)
         bad = np.array([(op, lim, 0)], dtype=np.uint32)
         assert create([0, 1, 1, 1, 2, 0, 1], 1, steps=ok) == 0 and create([0, 1, 1, 1, 2, 0, 1], 1, steps=bad) == -1
+
+
+def test_library_written_lookup_constraints_give_the_same_proofs(params):
+    """rk_air_create_lookup with ext_w != 0 appends eval_permutation_constraints itself (a binding hands over the chip's
+    own constraints and its interactions, nothing else): the same identities as AirBuilder writes, so the oracle's proof
+    over either list is the same words"""
+    import ctypes as C
+    from p3_cases import EXT_W, selfperm_air, widetuple_air
+    for preset in (0, 1):
+        over = dict(queries=4, pow_bits=2)
+        params(preset, **over)
+        blob = hal.make_params(preset, **over)
+        w = EXT_W[preset]
+
+        def both(make, trace):
+            b1, b2 = make(), make()
+            a_py, a_lib = b1.build(), b2.build(library_constraints=True)
+            assert a_lib.steps.shape[0] > len(b2.steps) and a_lib.n_constraints == a_py.n_constraints
+            assert a_lib.info()["log_quotient_degree"] == a_py.info()["log_quotient_degree"] == a_py.log_quotient_degree()
+            return p3.Table.from_canonical(a_py, trace), p3.Table.from_canonical(a_lib, trace)
+
+        def cpu():
+            b = p3.AirBuilder(5, 0, w)
+            b.assert_zero(b.local(4) * (b.local(4) - 1))
+            b.send(2, [0, 1, 2], mult=4, mult_is_const=False)
+            b.send(3, [0, 1, 3], mult=4, mult_is_const=False)
+            b.send(1, [0], mult=4, mult_is_const=False)
+            return b
+
+        def selfp():
+            b = p3.AirBuilder(10, 0, w)
+            for kind, bus, cols, m, const in ((0, 5, list(range(8)), 2, True), (1, 5, list(range(8)), 1, True), (1, 5, list(range(8)), 1, True),
+                                              (0, 6, [3], 8, False), (1, 6, [3], 8, False), (0, 7, [], 5, True), (1, 7, [], 5, True)):
+                (b.send if kind == 0 else b.receive)(bus, cols, mult=m, mult_is_const=const)
+            return b
+
+        rng = np.random.default_rng(preset)
+        demo = p3.lookup_demo_tables(4, 3, seed=3, ext_w=w)
+        t_py, t_lib = both(cpu, o.from_mont(demo[0].trace))
+        s_py, s_lib = both(selfp, rng.integers(0, P, size=(16, 10)))
+        init = p3.to_mont([preset])
+        pf_py = o.oracle_p3_prove([t_py] + demo[1:] + [s_py], init)
+        pf_lib = o.oracle_p3_prove([t_lib] + demo[1:] + [s_lib], init)
+        assert np.array_equal(pf_py, pf_lib)
+        assert p3.verify([t_lib] + demo[1:] + [s_lib], pf_py, init, params=blob) == 0
+    # the caller's list may not name the permutation trace when the library writes those constraints; W must be canonical
+    lib = _lib.load()
+    h = C.c_void_p()
+    iw = np.array([0, 1, 1, 1, 1, 0], dtype=np.uint32)
+    for steps, ext_w, want in (([(p3.LOCAL, 0, 0)], 11, 0), ([(p3.PERM_LOCAL, 0, 0)], 11, -1), ([(p3.LOCAL, 0, 0)], P, -1)):
+        a = np.array(steps, dtype=np.uint32)
+        rc = lib.rk_air_create_lookup(a.ctypes.data, a.shape[0], 2, 0, iw.ctypes.data_as(_lib.u32p), 1, iw.size, ext_w, C.byref(h))
+        assert rc == want
+        if rc == 0:
+            lib.rk_air_destroy(h)
+    a = np.array([(p3.LOCAL, 0, 0)], dtype=np.uint32)
+    assert lib.rk_air_create_lookup(a.ctypes.data, 1, 2, 0, None, 0, 0, 11, C.byref(h)) == -1      # W without interactions
 
 
 @pytest.mark.parametrize("preset", [0, 1])
