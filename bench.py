@@ -53,6 +53,8 @@ def parse_args():
                          "chip-shaped synthetic AIR under SP1's parameter set); its line has its own metric")
     ap.add_argument("--p3-shape", default="20x256,19x128,16x64,10x32", help="--preset sp1-p3: log2 rows x columns per table")
     ap.add_argument("--p3-jit", action="store_true", help="--preset sp1-p3: quotient through the hiprtc-generated kernel")
+    ap.add_argument("--p3-lookups", type=int, default=0, help="--preset sp1-p3: every table sends and receives this many tuples "
+                                                              "(2x interactions) through the permutation argument")
     ap.add_argument("--circuit", type=str, default="8000",
                     help="comma-separated op counts, e.g. 8000,33000: for each, the same S20 session again with the circuit's "
                          "two stages inside the timed region -- eval_check from a synthetic step list of that many ops over "
@@ -87,13 +89,14 @@ def main_p3(args):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_p3
     ns = argparse.Namespace(shape=args.p3_shape, jit=args.p3_jit, reps=min(max(args.steps, 1), 5), preset=1, no_verify=False,
-                            shards=max(args.steps, 1), batch=args.inflight)
+                            shards=max(args.steps, 1), batch=args.inflight, lookups=args.p3_lookups)
     r = bench_p3.run(ns)
     out = {"metric": "proven trace cells/sec (Plonky3-style uni-stark, SP1 parameter set; NOT the contract metric)",
            "value": r["cells_per_s"], "unit": "cells/s", "n_gpus": 1, "steps": ns.reps, "warmup": 1, "ms_per_step": r["wall_ms"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
            "config": {"workload": "one rk_p3_prove of tables %s (log2 rows x columns, chip-shaped degree-3 AIR, %s ops per quotient "
-                                  "point), blow-up 2, 100 queries, 16 proof-of-work bits, Poseidon2 width 16" % (r["shape"], r["ops_per_point"]),
+                                  "point%s), blow-up 2, 100 queries, 16 proof-of-work bits, Poseidon2 width 16"
+                                  % (r["shape"], r["ops_per_point"], ", %d interactions per table" % (2 * r["lookups"]) if r["lookups"] else ""),
                       "entry_point": "rk_p3_prove (on_device traces) + rk_p3_verify", "quotient": "generated kernel" if r["jit"] else "interpreter"},
            "stages_ms": r["stages_ms"], "proof_words": r["proof_words"], "verify_rc": r["verify_rc"], "verify_ms": r["verify_ms"],
            "one_proof_at_a_time": {"cells_per_s": r["cells_per_s"], "ms": r["wall_ms"]}}

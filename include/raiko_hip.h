@@ -627,6 +627,20 @@ int rk_air_get_steps(const rk_air* air, rk_air_step* out, size_t capacity, size_
 int rk_air_destroy(rk_air* air);
 int rk_air_get_info(const rk_air* air, rk_air_info* out);
 int rk_air_compile(rk_air* air, rk_ctx* ctx);
+/* The Poseidon2 chip: a table whose every row is one permutation of the parameter set's instance (width 16 or 24, either
+ * 4x4 block) with the intermediate values a degree-3 AIR needs in columns -- the shape of sp1-recursion-core's Poseidon2
+ * wide chip (RECALLED; outside the reference tree), the table a recursion / compress layer spends most of its rows on:
+ * every Merkle path step and sponge block of a proof it verifies is one lookup (bus: in[0..W), out[0..8)) into it.
+ * Columns: in W | external rounds 0..3: cube W, state after the round W | internal rounds: cube of cell 0 (R_P), cell 0
+ * entering rounds 1.. (R_P - 1) | state after the internal rounds W | external rounds 4..7 | multiplicity; x^7 = cube *
+ * cube * x, so every constraint has degree 3 (two quotient chunks).  314 columns for width 16, 474 for width 24.
+ * rk_p2_chip_air: the AIR (step list written by the library, one receive interaction on `bus` with the multiplicity
+ * column); rk_p2_chip_trace: the rows on the GPU under the context's parameter set, one lane per permutation -- d_inputs
+ * n x W row-major Montgomery words, d_mult n multiplicities or NULL for ones, d_trace n x rk_p2_chip_width row-major:
+ * ready to be an on_device rk_p3_table.  params NULL = the SP1 preset. */
+uint32_t rk_p2_chip_width(const rk_params* params);
+int rk_p2_chip_air(const rk_params* params, uint32_t bus, rk_air** out);
+int rk_p2_chip_trace(rk_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_mult, size_t n, uint32_t* d_trace);
 /* One table of a proof.  trace: row-major 2^log_height x width Montgomery words (Plonky3's RowMajorMatrix), in host
  * memory or -- on_device = 1 -- in the memory of the context's GPU (left untouched). */
 typedef struct {

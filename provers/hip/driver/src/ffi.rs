@@ -450,6 +450,9 @@ extern "C" {
     pub fn rk_air_destroy(air: *mut rk_air) -> c_int;
     pub fn rk_air_get_info(air: *const rk_air, out: *mut rk_air_info) -> c_int;
     pub fn rk_air_compile(air: *mut rk_air, ctx: *mut rk_ctx) -> c_int;
+    pub fn rk_p2_chip_width(params: *const rk_params) -> u32;
+    pub fn rk_p2_chip_air(params: *const rk_params, bus: u32, out: *mut *mut rk_air) -> c_int;
+    pub fn rk_p2_chip_trace(ctx: *mut rk_ctx, d_inputs: *const u32, d_mult: *const u32, n: usize, d_trace: *mut u32) -> c_int;
     pub fn rk_p3_prove(ctx: *mut rk_ctx, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, h_proof: *mut u32, capacity_words: usize, proof_words: *mut usize) -> c_int;
     pub fn rk_p3_verify(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, proof: *const u32, proof_words: usize) -> c_int;
     pub fn rk_p3_proof_bound_words(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32) -> usize;

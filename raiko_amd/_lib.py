@@ -252,6 +252,9 @@ SYMBOLS = {
     "rk_program_poly_ext": (C.c_int, [_vp, _u32, u32p, u32p, _sz, u32p, _u32, u32p, _u32, u32p]),
     "rk_air_create": (C.c_int, [_vp, _sz, _u32, _u32, C.POINTER(_vp)]),
     "rk_air_create_lookup": (C.c_int, [_vp, _sz, _u32, _u32, u32p, _u32, _sz, _u32, C.POINTER(_vp)]),
+    "rk_p2_chip_width": (_u32, [C.POINTER(RkParams)]),
+    "rk_p2_chip_air": (C.c_int, [C.POINTER(RkParams), _u32, C.POINTER(_vp)]),
+    "rk_p2_chip_trace": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "rk_air_get_steps": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "rk_air_destroy": (C.c_int, [_vp]),
     "rk_air_get_info": (C.c_int, [_vp, C.POINTER(RkAirInfo)]),

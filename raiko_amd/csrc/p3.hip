@@ -156,6 +156,11 @@ struct PermStepGen {
         return nv++;
     }
     void assert_zero(uint32_t v) { steps.push_back(rk_air_step{RK_AIR_ASSERT_ZERO, v, 0}); }
+    uint32_t add(uint32_t a, uint32_t b) { return push(RK_AIR_ADD, a, b); }
+    uint32_t sub(uint32_t a, uint32_t b) { return push(RK_AIR_SUB, a, b); }
+    uint32_t mul(uint32_t a, uint32_t b) { return push(RK_AIR_MUL, a, b); }
+    uint32_t cst(uint32_t canon) { return push(RK_AIR_CONST, canon); }
+    uint32_t col(uint32_t c) { return push(RK_AIR_LOCAL, c); }
     E leaf(uint32_t op, uint32_t at) { return E{push(op, 4 * at), push(op, 4 * at + 1), push(op, 4 * at + 2), push(op, 4 * at + 3)}; }
     E add(const E& x, const E& y) { return E{push(RK_AIR_ADD, x[0], y[0]), push(RK_AIR_ADD, x[1], y[1]), push(RK_AIR_ADD, x[2], y[2]), push(RK_AIR_ADD, x[3], y[3])}; }
     E sub(const E& x, const E& y) { return E{push(RK_AIR_SUB, x[0], y[0]), push(RK_AIR_SUB, x[1], y[1]), push(RK_AIR_SUB, x[2], y[2]), push(RK_AIR_SUB, x[3], y[3])}; }
@@ -221,6 +226,158 @@ struct PermStepGen {
         assert_ext_zero((int32_t)push(RK_AIR_IS_LAST_ROW), sub(phi_l, leaf(RK_AIR_CUMSUM, 0)));
     }
 };
+
+// ---------------------------------------------------------------- the Poseidon2 chip (rk_p2_chip_*)
+// One row = one permutation of the configured instance with the values a degree-3 AIR needs in columns -- the shape of
+// sp1-recursion-core's Poseidon2 wide chip (RECALLED), the table a recursion / compress layer spends most of its rows
+// on (every Merkle path step and sponge block of the proofs it verifies is one lookup into it):
+//   in W | per external round r = 0..3: x3_r W (the cube of state + rc), post_r W (the state after the round) |
+//   x3i_k R_P (cube of cell 0 + rc in internal round k) | s0_k R_P - 1 (cell 0 entering internal round k >= 1) |
+//   int_out W (the state after the internal rounds) | external rounds 4..7 likewise | multiplicity
+// x^7 = x3 * x3 * x keeps every constraint at degree 3; between commitments the state is carried as expressions.
+struct P2ChipLayout {
+    uint32_t W, RP, width;
+    RK_HD uint32_t in() const { return 0; }
+    RK_HD uint32_t x3(uint32_t r) const { return r < 4 ? W + 2 * W * r : W + 8 * W + 2 * RP - 1 + W + 2 * W * (r - 4); }
+    RK_HD uint32_t post(uint32_t r) const { return x3(r) + W; }
+    RK_HD uint32_t x3i(uint32_t k) const { return W + 8 * W + k; }
+    RK_HD uint32_t s0(uint32_t k) const { return W + 8 * W + RP + (k - 1); }   // k >= 1
+    RK_HD uint32_t int_out() const { return W + 8 * W + 2 * RP - 1; }
+    RK_HD uint32_t mult() const { return width - 1; }
+    RK_HD uint32_t out() const { return post(7); }
+};
+P2ChipLayout p2_chip_layout(const p2::Any& k) {
+    P2ChipLayout L;
+    L.W = (uint32_t)k.cells();
+    L.RP = (uint32_t)k.rounds_partial();
+    L.width = L.W + 16 * L.W + 2 * L.RP - 1 + L.W + 1;
+    return L;
+}
+void p2_chip_steps(const p2::Any& k, std::vector<rk_air_step>& steps) {
+    const P2ChipLayout L = p2_chip_layout(k);
+    const uint32_t W = L.W;
+    PermStepGen g{steps, 0, 0, {}};
+    auto m_ext = [&](std::vector<uint32_t>& c) {   // the external layer on expressions: the 4x4 block on every four cells, then the sums of the cells four apart
+        uint32_t sums[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < W; i += 4) {
+            const uint32_t a = c[i], b = c[i + 1], d = c[i + 2], e = c[i + 3];
+            if (!k.m4()) {
+                const uint32_t t0 = g.add(a, b), t1 = g.add(d, e), t2 = g.add(g.add(b, b), t1), t3 = g.add(g.add(e, e), t0);
+                const uint32_t t1_4 = g.add(g.add(t1, t1), g.add(t1, t1)), t0_4 = g.add(g.add(t0, t0), g.add(t0, t0));
+                const uint32_t t4 = g.add(t1_4, t3), t5 = g.add(t0_4, t2);
+                c[i] = g.add(t3, t5), c[i + 1] = t5, c[i + 2] = g.add(t2, t4), c[i + 3] = t4;
+            } else {
+                const uint32_t s = g.add(g.add(a, b), g.add(d, e));
+                c[i] = g.add(g.add(s, a), g.add(b, b));
+                c[i + 1] = g.add(g.add(s, b), g.add(d, d));
+                c[i + 2] = g.add(g.add(s, d), g.add(e, e));
+                c[i + 3] = g.add(g.add(s, e), g.add(a, a));
+            }
+            for (int j = 0; j < 4; j++) sums[j] = i == 0 ? c[j] : g.add(sums[j], c[i + j]);
+        }
+        for (uint32_t i = 0; i < W; i++) c[i] = g.add(c[i], sums[i & 3]);
+    };
+    auto ext_round = [&](std::vector<uint32_t>& st, uint32_t r) {
+        std::vector<uint32_t> x7(W);
+        for (uint32_t i = 0; i < W; i++) {
+            const uint32_t s = g.add(st[i], g.cst(bb::decode(k.rc_ext()[r * W + i]))), x3 = g.col(L.x3(r) + i);
+            g.assert_zero(g.sub(x3, g.mul(g.mul(s, s), s)));
+            x7[i] = g.mul(g.mul(x3, x3), s);
+        }
+        m_ext(x7);
+        for (uint32_t i = 0; i < W; i++) {
+            st[i] = g.col(L.post(r) + i);
+            g.assert_zero(g.sub(st[i], x7[i]));
+        }
+    };
+    std::vector<uint32_t> st(W);
+    for (uint32_t i = 0; i < W; i++) st[i] = g.col(L.in() + i);
+    m_ext(st);
+    for (uint32_t r = 0; r < 4; r++) ext_round(st, r);
+    for (uint32_t kk = 0; kk < L.RP; kk++) {
+        uint32_t s0 = st[0];
+        if (kk > 0) {
+            s0 = g.col(L.s0(kk));
+            g.assert_zero(g.sub(s0, st[0]));
+        }
+        const uint32_t t = g.add(s0, g.cst(bb::decode(k.rc_int()[kk]))), x3 = g.col(L.x3i(kk));
+        g.assert_zero(g.sub(x3, g.mul(g.mul(t, t), t)));
+        st[0] = g.mul(g.mul(x3, x3), t);
+        uint32_t sum = st[0];
+        for (uint32_t i = 1; i < W; i++) sum = g.add(sum, st[i]);
+        for (uint32_t i = 0; i < W; i++) st[i] = g.add(sum, g.mul(st[i], g.cst(bb::decode(k.diag()[i]))));
+    }
+    for (uint32_t i = 0; i < W; i++) {
+        const uint32_t c = g.col(L.int_out() + i);
+        g.assert_zero(g.sub(c, st[i]));
+        st[i] = c;
+    }
+    for (uint32_t r = 4; r < 8; r++) ext_round(st, r);
+}
+
+// the chip's rows on the GPU: one lane per permutation; tab = rc_ext | rc_int | diag (Montgomery words)
+template <int W, int RP, int M4>
+__device__ void p2_dev_m_ext(uint32_t (&c)[W]) {
+    uint32_t sums[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < W; i += 4) {
+        const uint32_t a = c[i], b = c[i + 1], d = c[i + 2], e = c[i + 3];
+        if (M4 == 0) {
+            const uint32_t t0 = bb::add(a, b), t1 = bb::add(d, e), t2 = bb::add(bb::dbl(b), t1), t3 = bb::add(bb::dbl(e), t0);
+            const uint32_t t4 = bb::add(bb::dbl(bb::dbl(t1)), t3), t5 = bb::add(bb::dbl(bb::dbl(t0)), t2);
+            c[i] = bb::add(t3, t5), c[i + 1] = t5, c[i + 2] = bb::add(t2, t4), c[i + 3] = t4;
+        } else {
+            const uint32_t s = bb::add(bb::add(a, b), bb::add(d, e));
+            c[i] = bb::add(bb::add(s, a), bb::dbl(b));
+            c[i + 1] = bb::add(bb::add(s, b), bb::dbl(d));
+            c[i + 2] = bb::add(bb::add(s, d), bb::dbl(e));
+            c[i + 3] = bb::add(bb::add(s, e), bb::dbl(a));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) sums[j] = bb::add(sums[j], c[i + j]);
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) c[i] = bb::add(c[i], sums[i & 3]);
+}
+template <int W, int RP, int M4>
+__global__ void __launch_bounds__(128) p2_chip_trace_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, const uint32_t* __restrict__ mult,
+                                                            const uint32_t* __restrict__ tab, size_t n, P2ChipLayout L) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t* row = out + r * L.width;
+    const uint32_t *rc_ext = tab, *rc_int = tab + 8 * W, *diag = rc_int + RP;
+    uint32_t c[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) row[i] = c[i] = in[r * W + i];
+    p2_dev_m_ext<W, RP, M4>(c);
+    auto ext_round = [&](int rd) {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const uint32_t s = bb::add(c[i], rc_ext[rd * W + i]), x3 = bb::mul(bb::sqr(s), s);
+            row[L.x3(rd) + i] = x3;
+            c[i] = bb::mul(bb::sqr(x3), s);
+        }
+        p2_dev_m_ext<W, RP, M4>(c);
+#pragma unroll
+        for (int i = 0; i < W; i++) row[L.post(rd) + i] = c[i];
+    };
+    for (int rd = 0; rd < 4; rd++) ext_round(rd);
+    for (int k = 0; k < RP; k++) {
+        if (k > 0) row[L.s0(k)] = c[0];
+        const uint32_t t = bb::add(c[0], rc_int[k]), x3 = bb::mul(bb::sqr(t), t);
+        row[L.x3i(k)] = x3;
+        c[0] = bb::mul(bb::sqr(x3), t);
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < W; i++) sum = bb::add(sum, c[i]);
+#pragma unroll
+        for (int i = 0; i < W; i++) c[i] = bb::add(sum, bb::mul(c[i], diag[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) row[L.int_out() + i] = c[i];
+    for (int rd = 4; rd < 8; rd++) ext_round(rd);
+    row[L.mult()] = mult ? mult[r] : bb::ONE;
+}
 
 // folder.rs on extension elements (the verifier's side): accumulator = accumulator * alpha + x per assert, in order
 struct PermView {   // the verifier's view of a table's lookup argument (all null without one)
@@ -1467,6 +1624,57 @@ int rk_air_create_lookup(const rk_air_step* steps_in, size_t n_steps_in, uint32_
     air->info.n_fp_slots = pi.n_fp_slots;
     *out = air.release();
     return RK_OK;
+    RK_GUARD_END
+}
+uint32_t rk_p2_chip_width(const rk_params* params) {
+    rk_params def;
+    rk::params_preset(&def, RK_PRESET_SP1);
+    rk::Sys sys;
+    auto k = std::make_unique<p2::Any>();
+    if (rk::resolve_params(params ? params : &def, &sys, k.get()) != RK_OK) return 0;
+    return p2_chip_layout(*k).width;
+}
+int rk_p2_chip_air(const rk_params* params, uint32_t bus, rk_air** out) {
+    RK_GUARD_BEGIN
+    if (!out) return RK_ERR_INVALID;
+    *out = nullptr;
+    rk_params def;
+    rk::params_preset(&def, RK_PRESET_SP1);
+    const rk_params& par = params ? *params : def;
+    rk::Sys sys;
+    auto k = std::make_unique<p2::Any>();
+    RK_TRY(rk::resolve_params(&par, &sys, k.get()));
+    if (bus >= bb::P) return RK_ERR_INVALID;
+    const P2ChipLayout L = p2_chip_layout(*k);
+    std::vector<rk_air_step> steps;
+    p2_chip_steps(*k, steps);
+    // receives (bus: in[0..W), out[0..8)) `multiplicity` times per row
+    std::vector<uint32_t> ix = {1, bus, 0, L.mult(), L.W + (uint32_t)p2::OUT};
+    for (uint32_t i = 0; i < L.W; i++) ix.push_back(L.in() + i);
+    for (uint32_t i = 0; i < (uint32_t)p2::OUT; i++) ix.push_back(L.out() + i);
+    return rk_air_create_lookup(steps.data(), steps.size(), L.width, 0, ix.data(), 1, ix.size(), par.ext_w, out);
+    RK_GUARD_END
+}
+int rk_p2_chip_trace(rk_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_mult, size_t n, uint32_t* d_trace) {
+    RK_GUARD_BEGIN
+    if (!ctx || !d_inputs || !d_trace || n == 0 || n > ((size_t)1 << 24)) return RK_ERR_INVALID;
+    RK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const p2::Any& k = ctx->h_p2;
+    const P2ChipLayout L = p2_chip_layout(k);
+    std::vector<uint32_t> tab(k.rc_ext(), k.rc_ext() + 8 * L.W);
+    tab.insert(tab.end(), k.rc_int(), k.rc_int() + L.RP);
+    tab.insert(tab.end(), k.diag(), k.diag() + L.W);
+    DevBuf d_tab;
+    RK_TRY(d_tab.alloc(ctx, tab.size() * 4));
+    RK_TRY(rk::upload(ctx, d_tab.p, tab.data(), tab.size() * 4));
+    const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    switch (k.kind) {
+        case 0: hipLaunchKernelGGL((p2_chip_trace_kernel<24, 21, 0>), grid, block, 0, ctx->stream, d_trace, d_inputs, d_mult, (const uint32_t*)d_tab.u32(), n, L); break;
+        case 1: hipLaunchKernelGGL((p2_chip_trace_kernel<24, 21, 1>), grid, block, 0, ctx->stream, d_trace, d_inputs, d_mult, (const uint32_t*)d_tab.u32(), n, L); break;
+        case 2: hipLaunchKernelGGL((p2_chip_trace_kernel<16, 13, 0>), grid, block, 0, ctx->stream, d_trace, d_inputs, d_mult, (const uint32_t*)d_tab.u32(), n, L); break;
+        default: hipLaunchKernelGGL((p2_chip_trace_kernel<16, 13, 1>), grid, block, 0, ctx->stream, d_trace, d_inputs, d_mult, (const uint32_t*)d_tab.u32(), n, L); break;
+    }
+    return rk::post_launch(ctx, "p2_chip_trace_kernel");
     RK_GUARD_END
 }
 int rk_air_get_steps(const rk_air* air, rk_air_step* out, size_t capacity, size_t* n_steps) {

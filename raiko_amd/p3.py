@@ -496,6 +496,88 @@ def last_timing(hal) -> dict:
     return {n: float(getattr(t, n)) for n, _ in t._fields_}
 
 
+# ---------------------------------------------------------------------------------------------- the Poseidon2 chip
+BUS_POSEIDON2 = 4
+
+
+def poseidon2_chip_air(params=None, bus=BUS_POSEIDON2):
+    """rk_p2_chip_air: one row = one Poseidon2 permutation of the parameter set's instance (params None = the SP1 preset),
+    receiving (bus: in[0..W), out[0..8)) multiplicity times -- the table a recursion / compress layer looks its hashing up in.
+    The step list is written by the library; .steps is read back (rk_air_get_steps) so that a checker can evaluate it too."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(None, lib.rk_p2_chip_air(C.byref(params) if params is not None else None, bus, C.byref(h)))
+    n = C.c_size_t(0)
+    lib.rk_air_get_steps(h, None, 0, C.byref(n))
+    steps = np.zeros((n.value, 3), dtype=np.uint32)
+    _lib.check(None, lib.rk_air_get_steps(h, steps.ctypes.data, n.value, C.byref(n)))
+    width = int(lib.rk_p2_chip_width(C.byref(params) if params is not None else None))
+    w_state = 16 if width == 314 else 24
+    out0 = width - 1 - w_state                      # the last external round's state: the permutation's output
+    air = Air(steps, width, 0, [Interaction(RECEIVE, bus, list(range(w_state)) + list(range(out0, out0 + 8)), width - 1)])
+    air._handle = h
+    air.state_width, air.out_col = w_state, out0
+    return air
+
+
+def poseidon2_chip_trace(hal, inputs_mont, mult_mont=None):
+    """rk_p2_chip_trace: the chip's rows for `inputs` (n, W) Montgomery words under hal's parameter set -> device buffer
+    (n x width row-major), ready as an on_device table"""
+    lib = _lib.load()
+    par = _lib.RkParams()
+    _lib.check(hal._ctx, lib.rk_get_params(hal._ctx, C.byref(par)))
+    width = int(lib.rk_p2_chip_width(C.byref(par)))
+    inp = np.ascontiguousarray(inputs_mont, dtype=np.uint32)
+    n = inp.shape[0]
+    d_in = hal.copy_from_elem(inp.reshape(-1))
+    d_mult = hal.copy_from_elem(np.ascontiguousarray(mult_mont, dtype=np.uint32)) if mult_mont is not None else None
+    d_out = hal.alloc_elem(n * width)
+    from .hal import _ptr
+    _lib.check(hal._ctx, lib.rk_p2_chip_trace(hal._ctx, _ptr(d_in), _ptr(d_mult) if d_mult is not None else None, n, _ptr(d_out)))
+    return d_out, width
+
+
+def merkle_path_air(ext_w=EXT_W, bus=BUS_POSEIDON2):
+    """The other side of the Poseidon2 chip in a recursion / compress layer: verifying Merkle paths (what the FRI verifier
+    spends its hashing on).  One row = one step of a path: the node `cur` and its sibling `sib` are ordered by `bit`
+    (1: cur is the right child) into left / right, parent = compress(left, right) is LOOKED UP in the Poseidon2 chip
+    (width-16 instance: the two digests fill the state); the next row of the same path starts at this row's parent; a
+    path's last step ends in the public root.  Columns: cur 8 | sib 8 | bit | left 8 | right 8 | parent 8 | is_real |
+    is_last (43); public values: the root (8)."""
+    CUR, SIB, BIT, LEFT, RIGHT, PARENT, REAL, LAST = 0, 8, 16, 17, 25, 33, 41, 42
+    b = AirBuilder(43, 8, ext_w)
+    bit, real, last = b.local(BIT), b.local(REAL), b.local(LAST)
+    for v in (bit, real, last):
+        b.assert_zero(v * (v - 1))
+    b.assert_zero(last * (1 - real))                       # only a real step ends a path
+    for i in range(8):
+        cur, sib = b.local(CUR + i), b.local(SIB + i)
+        b.assert_eq(b.local(LEFT + i), cur + bit * (sib - cur))
+        b.assert_eq(b.local(RIGHT + i), sib + bit * (cur - sib))
+        b.when_transition().assert_zero(real * (1 - last) * (b.next(CUR + i) - b.local(PARENT + i)))
+        b.assert_zero(last * (b.local(PARENT + i) - b.public(i)))
+    b.when_last_row().assert_zero(real * (1 - last))       # no path is cut off by the end of the table
+    b.send(bus, list(range(LEFT, LEFT + 8)) + list(range(RIGHT, RIGHT + 8)) + list(range(PARENT, PARENT + 8)), mult=REAL, mult_is_const=False)
+    return b.build()
+
+
+def merkle_path_rows(leaves_at, levels):
+    """rows of merkle_path_air for the paths from the leaves `leaves_at` (indices) up a tree given as `levels`
+    (levels[0] = the leaf digests (n, 8), levels[-1] = (1, 8) the root; canonical) -> (rows (m, 43), compress inputs (m, 16))"""
+    rows, ins = [], []
+    depth = len(levels) - 1
+    for leaf in leaves_at:
+        idx = int(leaf)
+        for lv in range(depth):
+            cur, sib, bit = levels[lv][idx], levels[lv][idx ^ 1], idx & 1
+            left, right = (sib, cur) if bit else (cur, sib)
+            parent = levels[lv + 1][idx >> 1]
+            rows.append(np.concatenate([cur, sib, [bit], left, right, parent, [1], [1 if lv == depth - 1 else 0]]))
+            ins.append(np.concatenate([left, right]))
+            idx >>= 1
+    return np.array(rows, dtype=np.uint64), np.array(ins, dtype=np.uint64)
+
+
 # ---------------------------------------------------------------------------------------------- example AIRs
 def fibonacci_air():
     """Plonky3's uni-stark test AIR (fib_air.rs, RECALLED): columns (left, right), public values (a, b, x):

@@ -31,6 +31,10 @@ P3_CASES = {
     "risc0_lookup_k7_blow2": (0, dict(queries=4, pow_bits=2, blowup_log2=2), [("lookup", 7, 5)], [3]),
     "sp1_selfperm_k5": (1, dict(queries=5, pow_bits=2), [("selfperm", 5, 10), ("fib", 3, None)], [4]),
     # two tuples of 60 values: 120 distinct columns staged per row (the limit), 248 challenge words, 9 rows more than a workgroup takes
+    "sp1_lookup_two_rows": (1, dict(queries=3, pow_bits=1), [("lookup", 1, 1)], [5]),      # the smallest tables there are
+    # a piece of a recursion / compress layer: Merkle paths (depth 6, 9 of them) verified by a path table that looks every
+    # compression up in the Poseidon2 chip (rk_p2_chip_air: one permutation per row, 314 columns); beside a plain table
+    "sp1_merkle_paths_poseidon2_chip": (1, dict(queries=4, pow_bits=2), [("merkle", 6, 9), ("fib", 5, None)], [2]),
     "sp1_wide_tuples_k9": (1, dict(queries=3, pow_bits=1), [("widetuple", 9, 130)], []),
 }
 
@@ -62,8 +66,34 @@ def widetuple_air(width, ext_w):
     return b.build()
 
 
+def merkle_tables(depth, n_paths, preset, seed):
+    """[path table, Poseidon2 chip table] for n_paths random leaves of a random tree of 2^depth leaves (numpy restatement
+    of the chip rows: tests/p2_chip_ref.py; the oracle must be on the case's parameter set)"""
+    import p2_chip_ref as R
+    from raiko_amd import hal
+    assert preset == 1
+    tabs = R.tables_of()
+    chip = air_of("p2chip", None, preset)
+    out0 = chip.out_col
+    rng = np.random.default_rng(seed)
+    levels = [rng.integers(0, p3.P, size=(1 << depth, 8)).astype(np.uint64)]
+    for _ in range(depth):
+        cur = levels[-1]
+        levels.append(R.chip_trace(np.concatenate([cur[0::2], cur[1::2]], axis=1), tabs)[:, out0:out0 + 8])
+    rows, ins = p3.merkle_path_rows(rng.integers(0, 1 << depth, size=n_paths), levels)
+
+    def pad(a, w):
+        t = np.zeros((max(2, 1 << int(len(a) - 1).bit_length()), w), dtype=np.uint64)
+        t[: len(a)] = a
+        return t
+
+    uniq, cnt = np.unique(ins, axis=0, return_counts=True)
+    return [p3.Table.from_canonical(air_of("merklepath", None, preset), pad(rows, 43), levels[-1][0]),
+            p3.Table.from_canonical(chip, R.chip_trace(pad(uniq, 16), tabs, pad(cnt[:, None], 1)[:, 0]))]
+
+
 def air_of(name, arg, preset=1):
-    key = (name, arg, preset if name in ("lookup", "selfperm", "widetuple") else None)
+    key = (name, arg, preset if name in ("lookup", "selfperm", "widetuple", "p2chip", "merklepath") else None)
     if key not in _AIRS:
         if name == "empty":      # `width` columns, nothing asserted: a valid AIR whose quotient is zero
             b = p3.AirBuilder(arg)
@@ -75,6 +105,11 @@ def air_of(name, arg, preset=1):
             _AIRS[key] = selfperm_air(arg, EXT_W[preset])
         elif name == "widetuple":
             _AIRS[key] = widetuple_air(arg, EXT_W[preset])
+        elif name == "p2chip":
+            from raiko_amd import hal
+            _AIRS[key] = p3.poseidon2_chip_air(hal.make_params(preset))
+        elif name == "merklepath":
+            _AIRS[key] = p3.merkle_path_air(EXT_W[preset])
         else:
             _AIRS[key] = p3.fibonacci_air() if name == "fib" else p3.cubic_air(arg) if name == "cubic" else p3.wide_air(arg)
     return _AIRS[key]
@@ -84,6 +119,9 @@ def tables_of(case):
     preset, _, specs, _ = P3_CASES[case]
     out = []
     for i, (name, k, arg) in enumerate(specs):
+        if name == "merkle":
+            out += merkle_tables(k, arg, preset, seed=50 + i)
+            continue
         air = air_of(name, arg, preset)
         if name == "lookup":
             out += p3.lookup_demo_tables(k, arg, seed=40 + i, airs=air)

@@ -1,0 +1,154 @@
+"""The Poseidon2 chip (rk_p2_chip_air / rk_p2_chip_trace, include/raiko_hip.h) and a Merkle-path table that looks its
+compressions up in it: a piece of the recursion / compress layer BASELINE config 5 names (the layer itself -- SP1's
+recursion VM -- is outside the reference tree: provers/sp1/driver/src/lib.rs:44-57 reaches it through sp1-sdk).
+CPU side: the library-written AIR accepts exactly the rows of a numpy restatement (tests/p2_chip_ref.py) whose outputs
+equal the oracle's permutation (oracle/or_ops.c), for both Poseidon2 instances; the oracle proves path table + chip
+and both verifiers accept; forged steps are refused."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+import p2_chip_ref as R
+from p3_cases import air_of, merkle_tables
+from raiko_amd import hal, p3
+
+P = o.P
+
+
+@pytest.fixture()
+def params():
+    yield o.oracle_set_params
+    o.oracle_set_params()
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_chip_air_accepts_the_permutation_and_nothing_else(params, preset):
+    params(preset)
+    tabs = R.tables_of()
+    w = tabs[2].size
+    air = p3.poseidon2_chip_air(hal.make_params(preset))
+    assert air.width == (314 if w == 16 else 474) == w + 16 * w + 2 * len(tabs[1]) - 1 + w + 1
+    info = air.info()
+    assert info["max_degree"] == 3 and info["log_quotient_degree"] == 1 and air.perm_width == 8
+    rng = np.random.default_rng(preset)
+    x = rng.integers(0, P, size=(6, w)).astype(np.uint64)
+    x[0] = 0
+    x[1] = P - 1
+    rows = R.chip_trace(x, tabs)
+    lib = o.oracle()
+    for i in range(x.shape[0]):                       # the restatement's outputs are the oracle's permutation
+        st = o.to_mont(x[i]).astype(np.uint32).copy()
+        lib.or_poseidon2_mix(st.ctypes.data)
+        assert np.array_equal(o.from_mont(st)[:8], rows[i, air.out_col: air.out_col + 8].astype(np.uint32))
+    assert air.check_trace(rows) == []
+    n_main = info["n_constraints"] - 16               # without the lookup argument's own asserts (one batch 4, first / transition / last 3 x 4)
+    hit = set()
+    for col in range(air.width - 1):                  # every committed cell is pinned by some constraint
+        bad = rows.copy()
+        bad[2, col] = (int(bad[2, col]) + 1) % P
+        v = air.check_trace(bad)
+        assert v and all(r == 2 and k < n_main for r, k in v), col
+        hit |= {k for _, k in v}
+    assert len(hit) == n_main
+
+
+def test_merkle_paths_through_the_chip(params):
+    over = dict(queries=4, pow_bits=2)
+    params(1, **over)
+    blob = hal.make_params(1, **over)
+    path, chip = merkle_tables(5, 6, 1, seed=3)
+    rows = o.from_mont(path.trace).astype(np.uint64)
+    root = o.from_mont(path.public_values)
+    assert path.air.check_trace(rows, root) == [] and path.air.log_quotient_degree() == 1
+    assert int(rows[:, 41].sum()) == 30 == int(o.from_mont(chip.trace)[:, -1].astype(np.int64).sum())   # 6 paths x 5 steps, every one looked up
+    init = p3.to_mont([9])
+    pf = o.oracle_p3_prove([path, chip], init)
+    assert o.oracle_p3_verify([path, chip], pf, init) == 0 == p3.verify([path, chip], pf, init, params=blob)
+
+    def verdict(tabs):
+        q = o.oracle_p3_prove(tabs, init)
+        a, b = o.oracle_p3_verify(tabs, q, init), p3.verify(tabs, q, init, params=blob)
+        assert a == b
+        return a
+
+    def with_path(r, pub=None):
+        return [p3.Table.from_canonical(path.air, r, root if pub is None else pub), chip]
+
+    forged = rows.copy()                              # a step that claims another parent: no such row in the chip
+    forged[3, 33] = (int(forged[3, 33]) + 1) % P
+    if forged[3, 42] == 0:
+        forged[4, 0] = forged[3, 33]                  # keep the chain consistent: only the lookup is wrong
+    assert verdict(with_path(forged)) == 8
+    other = root.astype(np.uint64).copy()
+    other[0] = (int(other[0]) + 1) % P
+    assert verdict(with_path(rows, other)) == 3       # the paths end in another root than the public one
+    cut = rows.copy()
+    cut[2, 42] = 1                                    # "this path ends here": its parent is not the root
+    assert verdict(with_path(cut)) == 3
+    swapped = rows.copy()                             # left / right not ordered by the bit
+    swapped[1, 16] ^= 1
+    assert verdict(with_path(swapped)) == 3
+    lazy = o.from_mont(chip.trace).astype(np.uint64)  # a chip row whose output was not computed by the permutation
+    lazy[0, chip.air.out_col] = (int(lazy[0, chip.air.out_col]) + 1) % P
+    assert verdict([path, p3.Table.from_canonical(chip.air, lazy)]) in (3, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", [0, 1])
+def test_gpu_chip_rows_equal_the_restatement(preset):
+    h = hal.HipHal(0)
+    try:
+        h.set_params(preset)
+        o.oracle_set_params(preset)
+        tabs = R.tables_of()
+        w = tabs[2].size
+        rng = np.random.default_rng(7 + preset)
+        for n in (1, 130, 4099):
+            x = rng.integers(0, P, size=(n, w)).astype(np.uint64)
+            mult = rng.integers(0, 9, size=n).astype(np.uint64)
+            d_rows, width = p3.poseidon2_chip_trace(h, o.to_mont(x), o.to_mont(mult))
+            got = o.from_mont(d_rows.to_host().reshape(n, width))
+            assert np.array_equal(got, R.chip_trace(x, tabs, mult).astype(np.uint32))
+            d_rows, _ = p3.poseidon2_chip_trace(h, o.to_mont(x))                      # no multiplicities: ones
+            assert np.array_equal(o.from_mont(d_rows.to_host().reshape(n, width))[:, -1], np.ones(n, dtype=np.uint32))
+    finally:
+        o.oracle_set_params()
+        h.close()
+
+
+@pytest.mark.gpu
+def test_gpu_proves_device_generated_chip_rows():
+    """2^13 permutations: rows written by rk_p2_chip_trace stay in HBM and go to rk_p3_prove as an on_device table (interpreter
+    and generated quotient kernel); the proof equals the oracle's over the restatement's rows and verifies"""
+    over = dict(queries=6, pow_bits=3)
+    h = hal.HipHal(0)
+    try:
+        blob = h.set_params(1, **over)
+        o.oracle_set_params(1, **over)
+        tabs = R.tables_of()
+        n = 1 << 13
+        rng = np.random.default_rng(11)
+        x = rng.integers(0, P, size=(n, 16)).astype(np.uint64)
+        x[n // 2:] = x[: n // 2]                                  # every input twice: a user table sends each (in, out) pair twice
+        chip = p3.poseidon2_chip_air(blob)
+        mult = np.zeros(n, dtype=np.uint64)
+        mult[: n // 2] = 2
+        d_rows, width = p3.poseidon2_chip_trace(h, o.to_mont(x), o.to_mont(mult))
+        ref = R.chip_trace(x, tabs, mult)
+        user = p3.AirBuilder(24, 0)
+        user.send(p3.BUS_POSEIDON2, list(range(24)))
+        user_air = user.build(library_constraints=True)
+        user_rows = np.concatenate([ref[:, :16], ref[:, chip.out_col: chip.out_col + 8]], axis=1)
+        tables = [p3.Table(chip, None, []), p3.Table.from_canonical(user_air, user_rows)]
+        tables[0].log_height = 13
+        from raiko_amd.hal import _ptr
+        dev = [(_ptr(d_rows), 13), None]
+        got = p3.prove(h, tables, device_traces=dev)
+        host_tables = [p3.Table.from_canonical(chip, ref), tables[1]]
+        assert np.array_equal(got, o.oracle_p3_prove(host_tables))
+        assert p3.verify(host_tables, got, params=blob) == 0
+        chip.compile(h)
+        assert np.array_equal(p3.prove(h, tables, device_traces=dev), got)
+    finally:
+        o.oracle_set_params()
+        h.close()
