@@ -21,7 +21,7 @@ wait
 RT=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so' | head -1)
 cd "$ROOT"
 fail=0
-for t in test_p3 test_verifier_fuzz test_verify test_mmcs test_program test_executor test_params test_abi test_prover_api test_pcs; do
+for t in test_p3 test_p2_chip test_verifier_fuzz test_verify test_mmcs test_program test_executor test_params test_abi test_prover_api test_pcs; do
   RAIKO_HIP_LIB="$B/libraiko_hip_asan.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 \
     python -m pytest tests/$t.py -x -q -m "not gpu" -p no:cacheprovider > "$B/$t.log" 2>&1 || fail=1
   n=$(grep -c 'runtime error\|ERROR: AddressSanitizer' "$B/$t.log" || true)
