@@ -676,6 +676,14 @@ int rk_p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const
  * 5 input opening, 6 commit-phase opening, 7 final polynomial, 8 the cumulative sums of the lookups do not cancel. */
 int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
                  const uint32_t* proof, size_t proof_words);
+/* rk_p3_verify that also hands back EVERY Poseidon2 permutation the check performed -- the transcript's, the leaf sponges
+ * over the opened rows, the Merkle compressions, the proof of work's -- as input states (p2_width Montgomery words each,
+ * in the order they happened): what the Poseidon2 chip of a recursion / compress layer has to prove for this proof
+ * (rk_p2_chip_trace turns them into that chip's rows).  Returns the verifier's verdict (0 accepted, 1..8 the reason a
+ * sequential check gives; the log then ends where the check stopped) or a negative status; RK_ERR_CAPACITY with
+ * *n_permutations set when `states` holds fewer than that many: call again. */
+int rk_p3_verify_hashes(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
+                        const uint32_t* proof, size_t proof_words, uint32_t* states, size_t capacity_permutations, size_t* n_permutations);
 /* exact proof size for the tables' shapes (log_height, width, air); 0 for shapes rk_p3_prove rejects */
 size_t rk_p3_proof_bound_words(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables);
 /* Many independent proofs -- the shards of one SP1 execution -- with `batch` of them in flight per GPU: what SP1's

@@ -455,6 +455,7 @@ extern "C" {
     pub fn rk_p2_chip_trace(ctx: *mut rk_ctx, d_inputs: *const u32, d_mult: *const u32, n: usize, d_trace: *mut u32) -> c_int;
     pub fn rk_p3_prove(ctx: *mut rk_ctx, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, h_proof: *mut u32, capacity_words: usize, proof_words: *mut usize) -> c_int;
     pub fn rk_p3_verify(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, proof: *const u32, proof_words: usize) -> c_int;
+    pub fn rk_p3_verify_hashes(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32, init_words: *const u32, n_init: usize, proof: *const u32, proof_words: usize, states: *mut u32, capacity_permutations: usize, n_permutations: *mut usize) -> c_int;
     pub fn rk_p3_proof_bound_words(params: *const rk_params, tables: *const rk_p3_table, n_tables: u32) -> usize;
     pub fn rk_p3_prove_shards(opts: *const rk_p3_session_opts, shards: *mut rk_p3_shard, n: usize, failed_index: *mut usize) -> c_int;
     pub fn rk_p3_last_timing(ctx: *mut rk_ctx, out: *mut rk_p3_timing) -> c_int;

@@ -262,6 +262,7 @@ SYMBOLS = {
     "rk_p3_prove": (C.c_int, [_vp, C.POINTER(RkP3Table), _u32, u32p, _sz, u32p, _sz, C.POINTER(_sz)]),
     "rk_p3_verify": (C.c_int, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32, u32p, _sz, u32p, _sz]),
     "rk_p3_proof_bound_words": (_sz, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32]),
+    "rk_p3_verify_hashes": (C.c_int, [C.POINTER(RkParams), C.POINTER(RkP3Table), _u32, u32p, _sz, u32p, _sz, u32p, _sz, C.POINTER(_sz)]),
     "rk_p3_last_timing": (C.c_int, [_vp, C.POINTER(RkP3Timing)]),
     "rk_p3_prove_shards": (C.c_int, [C.POINTER(RkP3SessionOpts), C.POINTER(RkP3Shard), _sz, C.POINTER(_sz)]),
     "rk_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -1067,7 +1067,7 @@ Ext load_ext(const uint32_t* p) { return Ext{{p[0], p[1], p[2], p[3]}}; }
 // (OodEvaluationMismatch), 4 proof of work, 5 input opening, 6 commit-phase opening, 7 final polynomial, 8 the
 // lookups' cumulative sums do not cancel
 int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init, size_t n_init,
-              const uint32_t* proof, size_t words) {
+              const uint32_t* proof, size_t words, bool one_thread = false) {
     rk_params def;
     rk::params_preset(&def, RK_PRESET_SP1);
     const rk_params& par = params ? *params : def;
@@ -1295,7 +1295,7 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     std::vector<uint32_t> indices(sys.queries);
     for (uint32_t qi = 0; qi < sys.queries; qi++) indices[qi] = ch.sample_bits(log_max);
     const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_thr = sys.queries >= 16 ? std::max(1u, std::min(4u, hw / 2)) : 1u;
+    const unsigned n_thr = sys.queries >= 16 && !one_thread ? std::max(1u, std::min(4u, hw / 2)) : 1u;
     std::vector<int> first_bad(n_thr, 0);
     std::vector<uint32_t> first_at(n_thr, 0xffffffffu);
     auto run = [&](unsigned t) {
@@ -1733,6 +1733,31 @@ int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_
                  const uint32_t* proof, size_t proof_words) {
     RK_GUARD_BEGIN
     return p3_verify(params, tables, n_tables, init_words, n_init, proof, proof_words);
+    RK_GUARD_END
+}
+
+int rk_p3_verify_hashes(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
+                        const uint32_t* proof, size_t proof_words, uint32_t* states, size_t capacity, size_t* n_permutations) {
+    RK_GUARD_BEGIN
+    if (!n_permutations || (capacity && !states)) return RK_ERR_INVALID;
+    rk_params def;
+    rk::params_preset(&def, RK_PRESET_SP1);
+    const size_t w = (params ? params : &def)->p2_width;
+    std::vector<uint32_t> log;
+    struct Scope {   // the log is this thread's for the duration of the check, also when the verifier throws
+        explicit Scope(std::vector<uint32_t>* l) { p2::g_permute_log = l; }
+        ~Scope() { p2::g_permute_log = nullptr; }
+    };
+    int verdict;
+    {
+        Scope scope(&log);
+        verdict = p3_verify(params, tables, n_tables, init_words, n_init, proof, proof_words, /*one_thread=*/true);
+    }
+    if (verdict < 0 || (w != 16 && w != 24)) return verdict < 0 ? verdict : RK_ERR_INVALID;
+    *n_permutations = log.size() / w;
+    if (*n_permutations > capacity) return RK_ERR_CAPACITY;
+    std::memcpy(states, log.data(), log.size() * 4);
+    return verdict;
     RK_GUARD_END
 }
 

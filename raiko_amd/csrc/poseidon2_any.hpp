@@ -5,6 +5,7 @@
 // kernels are instantiated per Core type in kernels_hash.hip and pick theirs from `kind`.
 #pragma once
 #include <cstring>
+#include <vector>
 
 #include "poseidon2_core.hpp"
 
@@ -15,6 +16,10 @@ using K1 = Core<24, 21, 1>;
 using K2 = Core<16, 13, 0>;
 using K3 = Core<16, 13, 1>;  // SP1 / Plonky3 shape
 constexpr int MAX_CELLS = 24;
+
+// rk_p3_verify_hashes: while set on the calling thread, every host permutation appends its input state here (what a
+// recursion layer's Poseidon2 chip has to prove for the proof being checked).  Host only.
+inline thread_local std::vector<uint32_t>* g_permute_log = nullptr;
 
 struct Any {
     int kind = 0;
@@ -54,6 +59,7 @@ struct Any {
         }
     }
     void permute(uint32_t* s) const {
+        if (g_permute_log) g_permute_log->insert(g_permute_log->end(), s, s + cells());
         switch (kind) {
             case 0: K0::permute(s, k0); break;
             case 1: K1::permute(s, k1); break;

@@ -490,6 +490,31 @@ def verify(tables, proof, init=(), params=None) -> int:
     return rc
 
 
+def verify_hashes(tables, proof, init=(), params=None):
+    """rk_p3_verify_hashes -> (verdict, (n, p2_width) uint32 array: the input state of every Poseidon2 permutation the
+    check performed, in order)"""
+    lib = _lib.load()
+    arr, keep = _c_tables(tables)
+    iw = np.ascontiguousarray(init, dtype=np.uint32)
+    pf = np.ascontiguousarray(proof, dtype=np.uint32)
+    w = int(params.p2_width) if params is not None else 16
+    n = C.c_size_t(0)
+    par = C.byref(params) if params is not None else None
+    rc = lib.rk_p3_verify_hashes(par, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size, pf.ctypes.data_as(_lib.u32p), pf.size,
+                                 None, 0, C.byref(n))
+    if rc != _lib.RK_ERR_CAPACITY:
+        if rc < 0:
+            _lib.check(None, rc)
+        return rc, np.zeros((0, w), dtype=np.uint32)
+    states = np.zeros((n.value, w), dtype=np.uint32)
+    rc = lib.rk_p3_verify_hashes(par, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size, pf.ctypes.data_as(_lib.u32p), pf.size,
+                                 states.ctypes.data_as(_lib.u32p), n.value, C.byref(n))
+    if rc < 0:
+        _lib.check(None, rc)
+    del keep
+    return rc, states[: n.value]
+
+
 def last_timing(hal) -> dict:
     t = _lib.RkP3Timing()
     _lib.check(hal._ctx, _lib.load().rk_p3_last_timing(hal._ctx, C.byref(t)))

@@ -93,6 +93,99 @@ def test_merkle_paths_through_the_chip(params):
     assert verdict([path, p3.Table.from_canonical(chip.air, lazy)]) in (3, 8)
 
 
+def claims_air():
+    """(in 16 | out 8 | is_real): every real row sends its (input, output) pair to the Poseidon2 chip"""
+    b = p3.AirBuilder(25, 0)
+    b.assert_zero(b.local(24) * (b.local(24) - 1))
+    b.send(p3.BUS_POSEIDON2, list(range(24)), mult=24, mult_is_const=False)
+    return b.build(library_constraints=True)
+
+
+def hash_statement_tables(states, chip, tabs):
+    """[chip table, claims table] for the permutations `states` (n, 16) Montgomery words: distinct inputs with their
+    multiplicities in the chip, one claim (input, output) per permutation"""
+    canon = o.from_mont(states).astype(np.uint64)
+    uniq, inverse, counts = np.unique(canon, axis=0, return_inverse=True, return_counts=True)
+
+    def pad(a, w):
+        t = np.zeros((max(2, 1 << int(len(a) - 1).bit_length()), w), dtype=np.uint64)
+        t[: len(a)] = a
+        return t
+
+    rows = R.chip_trace(pad(uniq, 16), tabs, pad(counts[:, None], 1)[:, 0])
+    out = rows[: len(uniq), chip.out_col: chip.out_col + 8][inverse.reshape(-1)]
+    claims = pad(np.concatenate([canon, out, np.ones((len(canon), 1), dtype=np.uint64)], axis=1), 25)
+    return [p3.Table.from_canonical(chip, rows), p3.Table.from_canonical(claims_air(), claims)]
+
+
+def test_the_hashing_of_a_verification_as_a_chip_table(params):
+    """rk_p3_verify_hashes: the verdict of rk_p3_verify plus every permutation the check performed; those permutations,
+    proven through the Poseidon2 chip (the hash part of a compress step over the proof), verify -- the whole loop on the
+    CPU through the oracle"""
+    from p3_cases import P3_CASES, init_of, tables_of
+    case = "sp1_mixed_fib8_cubic4"
+    preset, over, _, _ = P3_CASES[case]
+    params(preset, **over)
+    blob = hal.make_params(preset, **over)
+    tables, init = tables_of(case), init_of(case)
+    pf = o.oracle_p3_prove(tables, init)
+    rc, states = p3.verify_hashes(tables, pf, init, params=blob)
+    assert rc == 0 and states.shape[1] == 16 and int(states.max()) < P
+    # 10 queries x (two input batches + 8 FRI rounds): leaf sponges + paths, and the transcript's permutations on top
+    log_max = 8 + blob.blowup_log2
+    paths = blob.queries * (2 * log_max + sum(log_max - 1 - r for r in range(8)))
+    assert states.shape[0] > paths + blob.queries * (2 + 8)
+    again = p3.verify_hashes(tables, pf, init, params=blob)
+    assert again[0] == 0 and np.array_equal(again[1], states)
+    # the very first permutation is the transcript's first duplexing: its input starts with the init words
+    assert np.array_equal(states[0][: init.size], init)
+    for k in (1, pf.size // 2, pf.size - 3):              # a refused proof: the same verdict, the log ends where the check stopped
+        bad = pf.copy()
+        bad[k] = (int(bad[k]) + 1) % P
+        brc, bst = p3.verify_hashes(tables, bad, init, params=blob)
+        assert brc == p3.verify(tables, bad, init, params=blob) != 0 and bst.shape[0] <= states.shape[0]
+    assert p3.verify_hashes(tables, pf[:-1], init, params=blob)[0] == 1
+    chip = air_of("p2chip", None, 1)
+    pair = hash_statement_tables(states, chip, R.tables_of())
+    hp = o.oracle_p3_prove(pair)
+    assert o.oracle_p3_verify(pair, hp) == 0 == p3.verify(pair, hp, params=blob)
+    lie = o.from_mont(pair[1].trace).astype(np.uint64)
+    lie[5, 16] = (int(lie[5, 16]) + 1) % P                 # one claimed digest word that the permutation does not give
+    off = [pair[0], p3.Table.from_canonical(pair[1].air, lie)]
+    assert o.oracle_p3_verify(off, o.oracle_p3_prove(off)) == 8
+
+
+@pytest.mark.gpu
+def test_gpu_compress_hash_statement():
+    """the same loop with the GPU in it: shard proof by rk_p3_prove, its verifier's permutations, chip rows by rk_p2_chip_trace,
+    the hash proof by rk_p3_prove = the oracle's words"""
+    from p3_cases import P3_CASES, init_of, tables_of
+    case = "sp1_lookup_beside_plain"
+    preset, over, _, _ = P3_CASES[case]
+    h = hal.HipHal(0)
+    try:
+        blob = h.set_params(preset, **over)
+        o.oracle_set_params(preset, **over)
+        tables, init = tables_of(case), init_of(case)
+        pf = p3.prove(h, tables, init)
+        rc, states = p3.verify_hashes(tables, pf, init, params=blob)
+        assert rc == 0
+        chip = air_of("p2chip", None, 1)
+        ref_pair = hash_statement_tables(states, chip, R.tables_of())
+        n_chip = ref_pair[0].trace.shape[0]
+        d_rows, width = p3.poseidon2_chip_trace(h, ref_pair[0].trace[:, :16], ref_pair[0].trace[:, -1])
+        assert np.array_equal(d_rows.to_host().reshape(n_chip, width), ref_pair[0].trace)
+        from raiko_amd.hal import _ptr
+        dev_pair = [p3.Table(chip, None, []), ref_pair[1]]
+        dev_pair[0].log_height = ref_pair[0].log_height
+        got = p3.prove(h, dev_pair, device_traces=[(_ptr(d_rows), ref_pair[0].log_height), None])
+        assert np.array_equal(got, o.oracle_p3_prove(ref_pair))
+        assert p3.verify(ref_pair, got, params=blob) == 0
+    finally:
+        o.oracle_set_params()
+        h.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("preset", [0, 1])
 def test_gpu_chip_rows_equal_the_restatement(preset):

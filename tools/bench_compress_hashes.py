@@ -31,6 +31,13 @@ def main():
     import bench_p3
     hal = H.HipHal(0)
     blob = hal.set_params(1)
+    chip = p3.poseidon2_chip_air(blob)
+    chip.compile(hal)                                   # hiprtc, once per parameter set
+    cb = p3.AirBuilder(25, 0)
+    cb.assert_zero(cb.local(24) * (cb.local(24) - 1))
+    cb.send(p3.BUS_POSEIDON2, list(range(24)), mult=24, mult_is_const=False)
+    claims_air = cb.build(library_constraints=True)
+    claims_air.compile(hal)
     # 1. the shard proof
     tables, bufs, dev = [], [], []
     for i, spec in enumerate(args.shape.split(",")):
@@ -62,8 +69,6 @@ def main():
     chip_in[: len(uniq)] = uniq
     mult = np.zeros(1 << k_chip, dtype=np.uint32)
     mult[: len(uniq)] = p3.to_mont(counts)
-    chip = p3.poseidon2_chip_air(blob)
-    chip.compile(hal)
     d_rows, width = p3.poseidon2_chip_trace(hal, chip_in, mult)
     rows = torch.as_tensor(d_rows.to_host().reshape(-1, width).astype(np.int64))          # outputs for the claims table
     out = rows[:, chip.out_col: chip.out_col + 8].numpy().astype(np.uint32)
@@ -71,11 +76,6 @@ def main():
     claims[: len(states), :16] = states
     claims[: len(states), 16:24] = out[inverse.reshape(-1)]
     claims[: len(states), 24] = p3.to_mont(1)
-    cb = p3.AirBuilder(25, 0)
-    cb.assert_zero(cb.local(24) * (cb.local(24) - 1))
-    cb.send(p3.BUS_POSEIDON2, list(range(24)), mult=24, mult_is_const=False)
-    claims_air = cb.build(library_constraints=True)
-    claims_air.compile(hal)
     pair = [p3.Table(chip, None, []), p3.Table(claims_air, claims)]
     pair[0].log_height = k_chip
     from raiko_amd.hal import _ptr
