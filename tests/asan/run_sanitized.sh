@@ -11,7 +11,7 @@ B=${1:-$ROOT/tests/asan/_build/host}
 mkdir -p "$B"
 SRC=$ROOT/raiko_amd/csrc
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
-for f in context kernels_ntt kernels_hash kernels_poly kernels_scan circuit_program circuit_jit mmcs kernels_pcs p3 comm prover verify session; do
+for f in context kernels_ntt kernels_hash kernels_poly kernels_scan circuit_program circuit_jit mmcs kernels_pcs p3_air p3 comm prover verify session; do
   [ "$B/$f.o" -nt "$SRC/$f.hip" ] || /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$B/$f.o" &
   if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi
 done
