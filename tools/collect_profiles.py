@@ -31,6 +31,9 @@ def main():
     cp(f"{tag}_final_pmc_fetch/{tag}_counter_collection.csv", f"{tag}_final_pmc_fetch_size.csv")
     cp(f"{tag}_final_pmc_write/{tag}_counter_collection.csv", f"{tag}_final_pmc_write_size.csv")
     cp(f"{tag}_final_bench.json", f"{tag}_final_bench.json")
+    for extra in ("other_shapes.jsonl", "bench_sp1_p3_lookups.json", "bench_p2_chip.jsonl", "bench_compress_hashes.json"):
+        if os.path.exists(os.path.join(g, f"{tag}_{extra}")):
+            cp(f"{tag}_{extra}", f"{tag}_{extra}")
     for k in ("if1", "if3"):
         lines = [l for l in open(os.path.join(g, f"{tag}_final_{k}.log")) if l.startswith('{"metric"')]
         open(os.path.join(p, f"{tag}_final_bench_inflight{k[-1]}_under_rocprof.json"), "w").write(lines[-1])
