@@ -41,6 +41,8 @@ def test_gpu_proof_equals_oracle_and_committed_digest(hal, case):
     assert o.oracle_p3_verify(tables, got, init) == 0
     tm = p3.last_timing(hal)
     assert tm["total"] > 0 and tm["quotient"] > 0
+    arr, keep = p3._c_tables(tables)                      # the size bound is exact, lookups or not
+    assert p3._lib.load().rk_p3_proof_bound_words(blob, arr, len(tables)) == got.size
 
 
 def test_generated_kernel_gives_the_same_proof(hal):

@@ -37,6 +37,8 @@ def test_cases_match_committed_digests_and_both_verifiers_accept(params):
         assert {"words": int(pf.size), "sha256": sha(pf)} == GOLD[case], case
         assert o.oracle_p3_verify(tables, pf, init) == 0
         assert p3.verify(tables, pf, init, params=blob) == 0
+        arr, keep = p3._c_tables(tables)                  # rk_p3_proof_bound_words is exact (lookups or not)
+        assert _lib.load().rk_p3_proof_bound_words(blob, arr, len(tables)) == pf.size, case
         # bound to the statement: other init words, other public values, another parameter set
         assert p3.verify(tables, pf, np.concatenate([init, [1]]).astype(np.uint32), params=blob) != 0
         if tables[0].public_values.size:
