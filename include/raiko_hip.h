@@ -560,6 +560,9 @@ int rk_exec_lookup_tables(const rk_exec* ex, uint32_t index, uint32_t* range_tab
  * ctx stream: only the executed cycles (28 bytes each) cross PCIe; the trace has been copied when the call returns.
  * Hand the buffers to rk_prove_segment / a session as on_device inputs after rk_sync(ctx). */
 int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data);
+/* the 16 data columns as ONE row-major matrix (2^po2 rows x RK_TRACE_DATA_COLS words) in device memory: the form an
+ * on_device rk_p3_table takes (the execution proven as uni-stark shards: raiko_amd/executor.py p3_trace_air) */
+int rk_exec_witness_device_rows(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_rows);
 const char* rk_exec_error(const rk_exec* ex);
 int rk_exec_free(rk_exec* ex);
 

@@ -442,6 +442,7 @@ extern "C" {
     pub fn rk_exec_witness(ex: *const rk_exec, index: u32, code: *mut u32, data: *mut u32) -> c_int;
     pub fn rk_exec_lookup_tables(ex: *const rk_exec, index: u32, range_table: *mut u32, program_table: *mut u32, program_rows: *mut usize) -> c_int;
     pub fn rk_exec_witness_device(ctx: *mut rk_ctx, ex: *const rk_exec, index: u32, d_code: *mut u32, d_data: *mut u32) -> c_int;
+    pub fn rk_exec_witness_device_rows(ctx: *mut rk_ctx, ex: *const rk_exec, index: u32, d_rows: *mut u32) -> c_int;
     pub fn rk_exec_error(ex: *const rk_exec) -> *const c_char;
     pub fn rk_exec_free(ex: *mut rk_exec) -> c_int;
     pub fn rk_air_create(steps: *const rk_air_step, n_steps: usize, width: u32, n_public: u32, out: *mut *mut rk_air) -> c_int;

@@ -241,6 +241,7 @@ SYMBOLS = {
     "rk_exec_witness": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     "rk_exec_lookup_tables": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p, C.POINTER(C.c_size_t)]),
     "rk_exec_witness_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rk_exec_witness_device_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rk_exec_error": (C.c_char_p, [C.c_void_p]),
     "rk_exec_free": (C.c_int, [C.c_void_p]),
     "rk_program_create": (C.c_int, [_vp, _sz, _u32, C.POINTER(RkTaps), C.POINTER(_vp)]),

@@ -409,7 +409,7 @@ int exec_elf(const uint8_t* elf, size_t elf_bytes, const rk_exec_opts* o, rk_exe
 // The same columns written by the GPU: one lane per row, the trace rows (28 bytes per cycle) are the only upload --
 // 2.5x less over PCIe than the 18 finished columns and none of the host's time (rk_exec_witness_device).
 __global__ void exec_witness_kernel(uint32_t* __restrict__ code, uint32_t* __restrict__ data, const TraceRow* __restrict__ tr,
-                                    size_t cycles, size_t n, uint32_t end_pc) {
+                                    size_t cycles, size_t n, uint32_t end_pc, uint32_t rows_only) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool active = i < cycles;
@@ -418,9 +418,14 @@ __global__ void exec_witness_kernel(uint32_t* __restrict__ code, uint32_t* __res
     else r.pc = r.next = end_pc;
     const uint32_t lo = r.pc & 0xffffu, carry = (active && lo + 4 > 0xffffu) ? 1u : 0u;
     const uint32_t seq = (active && r.next == r.pc + 4 && r.pc <= 0xfffffffbu) ? 1u : 0u;
-    auto put = [&](uint32_t* base, unsigned col, uint32_t canon) { base[(size_t)col * n + i] = bb::mul(canon, bb::R2); };
-    put(code, 0, i == 0 ? 1u : 0u);
-    put(code, 1, i + 1 == n ? 1u : 0u);
+    // rows_only: the 16 data columns as one row-major row per lane (64 contiguous bytes: an rk_p3_table), no code columns
+    auto put = [&](uint32_t* base, unsigned col, uint32_t canon) {
+        base[rows_only ? i * RK_TRACE_DATA_COLS + col : (size_t)col * n + i] = bb::mul(canon, bb::R2);
+    };
+    if (!rows_only) {
+        put(code, 0, i == 0 ? 1u : 0u);
+        put(code, 1, i + 1 == n ? 1u : 0u);
+    }
     put(data, 0, lo);
     put(data, 1, r.pc >> 16);
     put(data, 2, r.next & 0xffffu);
@@ -546,21 +551,38 @@ int rk_exec_lookup_tables(const rk_exec* ex, uint32_t index, uint32_t* range_tab
     // among the ten limbs a row sends to the range table
     std::vector<uint32_t> hist((size_t)1 << 16, 0);
     std::unordered_map<uint64_t, uint32_t> seen;
-    seen.reserve(1 << 12);
+    // programs run from a few KiB of text: count per word of the executed pc range; the map only for what does not fit that
+    // picture (a range above 16 MiB, an address executed with two different instruction words)
+    uint32_t pc_lo = 0xffffffffu, pc_hi = 0;
+    for (const TraceRow& r : tr) pc_lo = std::min(pc_lo, r.pc), pc_hi = std::max(pc_hi, r.pc);
+    struct Slot {
+        uint32_t ins, count;
+    };
+    std::vector<Slot> direct;
+    const bool use_direct = !tr.empty() && (pc_hi - pc_lo) / 4 < (1u << 22);
+    if (use_direct) direct.assign((size_t)(pc_hi - pc_lo) / 4 + 1, Slot{0, 0});
     uint64_t last_key = ~(uint64_t)0;
     uint32_t* last = nullptr;
     for (const TraceRow& r : tr) {
-        const uint64_t key = (uint64_t)r.pc << 32 | r.ins;
-        if (key != last_key) {
-            last = &seen[key];     // references into an unordered_map stay valid across rehashing
-            last_key = key;
+        Slot* sl = use_direct && (r.pc & 3u) == 0 ? &direct[(r.pc - pc_lo) / 4] : nullptr;
+        if (sl && (sl->count == 0 || sl->ins == r.ins)) {
+            sl->ins = r.ins;
+            sl->count++;
+        } else {
+            const uint64_t key = (uint64_t)r.pc << 32 | r.ins;
+            if (key != last_key) {
+                last = &seen[key];     // references into an unordered_map stay valid across rehashing
+                last_key = key;
+            }
+            ++*last;
         }
-        ++*last;
         for (uint32_t v : {r.pc, r.next, r.a, r.b, r.res}) {
             hist[v & 0xffffu]++;
             hist[v >> 16]++;
         }
     }
+    for (size_t i = 0; i < direct.size(); i++)
+        if (direct[i].count) seen[(uint64_t)(pc_lo + 4 * (uint32_t)i) << 32 | direct[i].ins] += direct[i].count;
     size_t rows = 2;
     while (rows < seen.size()) rows <<= 1;
     const size_t capacity = *program_rows;
@@ -586,9 +608,21 @@ int rk_exec_lookup_tables(const rk_exec* ex, uint32_t index, uint32_t* range_tab
     return RK_OK;
     RK_GUARD_END
 }
+static int witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data, bool rows_only);
 int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data) {
     RK_GUARD_BEGIN
-    if (!ctx || !ex || !d_code || !d_data || index >= ex->segments.size() || index >= ex->traces.size()) return RK_ERR_INVALID;
+    if (!d_code) return RK_ERR_INVALID;
+    return witness_device(ctx, ex, index, d_code, d_data, false);
+    RK_GUARD_END
+}
+int rk_exec_witness_device_rows(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_rows) {
+    RK_GUARD_BEGIN
+    return witness_device(ctx, ex, index, nullptr, d_rows, true);
+    RK_GUARD_END
+}
+static int witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint32_t* d_code, uint32_t* d_data, bool rows_only) {
+    {
+    if (!ctx || !ex || !d_data || index >= ex->segments.size() || index >= ex->traces.size()) return RK_ERR_INVALID;
     const rk_exec_segment& seg = ex->segments[index];
     const std::vector<TraceRow>& tr = ex->traces[index];
     const size_t n = (size_t)1 << seg.po2;
@@ -608,12 +642,12 @@ int rk_exec_witness_device(rk_ctx* ctx, const rk_exec* ex, uint32_t index, uint3
     }
     if (st == RK_OK) {
         hipLaunchKernelGGL(exec_witness_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_code, d_data,
-                           (const TraceRow*)d_tr, tr.size(), n, seg.end_pc);
+                           (const TraceRow*)d_tr, tr.size(), n, seg.end_pc, rows_only ? 1u : 0u);
         st = rk::post_launch(ctx, "exec_witness_kernel");
     }
     rk::dev_free(ctx, d_tr);
     return st;
-    RK_GUARD_END
+    }
 }
 const char* rk_exec_error(const rk_exec* ex) { return ex ? ex->error.c_str() : ""; }
 int rk_exec_free(rk_exec* ex) {

@@ -177,6 +177,35 @@ class Stepper:
         self.n += 1
         return seg, code, data
 
+    def next_shard(self, hal, lookups=True):
+        """the next executed segment as the tables of a uni-stark shard: the 16 data columns written on the GPU as one
+        row-major matrix (rk_exec_witness_device_rows) and -- lookups -- the program / range tables (rk_exec_lookup_tables,
+        host) -> (ExecSegment, device rows buffer, program table or None, range table or None), or None after the last"""
+        if not self.more:
+            return None
+        more = C.c_int(0)
+        st = self._lib.rk_exec_next_segment(self._h, C.byref(more))
+        if st != 0:
+            raise ExecutorError("%s: %s" % (self._lib.rk_strerror(st).decode(), self._lib.rk_exec_error(self._h).decode()))
+        self.more = bool(more.value)
+        s = RkExecSegment()
+        self._lib.rk_exec_segment_get(self._h, self.n, C.byref(s))
+        seg = ExecSegment(s.index, s.po2, int(s.cycles), s.start_pc, s.end_pc, s.exit, tuple(s.pre_state), tuple(s.post_state))
+        rows = hal.alloc_elem(TRACE_DATA_COLS << seg.po2)
+        _lib.check(hal._ctx, self._lib.rk_exec_witness_device_rows(hal._ctx, self._h, self.n, C.c_void_p(rows.ptr)))
+        prog = rng = None
+        if lookups:
+            rng = np.zeros((1 << 16, 2), dtype=np.uint32)
+            n_rows = C.c_size_t(0)
+            st2 = self._lib.rk_exec_lookup_tables(self._h, self.n, rng.ctypes.data_as(_lib.u32p), None, C.byref(n_rows))
+            if st2 != _lib.RK_ERR_CAPACITY:
+                _lib.check(None, st2 or _lib.RK_ERR_INTERNAL)
+            prog = np.zeros((n_rows.value, 5), dtype=np.uint32)
+            _lib.check(None, self._lib.rk_exec_lookup_tables(self._h, self.n, rng.ctypes.data_as(_lib.u32p), prog.ctypes.data_as(_lib.u32p), C.byref(n_rows)))
+        hal.sync()       # the rows are complete before another context's stream reads them
+        self.n += 1
+        return seg, rows, prog, rng
+
     def finish(self) -> Execution:
         summ = RkExecSummary()
         self._lib.rk_exec_summary_get(self._h, C.byref(summ))
@@ -380,6 +409,114 @@ def p3_shards(ex: Execution, air=None, lookups=False, ext_w=None):
             tables += [p3.Table.from_canonical(prog_air, prog), p3.Table.from_canonical(range_air, rng)]
         out.append((tables, np.array(list(s.pre_state) + list(s.post_state), dtype=np.uint32)))
     return out
+
+
+class P3Pipeline:
+    """ELF -> verified shard proofs with the three stages overlapped: the calling thread runs the executor one shard at a
+    time (rk_exec_next_segment), has the shard's cpu table written on the GPU from the executed cycles
+    (rk_exec_witness_device_rows: the trace never exists on the host) and builds its lookup tables; a second thread proves
+    the shards as they arrive (rk_p3_prove on its own context, the cpu table an on_device input); a small pool verifies
+    the proofs (rk_p3_verify is host code).  The contexts and the (compiled) AIRs live as long as the object: run() any
+    number of programs, then close()."""
+
+    def __init__(self, params=None, device: int = 0, lookups=True, compile_airs=True):
+        from . import p3
+        from .hal import HipHal, make_params
+        self.params = params if params is not None else make_params(1)
+        self.lookups = lookups
+        ext_w = int(self.params.ext_w)
+        self.cpu_air = p3_trace_air(lookups, ext_w)
+        self.prog_air, self.range_air = (p3_program_air(ext_w), p3_range_air(ext_w)) if lookups else (None, None)
+        self.wit_hal, self.prove_hal = HipHal(device), HipHal(device)
+        _lib.check(self.prove_hal._ctx, self.prove_hal._lib.rk_set_params(self.prove_hal._ctx, C.byref(self.params)))
+        if compile_airs:
+            for a in (self.cpu_air, self.prog_air, self.range_air):
+                if a is not None:
+                    a.compile(self.prove_hal)
+
+    def close(self):
+        for h in (self.wit_hal, self.prove_hal):
+            if h is not None:
+                h.close()
+        self.wit_hal = self.prove_hal = None
+
+    def run(self, elf: bytes, input_words: Sequence[int] = (), shard_po2: int = 20, verify=True, keep_tables=False):
+        """-> (Execution, [proof words], [(tables, init)] when keep_tables)"""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        from . import p3
+        from .hal import _ptr
+        mont = lambda v: (int(v) << 32) % P
+        todo = queue.Queue(maxsize=3)           # back-pressure: at most three shards' tables wait for the prover
+        done = queue.Queue()                    # cpu tables the prover is through with: freed by the thread that owns their context
+        proofs, checks, kept, errors = [], [], [], []
+        pool = ThreadPoolExecutor(max_workers=4)
+        lookups, params = self.lookups, self.params
+
+        def prover():
+            try:
+                while True:
+                    item = todo.get()
+                    if item is None:
+                        return
+                    seg, rows, prog, rng = item
+                    pub = np.array([mont(v) for v in (seg.start_pc & 0xFFFF, seg.start_pc >> 16, seg.end_pc & 0xFFFF, seg.end_pc >> 16)], dtype=np.uint32)
+                    cpu = p3.Table(self.cpu_air, None, pub)
+                    cpu.log_height = seg.po2
+                    tables = [cpu] + ([p3.Table(self.prog_air, prog), p3.Table(self.range_air, rng)] if lookups else [])
+                    init = np.array(list(seg.pre_state) + list(seg.post_state), dtype=np.uint32)
+                    pf = p3.prove(self.prove_hal, tables, init, device_traces=[(_ptr(rows), seg.po2)] + [None] * (len(tables) - 1))
+                    proofs.append(pf)
+                    if verify:
+                        checks.append(pool.submit(p3.verify, tables, pf, init, params))
+                    if keep_tables:
+                        host = p3.Table(self.cpu_air, rows.to_host().reshape(-1, TRACE_DATA_COLS), pub)
+                        kept.append(([host] + tables[1:], init))
+                    done.put(rows)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                while todo.get() is not None:      # drain: the producer must not block on a full queue
+                    pass
+
+        th = threading.Thread(target=prover)
+        th.start()
+        stepper = Stepper(elf, input_words, shard_po2)
+        metas, bad = [], []
+        try:
+            while True:
+                while not done.empty():
+                    done.get().free()
+                item = stepper.next_shard(self.wit_hal, lookups)
+                if item is None or errors:
+                    break
+                metas.append(item[0])
+                todo.put(item)
+            ex = stepper.finish()
+            ex.segments = metas
+        finally:
+            todo.put(None)
+            th.join()
+            while not done.empty():
+                done.get().free()
+            stepper.close()
+            bad = [i for i, c in enumerate(checks) if c.result() != 0]
+            pool.shutdown()
+        if errors:
+            raise errors[0]
+        if bad:
+            raise _lib.RkError(_lib.RK_ERR_VERIFY, "shard %d does not verify" % bad[0])
+        return ex, proofs, kept
+
+
+def execute_and_prove_p3_pipelined(elf: bytes, input_words: Sequence[int] = (), shard_po2: int = 20, params=None, device: int = 0,
+                                   lookups=True, compile_airs=True, verify=True, keep_tables=False):
+    """one program through a P3Pipeline of its own"""
+    pipe = P3Pipeline(params, device, lookups, compile_airs)
+    try:
+        return pipe.run(elf, input_words, shard_po2, verify, keep_tables)
+    finally:
+        pipe.close()
 
 
 def execute_and_prove_p3(elf: bytes, input_words: Sequence[int] = (), shard_po2: int = 16, params=None, device: int = 0, batch: int = 3,

@@ -245,4 +245,13 @@ def test_elf_to_shard_proofs(hal):
     with pytest.raises(RkError) as ei:
         p3.prove_shards(bad, blob, batch=2, verify=True)
     assert ei.value.status == -7 and ei.value.segment == 1
+    # the same, overlapped: executor | cpu table written on the GPU (rk_exec_witness_device_rows) | prover | verifier
+    ex4, pproofs, kept = X.execute_and_prove_p3_pipelined(image, shard_po2=13, params=blob, keep_tables=True)
+    assert ex4.total_cycles == ex3.total_cycles and len(pproofs) == 5
+    for a, b in zip(pproofs, lproofs):
+        assert np.array_equal(a, b)
+    for (ta, _), (tb, _) in zip(kept, lk):                 # the GPU-written cpu table and the native lookup tables: the host route's
+        assert all(np.array_equal(x.trace, y.trace) for x, y in zip(ta, tb))
+    plain = X.execute_and_prove_p3_pipelined(image, shard_po2=13, params=blob, lookups=False, compile_airs=False)[1]
+    assert all(np.array_equal(a, b) for a, b in zip(plain, proofs))
     H.session_release()
