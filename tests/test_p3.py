@@ -117,6 +117,20 @@ def test_lookup_air_create_rejects_malformed_interactions():
     assert create(wide + [0, 1, 1, 1, 1, 120], 3, width=200) == -1
     # the permutation leaves are range-checked against what the interactions give: 1 interaction = 8 base columns,
     # a tuple of 2 = alpha, beta^0..beta^2 = 16 challenge words
+    # random word lists: accepted or refused, never anything else (this file also runs under ASan / UBSan: tests/asan)
+    rng = np.random.default_rng(5)
+    seen = set()
+    for k in range(400):
+        n_ix = int(rng.integers(0, 5))
+        words = []
+        for _ in range(n_ix):
+            nv = int(rng.integers(0, 5))
+            words += [int(rng.integers(0, 3)), int(rng.integers(0, 9)), int(rng.integers(0, 3)), int(rng.integers(0, 5)), nv if rng.random() < 0.9 else nv + 1]
+            words += [int(v) for v in rng.integers(0, 4, size=nv)]
+        if rng.random() < 0.2 and words:
+            words = words[: int(rng.integers(0, len(words)))]
+        seen.add(create(words or [0], n_ix if words else 0, ext_w=int(rng.integers(0, 2)) * 11) if words or n_ix == 0 else -1)
+    assert seen == {0, -1}
     for op, lim in ((p3.PERM_LOCAL, 8), (p3.PERM_NEXT, 8), (p3.CHALLENGE, 16), (p3.CUMSUM, 4)):
         ok = np.array([(op, lim - 1, 0)], dtype=np.uint32)
         bad = np.array([(op, lim, 0)], dtype=np.uint32)
