@@ -28,6 +28,7 @@
 //   queries        every opened row and sibling digest of the proof in ONE gather launch and one download
 // The transcript (DuplexChallenger) runs on the host between those steps; the proof of work on the GPU.
 #include "p3_air.hpp"
+#include "p3_kernels.hpp"
 
 #include <array>
 #include <atomic>
@@ -161,63 +162,15 @@ __global__ void add_words_kernel(uint32_t* __restrict__ io, const uint32_t* __re
     if (i < n) io[i] = bb::add(io[i], in[i]);
 }
 
-// ---- lookups (sp1-core generate_permutation_trace, RECALLED).  desc = the challenge vector [alpha | beta^0 | beta^1 ..]
-// (4 words each, n_chal words), the flat interactions (kind, bus, mult_is_const, mult, n_values, slots...; constants as
-// Montgomery words; columns renumbered to slots of the `used` list), then the n_used distinct main-trace columns the
-// interactions read.  A workgroup takes PERM_ROWS rows of the row-major trace: first every wave stages the used
-// columns of its rows in LDS -- one row per load instruction, the lanes along the used columns, so a row's cache lines
-// are fetched once instead of once per interaction --, then one lane per row walks the interactions out of LDS
-// (slot-major: conflict-free).  out = 4 (nb + 1) columns of n words: the nb batch entries, then the row totals (the
-// prefix sums turn those into the running sum in place).
-constexpr int PERM_ROWS = 256, PERM_LD = PERM_ROWS + 1;   // odd slot stride: the staging writes (lanes along slots) and the reads (lanes along rows) both spread over the banks
-struct PermArgs {
-    uint32_t* out;
-    const uint32_t* trace;
-    const uint32_t* desc;
-    size_t n, w;
-    uint32_t n_chal, n_lookups, wm, n_used, desc_words;
-};
+// ---- lookups: the permutation trace.  The lane bodies are p3_kernels.hpp's (tests/emul runs them on the CPU too)
+using p3k::PERM_LD;
+using p3k::PERM_ROWS;
+using p3k::PermArgs;
 __global__ void __launch_bounds__(PERM_ROWS) perm_entries_kernel(PermArgs a) {
     extern __shared__ uint32_t tile[];   // n_used x PERM_LD
-    const size_t r0 = (size_t)blockIdx.x * PERM_ROWS;
-    const uint32_t* used = a.desc + a.desc_words;
-    {
-        const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (unsigned i = 0; i < 64; i++) {
-            const unsigned lr = wave * 64 + i;
-            if (r0 + lr >= a.n) break;
-            const uint32_t* row = a.trace + (r0 + lr) * a.w;
-            for (uint32_t u = lane; u < a.n_used; u += 64) tile[u * PERM_LD + lr] = row[used[u]];
-        }
-    }
+    p3k::perm_stage(a, blockIdx.x, threadIdx.x, tile);
     __syncthreads();
-    const size_t r = r0 + threadIdx.x;
-    if (r >= a.n) return;
-    const uint32_t* row = tile + threadIdx.x;
-    const uint32_t* ch = a.desc;
-    const uint32_t* d = a.desc + a.n_chal;
-    const Ext alpha{{ch[0], ch[1], ch[2], ch[3]}};
-    Ext total = bb::ext_zero(), entry = bb::ext_zero();
-    const uint32_t nb = (a.n_lookups + 1) / 2;
-    for (uint32_t i = 0; i < a.n_lookups; i++) {
-        const uint32_t kind = d[0], bus = d[1], is_const = d[2], mult = d[3], nv = d[4];
-        Ext rlc = bb::add(alpha, bb::scale(Ext{{ch[4], ch[5], ch[6], ch[7]}}, bus));
-        for (uint32_t j = 0; j < nv; j++) {
-            const uint32_t* b = ch + 8 + 4 * j;
-            rlc = bb::add(rlc, bb::scale(Ext{{b[0], b[1], b[2], b[3]}}, row[d[5 + j] * PERM_LD]));
-        }
-        const uint32_t m = is_const ? mult : row[mult * PERM_LD];
-        const Ext term = bb::scale(bb::inv(rlc, a.wm), kind == 0 ? m : bb::neg(m));
-        entry = bb::add(entry, term);
-        d += 5 + nv;
-        if ((i & 1u) || i + 1 == a.n_lookups) {
-            const uint32_t b = i >> 1;
-            for (int k = 0; k < 4; k++) a.out[(size_t)(4 * b + k) * a.n + r] = entry.c[k];
-            total = bb::add(total, entry);
-            entry = bb::ext_zero();
-        }
-    }
-    for (int k = 0; k < 4; k++) a.out[(size_t)(4 * nb + k) * a.n + r] = total.c[k];
+    p3k::perm_row(a, blockIdx.x, threadIdx.x, tile);
 }
 
 // inclusive prefix sums of `cols` columns of n words (blockIdx.y = column), in place: workgroup totals, one carry pass

@@ -5,6 +5,7 @@
 // provers/sp1/driver/src/lib.rs:44-57; p3-uni-stark symbolic_builder.rs / symbolic_expression.rs, sp1-core
 // stark/permutation.rs, sp1-recursion-core's Poseidon2 wide chip: outside the reference tree, RECALLED.
 #include "p3_air.hpp"
+#include "p3_kernels.hpp"
 
 #include <array>
 #include <cstring>
@@ -155,17 +156,7 @@ struct PermStepGen {
 //   x3i_k R_P (cube of cell 0 + rc in internal round k) | s0_k R_P - 1 (cell 0 entering internal round k >= 1) |
 //   int_out W (the state after the internal rounds) | external rounds 4..7 likewise | multiplicity
 // x^7 = x3 * x3 * x keeps every constraint at degree 3; between commitments the state is carried as expressions.
-struct P2ChipLayout {
-    uint32_t W, RP, width;
-    RK_HD uint32_t in() const { return 0; }
-    RK_HD uint32_t x3(uint32_t r) const { return r < 4 ? W + 2 * W * r : W + 8 * W + 2 * RP - 1 + W + 2 * W * (r - 4); }
-    RK_HD uint32_t post(uint32_t r) const { return x3(r) + W; }
-    RK_HD uint32_t x3i(uint32_t k) const { return W + 8 * W + k; }
-    RK_HD uint32_t s0(uint32_t k) const { return W + 8 * W + RP + (k - 1); }   // k >= 1
-    RK_HD uint32_t int_out() const { return W + 8 * W + 2 * RP - 1; }
-    RK_HD uint32_t mult() const { return width - 1; }
-    RK_HD uint32_t out() const { return post(7); }
-};
+using p3k::P2ChipLayout;
 P2ChipLayout p2_chip_layout(const p2::Any& k) {
     P2ChipLayout L;
     L.W = (uint32_t)k.cells();
@@ -235,68 +226,13 @@ void p2_chip_steps(const p2::Any& k, std::vector<rk_air_step>& steps) {
     for (uint32_t r = 4; r < 8; r++) ext_round(st, r);
 }
 
-// the chip's rows on the GPU: one lane per permutation; tab = rc_ext | rc_int | diag (Montgomery words)
-template <int W, int RP, int M4>
-__device__ void p2_dev_m_ext(uint32_t (&c)[W]) {
-    uint32_t sums[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < W; i += 4) {
-        const uint32_t a = c[i], b = c[i + 1], d = c[i + 2], e = c[i + 3];
-        if (M4 == 0) {
-            const uint32_t t0 = bb::add(a, b), t1 = bb::add(d, e), t2 = bb::add(bb::dbl(b), t1), t3 = bb::add(bb::dbl(e), t0);
-            const uint32_t t4 = bb::add(bb::dbl(bb::dbl(t1)), t3), t5 = bb::add(bb::dbl(bb::dbl(t0)), t2);
-            c[i] = bb::add(t3, t5), c[i + 1] = t5, c[i + 2] = bb::add(t2, t4), c[i + 3] = t4;
-        } else {
-            const uint32_t s = bb::add(bb::add(a, b), bb::add(d, e));
-            c[i] = bb::add(bb::add(s, a), bb::dbl(b));
-            c[i + 1] = bb::add(bb::add(s, b), bb::dbl(d));
-            c[i + 2] = bb::add(bb::add(s, d), bb::dbl(e));
-            c[i + 3] = bb::add(bb::add(s, e), bb::dbl(a));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) sums[j] = bb::add(sums[j], c[i + j]);
-    }
-#pragma unroll
-    for (int i = 0; i < W; i++) c[i] = bb::add(c[i], sums[i & 3]);
-}
+// the chip's rows on the GPU: one lane per permutation (p3k::chip_row, p3_kernels.hpp)
 template <int W, int RP, int M4>
 __global__ void __launch_bounds__(128) p2_chip_trace_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, const uint32_t* __restrict__ mult,
                                                             const uint32_t* __restrict__ tab, size_t n, P2ChipLayout L) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    uint32_t* row = out + r * L.width;
-    const uint32_t *rc_ext = tab, *rc_int = tab + 8 * W, *diag = rc_int + RP;
-    uint32_t c[W];
-#pragma unroll
-    for (int i = 0; i < W; i++) row[i] = c[i] = in[r * W + i];
-    p2_dev_m_ext<W, RP, M4>(c);
-    auto ext_round = [&](int rd) {
-#pragma unroll
-        for (int i = 0; i < W; i++) {
-            const uint32_t s = bb::add(c[i], rc_ext[rd * W + i]), x3 = bb::mul(bb::sqr(s), s);
-            row[L.x3(rd) + i] = x3;
-            c[i] = bb::mul(bb::sqr(x3), s);
-        }
-        p2_dev_m_ext<W, RP, M4>(c);
-#pragma unroll
-        for (int i = 0; i < W; i++) row[L.post(rd) + i] = c[i];
-    };
-    for (int rd = 0; rd < 4; rd++) ext_round(rd);
-    for (int k = 0; k < RP; k++) {
-        if (k > 0) row[L.s0(k)] = c[0];
-        const uint32_t t = bb::add(c[0], rc_int[k]), x3 = bb::mul(bb::sqr(t), t);
-        row[L.x3i(k)] = x3;
-        c[0] = bb::mul(bb::sqr(x3), t);
-        uint32_t sum = 0;
-#pragma unroll
-        for (int i = 0; i < W; i++) sum = bb::add(sum, c[i]);
-#pragma unroll
-        for (int i = 0; i < W; i++) c[i] = bb::add(sum, bb::mul(c[i], diag[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < W; i++) row[L.int_out() + i] = c[i];
-    for (int rd = 4; rd < 8; rd++) ext_round(rd);
-    row[L.mult()] = mult ? mult[r] : bb::ONE;
+    p3k::chip_row<W, RP, M4>(out + r * L.width, in + r * W, mult ? mult[r] : bb::ONE, tab, L);
 }
 
 }  // namespace

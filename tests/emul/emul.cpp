@@ -3,6 +3,7 @@
 // the tile/index/twiddle logic of the HIP kernels can be checked against the
 // oracle without a GPU.  The GPU kernels are these same phase functions with
 // __syncthreads() between phases (raiko_amd/csrc/kernels_ntt.hip).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -11,6 +12,7 @@
 #include "ntt_fused.hpp"
 #include "poseidon2_any.hpp"
 #include "poseidon2_consts.inc"
+#include "p3_kernels.hpp"
 
 namespace {
 std::vector<uint32_t> g_tables;
@@ -267,5 +269,33 @@ void emul_ext_inv(const uint32_t* a, uint32_t* o) {
     std::memcpy(o, r.c, 16);
 }
 uint32_t emul_pow3(uint32_t e) { ensure_tables(); return ntt::pow3(g_tb, e); }
+
+// mirrors perm_entries_kernel (p3.hip): per workgroup, phase 1 (staging) for every lane, then phase 2 (one row per lane)
+void emul_perm_entries(uint32_t* out, const uint32_t* trace, const uint32_t* desc, size_t n, size_t w, uint32_t n_chal, uint32_t n_lookups,
+                       uint32_t wm, uint32_t n_used, uint32_t desc_words) {
+    p3k::PermArgs a{out, trace, desc, n, w, n_chal, n_lookups, wm, n_used, desc_words};
+    std::vector<uint32_t> tile((size_t)(n_used ? n_used : 1) * p3k::PERM_LD, 0xdeadbeefu);
+    for (size_t blk = 0; blk < (n + p3k::PERM_ROWS - 1) / p3k::PERM_ROWS; blk++) {
+        std::fill(tile.begin(), tile.end(), 0xdeadbeefu);      // a read of a slot nobody staged shows
+        for (unsigned tid = 0; tid < (unsigned)p3k::PERM_ROWS; tid++) p3k::perm_stage(a, blk, tid, tile.data());
+        for (unsigned tid = 0; tid < (unsigned)p3k::PERM_ROWS; tid++) p3k::perm_row(a, blk, tid, tile.data());
+    }
+}
+// mirrors p2_chip_trace_kernel (p3_air.hip)
+int emul_p2_chip_rows(uint32_t* out, const uint32_t* in, const uint32_t* mult, const uint32_t* tab, size_t n, int width16, int m4) {
+    p3k::P2ChipLayout L;
+    L.W = width16 ? 16 : 24;
+    L.RP = width16 ? 13 : 21;
+    L.width = L.W + 16 * L.W + 2 * L.RP - 1 + L.W + 1;
+    for (size_t r = 0; r < n; r++) {
+        uint32_t* row = out + r * L.width;
+        const uint32_t m = mult ? mult[r] : bb::ONE;
+        if (width16 && m4) p3k::chip_row<16, 13, 1>(row, in + r * 16, m, tab, L);
+        else if (width16) p3k::chip_row<16, 13, 0>(row, in + r * 16, m, tab, L);
+        else if (m4) p3k::chip_row<24, 21, 1>(row, in + r * 24, m, tab, L);
+        else p3k::chip_row<24, 21, 0>(row, in + r * 24, m, tab, L);
+    }
+    return (int)L.width;
+}
 
 }  // extern "C"

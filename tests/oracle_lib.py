@@ -28,7 +28,8 @@ def build_oracle(force=False):
 def build_emul(force=False):
     csrc = os.path.join(ROOT, "raiko_amd", "csrc")
     srcs = [os.path.join(EMUL_DIR, "emul.cpp")] + [os.path.join(csrc, f) for f in
-                                                   ("bb.hpp", "ntt_core.hpp", "ntt_fused.hpp", "poseidon2_core.hpp", "poseidon2_any.hpp", "poseidon2_consts.inc")]
+                                                   ("bb.hpp", "ntt_core.hpp", "ntt_fused.hpp", "poseidon2_core.hpp", "poseidon2_any.hpp", "poseidon2_consts.inc",
+                                                    "p3_kernels.hpp")]
     if not force and os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs):
         return EMUL_SO
     os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
@@ -200,6 +201,10 @@ def emul():
         lib.emul_ext_mul.argtypes = [vp, vp, vp]
         lib.emul_ext_inv.restype = None
         lib.emul_ext_inv.argtypes = [vp, vp]
+        lib.emul_perm_entries.restype = None
+        lib.emul_perm_entries.argtypes = [vp, vp, vp, sz, sz, u32, u32, u32, u32, u32]
+        lib.emul_p2_chip_rows.restype = C.c_int
+        lib.emul_p2_chip_rows.argtypes = [vp, vp, vp, vp, sz, C.c_int, C.c_int]
         _emul = lib
     return _emul
 

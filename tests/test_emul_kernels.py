@@ -183,3 +183,88 @@ def test_poseidon2_with_other_constants(emu):
             st = o.to_mont(np.array(c, dtype=np.uint64))
             emu.emul_poseidon2_permute_with(st.ctypes.data, m[0].ctypes.data, m[1].ctypes.data, m[2].ctypes.data)
             assert [int(x) for x in o.from_mont(st)] == _py_permute(c, ext, internal, diag)
+
+
+# ---- the uni-stark path's own kernels (raiko_amd/csrc/p3_kernels.hpp): the lane bodies of perm_entries_kernel and
+# p2_chip_trace_kernel, emulated lane by lane
+@pytest.mark.parametrize("preset", [0, 1])
+def test_poseidon2_chip_rows_lane_by_lane(emu, preset):
+    """p3k::chip_row (one lane of rk_p2_chip_trace) against the numpy restatement, whose outputs are the oracle's permutation"""
+    import p2_chip_ref as R
+    o.oracle_set_params(preset)
+    try:
+        rc_ext, rc_int, diag, m4 = R.tables_of()
+        w = diag.size
+        tab = o.to_mont(np.concatenate([rc_ext.reshape(-1), rc_int, diag]))
+        rng = np.random.default_rng(3 + preset)
+        x = rng.integers(0, P, size=(37, w)).astype(np.uint64)
+        mult = rng.integers(0, 5, size=37).astype(np.uint64)
+        want = R.chip_trace(x, (rc_ext, rc_int, diag, m4), mult).astype(np.uint32)
+        got = np.zeros(want.shape, dtype=np.uint32)
+        xin, mm = o.to_mont(x), o.to_mont(mult)
+        width = emu.emul_p2_chip_rows(got.ctypes.data, xin.ctypes.data, mm.ctypes.data, tab.ctypes.data, 37, 1 if w == 16 else 0, m4)
+        assert width == want.shape[1] and np.array_equal(o.from_mont(got), want)
+        emu.emul_p2_chip_rows(got.ctypes.data, xin.ctypes.data, None, tab.ctypes.data, 37, 1 if w == 16 else 0, m4)
+        assert np.array_equal(o.from_mont(got[:, -1]), np.ones(37, dtype=np.uint32))
+    finally:
+        o.oracle_set_params()
+
+
+@pytest.mark.parametrize("n,w", [(2, 5), (300, 9), (513, 130)])
+def test_permutation_trace_lane_by_lane(orc, emu, n, w):
+    """p3k::perm_stage / perm_row (perm_entries_kernel: the used columns of 256 rows staged through LDS, then one lane per
+    row) against the definition evaluated with the oracle's extension arithmetic: per batch of two interactions
+    sum of +-mult / (alpha + beta^0 bus + sum_j beta^(j+1) x_j), then the row total"""
+    rng = np.random.default_rng(n + w)
+    wm = o.to_mont(np.array([11], dtype=np.uint64))[0]
+    orc_w = o.oracle_set_params(1)                      # x^4 - 11: the extension the oracle's fp4 ops use now
+    try:
+        trace = o.rand_elems(rng, (n, w))
+        # interactions: (kind, bus, mult_is_const, mult, columns); up to 120 distinct columns when the table is wide
+        ix = [(0, 3, 1, 2, [0, 1]), (1, 3, 0, 2, [1, 0, 3]), (0, 9, 1, 0, []), (1, 4, 0, 4, [2]), (0, 5, 1, 7, [4, 4])]
+        if w > 100:
+            ix.append((1, 6, 1, 1, list(range(10, 70))))
+            ix.append((0, 7, 0, 99, list(range(69, 129))))
+        kmax = max(len(c) for *_, c in ix)
+        chal = o.rand_elems(rng, (kmax + 2, 4))            # alpha, beta^0 .. beta^K (any values do for the kernel)
+        used, flat = [], []
+        slot = lambda c: used.index(c) if c in used else (used.append(c) or len(used) - 1)
+        for kind, bus, is_const, mult, cols in ix:
+            m = int(o.to_mont(np.array([mult], dtype=np.uint64))[0]) if is_const else slot(mult)
+            flat += [kind, int(o.to_mont(np.array([bus], dtype=np.uint64))[0]), is_const, m, len(cols)] + [slot(c) for c in cols]
+        desc = np.concatenate([chal.reshape(-1), np.array(flat, dtype=np.uint32), np.array(used, dtype=np.uint32)]).astype(np.uint32)
+        nb = (len(ix) + 1) // 2
+        got = np.zeros((4 * (nb + 1), n), dtype=np.uint32)
+        emu.emul_perm_entries(got.ctypes.data, trace.ctypes.data, desc.ctypes.data, n, w, chal.size, len(ix), int(wm), len(used), chal.size + len(flat))
+
+        def ext_mul(a, b):
+            out = np.zeros(4, dtype=np.uint32)
+            orc.or_fp4_mul(np.ascontiguousarray(a).ctypes.data_as(o.u32p), np.ascontiguousarray(b).ctypes.data_as(o.u32p), out.ctypes.data_as(o.u32p))
+            return out
+
+        def ext_inv(a):
+            out = np.zeros(4, dtype=np.uint32)
+            orc.or_fp4_inv(np.ascontiguousarray(a).ctypes.data_as(o.u32p), out.ctypes.data_as(o.u32p))
+            return out
+
+        add = lambda a, b: np.array([orc.or_fp_add(int(x), int(y)) for x, y in zip(a, b)], dtype=np.uint32)
+        scale = lambda a, s: np.array([orc.or_fp_mul(int(x), int(s)) for x in a], dtype=np.uint32)
+        neg = lambda a: np.array([orc.or_fp_sub(0, int(x)) for x in a], dtype=np.uint32)
+        rows = [0, n - 1] if n <= 2 else [0, 1, 255, 256, n - 1]
+        for r in rows:
+            total = np.zeros(4, dtype=np.uint32)
+            for b in range(nb):
+                entry = np.zeros(4, dtype=np.uint32)
+                for kind, bus, is_const, mult, cols in ix[2 * b: 2 * b + 2]:
+                    rlc = add(chal[0], scale(chal[1], o.to_mont(np.array([bus], dtype=np.uint64))[0]))
+                    for j, c in enumerate(cols):
+                        rlc = add(rlc, scale(chal[2 + j], trace[r, c]))
+                    m = o.to_mont(np.array([mult], dtype=np.uint64))[0] if is_const else trace[r, mult]
+                    term = scale(ext_inv(rlc), m)
+                    entry = add(entry, term if kind == 0 else neg(term))
+                assert np.array_equal(got[4 * b: 4 * b + 4, r], entry), (r, b)
+                total = add(total, entry)
+            assert np.array_equal(got[4 * nb:, r], total), r
+        assert ext_mul(chal[0], ext_inv(chal[0])).tolist() == [int(o.to_mont(np.array([1], dtype=np.uint64))[0]), 0, 0, 0]
+    finally:
+        o.oracle_set_params()
