@@ -310,41 +310,53 @@ int d2h(rk_ctx* ctx, void* h, const void* d, size_t bytes) {
     return RK_OK;
 }
 
-int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init, size_t n_init, uint32_t* h_proof,
-             size_t capacity, size_t* proof_words) {
+// One rk_p3_prove: the state the stages share and the stages in the order the transcript imposes
+struct ProofRun {
+    rk_ctx* ctx;
+    const rk_p3_table* tables;
+    uint32_t n_tables;
     rk_params par;
-    RK_TRY(rk_get_params(ctx, &par));
+    unsigned blow = 0;
     uint32_t lqd[MAX_TABLES];
-    RK_TRY(check_tables(par, tables, n_tables, true, lqd));
-    for (size_t i = 0; i < n_init; i++)
-        if (init[i] >= bb::P) return RK_ERR_INVALID;
-    const size_t bound = proof_bound(par, tables, n_tables, lqd);
-    if (capacity < bound) {
-        *proof_words = bound;
-        return RK_ERR_CAPACITY;
-    }
-    const unsigned blow = par.blowup_log2;
-    rk_p3_timing& tm = ctx->p3_timing;
-    tm = rk_p3_timing{};
-    const double t_start = now_ms();
-    double t_mark = t_start;
-    auto lap = [&](float& slot) {
+    rk_p3_timing& tm;
+    double t_mark = 0;
+    std::vector<uint32_t> pf;            // the proof words before the query openings
+    Challenger ch;
+    std::vector<TableState> ts;
+    std::vector<rk_matrix> tmats, pmats, qmats;   // the three input batches: traces, permutation traces, quotient chunks
+    DevBuf tnodes, pnodes, qnodes;
+    size_t Ht = 0, Hp = 0, Hq = 0;
+    unsigned log_max = 0, n_rounds = 0;
+    std::vector<uint32_t> pchal;         // lookups: [alpha | beta^0 | .. | beta^K], every table reads a prefix
+    uint32_t root[8];
+    Ext zeta;
+    DevBuf ro[ntt::LAMBDA + 1];          // reduced openings per LDE height
+    struct Layer {
+        DevBuf values, nodes;            // 2^(log_max - round) extension elements; the tree over their pairs
+    };
+    std::vector<Layer> layers;
+
+    ProofRun(rk_ctx* c, const rk_p3_table* t, uint32_t n) : ctx(c), tables(t), n_tables(n), tm(c->p3_timing), ch(&c->h_p2) {}
+    void lap(float& slot) {
         (void)hipStreamSynchronize(ctx->stream);
         const double t = now_ms();
         slot += (float)(t - t_mark);
         t_mark = t;
-    };
-    std::vector<uint32_t> pf;
-    pf.reserve(bound);
-    auto push = [&](const uint32_t* w, size_t n) { pf.insert(pf.end(), w, w + n); };
-    Challenger ch(&ctx->h_p2);
-    ch.observe(init, n_init);
+    }
+    void push(const uint32_t* w, size_t n) { pf.insert(pf.end(), w, w + n); }
 
+    int commit_traces();
+    int permutation_traces();
+    int quotients(const Ext& alpha);
+    int open();
+    int fri();
+    int queries(uint32_t* h_proof, size_t capacity, size_t* proof_words);
+};
+
+int ProofRun::commit_traces() {
     // ---- trace LDEs and their commitment
-    std::vector<TableState> ts(n_tables);
-    std::vector<rk_matrix> tmats(n_tables);
-    size_t Ht = 0;
-    unsigned log_max = 0;
+    ts = std::vector<TableState>(n_tables);
+    tmats.resize(n_tables);
     pf.push_back(n_tables);
     for (uint32_t t = 0; t < n_tables; t++) {
         const rk_p3_table& tb = tables[t];
@@ -371,20 +383,18 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         log_max = std::max(log_max, s.k + blow);
     }
     lap(tm.lde);
-    DevBuf tnodes;
     RK_TRY(tnodes.alloc(ctx, 2 * Ht * p2::OUT * 4));
-    uint32_t root[8];
     RK_TRY(rk_mmcs_commit(ctx, tmats.data(), n_tables, tnodes.u32(), root));
     push(root, 8);
     ch.observe(root, 8);
     for (uint32_t t = 0; t < n_tables; t++) ch.observe(tables[t].public_values, tables[t].n_public);
     lap(tm.commit);
 
+    return RK_OK;
+}
+
+int ProofRun::permutation_traces() {
     // ---- lookups: permutation traces, their LDE and commitment (nothing of this without interactions)
-    std::vector<rk_matrix> pmats;
-    DevBuf pnodes;
-    size_t Hp = 0;
-    std::vector<uint32_t> pchal;   // [alpha | beta^0 | .. | beta^K]: every table reads a prefix
     {
         uint32_t n_chal = 0;
         for (uint32_t t = 0; t < n_tables; t++) n_chal = std::max(n_chal, tables[t].air->n_chal);
@@ -451,11 +461,11 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
             lap(tm.commit);
         }
     }
-    const Ext alpha = ch.sample_ext();
+    return RK_OK;
+}
 
+int ProofRun::quotients(const Ext& alpha) {
     // ---- quotients
-    std::vector<rk_matrix> qmats;
-    size_t Hq = 0;
     for (uint32_t t = 0; t < n_tables; t++) {
         const rk_p3_table& tb = tables[t];
         TableState& s = ts[t];
@@ -520,17 +530,19 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         Hq = std::max(Hq, s.H);
     }
     lap(tm.quotient);
-    DevBuf qnodes;
     RK_TRY(qnodes.alloc(ctx, 2 * Hq * p2::OUT * 4));
     RK_TRY(rk_mmcs_commit(ctx, qmats.data(), (uint32_t)qmats.size(), qnodes.u32(), root));
     push(root, 8);
     ch.observe(root, 8);
-    const Ext zeta = ch.sample_ext();
+    zeta = ch.sample_ext();
     lap(tm.commit);
 
+    return RK_OK;
+}
+
+int ProofRun::open() {
     // ---- PCS open: opened values and reduced openings
     const Ext alpha2 = ch.sample_ext();
-    DevBuf ro[ntt::LAMBDA + 1];
     uint64_t num_reduced[ntt::LAMBDA + 1] = {0};
     // every opened value first (no host round trip between the launches), ONE download, then the reduced openings, which
     // need the opened values on the host: a shard of a dozen tables waits once instead of three dozen times
@@ -582,12 +594,13 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     for (const TableState& s : ts) push(s.y.data(), s.y.size());
     lap(tm.open);
 
+    return RK_OK;
+}
+
+int ProofRun::fri() {
     // ---- FRI commit phase
-    const unsigned n_rounds = log_max - blow;
-    struct Layer {
-        DevBuf values, nodes;   // 2^(log_max - round) extension elements; the tree over their pairs
-    };
-    std::vector<Layer> layers(n_rounds);
+    n_rounds = log_max - blow;
+    layers = std::vector<Layer>(n_rounds);
     DevBuf folded = std::move(ro[log_max]);
     size_t len = (size_t)1 << log_max;
     pf.push_back(n_rounds);
@@ -624,6 +637,10 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
     pf.push_back(witness);
     lap(tm.fri);
 
+    return RK_OK;
+}
+
+int ProofRun::queries(uint32_t* h_proof, size_t capacity, size_t* proof_words) {
     // ---- queries: all indices first (they depend on the transcript only), then one gather
     std::vector<GatherJob> jobs;
     uint32_t at = 0;
@@ -663,8 +680,36 @@ int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const ui
         RK_TRY(d2h(ctx, h_proof + pf.size(), d_out.p, (size_t)at * 4));
     }
     *proof_words = pf.size() + at;
-    lap(tm.query);
-    tm.total = (float)(now_ms() - t_start);
+    return RK_OK;
+}
+
+int p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init, size_t n_init, uint32_t* h_proof,
+             size_t capacity, size_t* proof_words) {
+    ProofRun run(ctx, tables, n_tables);
+    RK_TRY(rk_get_params(ctx, &run.par));
+    RK_TRY(check_tables(run.par, tables, n_tables, true, run.lqd));
+    for (size_t i = 0; i < n_init; i++)
+        if (init[i] >= bb::P) return RK_ERR_INVALID;
+    const size_t bound = proof_bound(run.par, tables, n_tables, run.lqd);
+    if (capacity < bound) {
+        *proof_words = bound;
+        return RK_ERR_CAPACITY;
+    }
+    run.blow = run.par.blowup_log2;
+    run.tm = rk_p3_timing{};
+    const double t_start = now_ms();
+    run.t_mark = t_start;
+    run.pf.reserve(bound);
+    run.ch.observe(init, n_init);
+    RK_TRY(run.commit_traces());
+    RK_TRY(run.permutation_traces());     // nothing of it without interactions
+    const Ext alpha = run.ch.sample_ext();
+    RK_TRY(run.quotients(alpha));
+    RK_TRY(run.open());
+    RK_TRY(run.fri());
+    RK_TRY(run.queries(h_proof, capacity, proof_words));
+    run.lap(run.tm.query);
+    run.tm.total = (float)(now_ms() - t_start);
     return RK_OK;
 }
 
