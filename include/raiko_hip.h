@@ -648,7 +648,7 @@ int rk_p2_chip_trace(rk_ctx* ctx, const uint32_t* d_inputs, const uint32_t* d_mu
  * memory or -- on_device = 1 -- in the memory of the context's GPU (left untouched). */
 typedef struct {
     const uint32_t* trace;
-    uint32_t log_height;           /* 1 .. 24 - blowup_log2; the verifier reads it from the proof */
+    uint32_t log_height;           /* 1 .. 24 - blowup_log2; verifier: 0 = read it from the proof, else the height required */
     uint32_t width;                /* = the AIR's */
     const rk_air* air;
     const uint32_t* public_values; /* host, Montgomery words */
@@ -673,8 +673,9 @@ typedef struct {
  * yields a proof (as in Plonky3's release builds); rk_p3_verify rejects it with reason 3. */
 int rk_p3_prove(rk_ctx* ctx, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,
                 uint32_t* h_proof, size_t capacity_words, size_t* proof_words);
-/* p3-uni-stark `verify` on the host (no GPU): params NULL = the SP1 preset; trace / log_height / on_device of the tables
- * are ignored.  0 = accepted, RK_ERR_INVALID for malformed arguments, otherwise a reason: 1 malformed proof (short,
+/* p3-uni-stark `verify` on the host (no GPU): params NULL = the SP1 preset; trace / on_device of the tables are ignored;
+ * log_height = 0 takes the table's height from the proof, any other value PINS it (the proof must carry that height: what
+ * a statement with a fixed-size table -- all 2^16 values of a range check -- needs).  0 = accepted, RK_ERR_INVALID for malformed arguments, otherwise a reason: 1 malformed proof (short,
  * trailing or non-canonical words), 2 shape mismatch, 3 constraint identity (OodEvaluationMismatch), 4 proof of work,
  * 5 input opening, 6 commit-phase opening, 7 final polynomial, 8 the cumulative sums of the lookups do not cancel. */
 int rk_p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tables, const uint32_t* init_words, size_t n_init,

@@ -516,6 +516,7 @@ int or_p3_verify(const or_p3_table* tables, uint32_t n_tables, const fp* init, s
     for (uint32_t t = 0; t < n_tables; t++) {
         log_n[t] = *rd_take(&r, 1);
         if (r.bad || log_n[t] < 1 || log_n[t] + blow > 24) return 2;
+        if (tables[t].log_height && tables[t].log_height != log_n[t]) return 2;   /* a height the statement pins */
         if (air_check(tables[t].air, tables[t].width, tables[t].n_public) != 0) return -1;
         int d = or_air_log_quotient_degree(tables[t].air);
         if (d < 0 || (unsigned)d > blow) return 2;

@@ -227,7 +227,7 @@ typedef struct { uint32_t kind, bus, mult_is_const, mult, n_values; const uint32
 typedef struct { const or_air_step* steps; size_t n_steps; const or_interaction* interactions; uint32_t n_interactions; } or_air;
 typedef struct {
     const fp* trace;               /* row-major 2^log_height x width (prover only) */
-    uint32_t log_height, width;    /* the verifier takes log_height from the proof */
+    uint32_t log_height, width;    /* the verifier takes log_height from the proof when 0, else requires it */
     const or_air* air;
     const fp* public_values; uint32_t n_public;
 } or_p3_table;

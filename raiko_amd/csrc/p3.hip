@@ -771,6 +771,7 @@ int p3_verify(const rk_params* params, const rk_p3_table* tables, uint32_t n_tab
     for (uint32_t t = 0; t < n_tables; t++) {
         log_n[t] = hdr[1 + t];
         if (log_n[t] < 1 || log_n[t] + blow > ntt::LAMBDA) return 2;
+        if (tables[t].log_height && tables[t].log_height != log_n[t]) return 2;   // a height the statement pins (a 2^16-row range table)
         log_max = std::max(log_max, log_n[t] + blow);
     }
     Challenger ch(k.get());

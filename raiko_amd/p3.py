@@ -423,6 +423,8 @@ def _c_tables(tables, device_traces=None):
         elif t.trace is not None:
             arr[i].trace = t.trace.ctypes.data
             arr[i].log_height = t.log_height
+        elif getattr(t, "log_height", 0):       # no trace (a verifier's table): the height the statement pins
+            arr[i].log_height = t.log_height
     return arr, keep
 
 

@@ -352,6 +352,8 @@ def _or_p3_tables(tables):
             keep.append(tr)
             arr[i].trace = tr.ctypes.data
             arr[i].log_height = t.log_height
+        elif getattr(t, "log_height", 0):
+            arr[i].log_height = t.log_height
         arr[i].width = t.air.width
         arr[i].air = C.pointer(air)
         arr[i].public_values = pv.ctypes.data

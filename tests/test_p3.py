@@ -233,6 +233,14 @@ def test_lookups_that_do_not_balance_are_rejected_by_both_verifiers(params, pres
     s = pf.copy()
     s[at] = (int(s[at]) + 5) % P
     assert o.oracle_p3_verify(tables, s, init) == 8 == p3.verify(tables, s, init, params=blob)
+    # a verifier can pin a table's height (the range table must hold ALL values): the proof's own height word is not enough
+    free = [p3.Table(t.air, None, t.public_values) for t in tables]
+    assert p3.verify(free, pf, init, params=blob) == 0 == o.oracle_p3_verify(free, pf, init)       # heights from the proof
+    pinned = [p3.Table(t.air, None, t.public_values) for t in tables]
+    pinned[3].log_height = tables[3].log_height
+    assert p3.verify(pinned, pf, init, params=blob) == 0 == o.oracle_p3_verify(pinned, pf, init)
+    pinned[3].log_height = tables[3].log_height + 1
+    assert p3.verify(pinned, pf, init, params=blob) == 2 == o.oracle_p3_verify(pinned, pf, init)
     # the same tables under an AIR whose lookup constraints were built for the other extension do not verify
     wrong = p3.lookup_demo_airs(EXT_W[1 - preset])
     wt = [p3.Table(a, t.trace, t.public_values) for a, t in zip(wrong, tables)]
