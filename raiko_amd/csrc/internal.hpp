@@ -116,6 +116,7 @@ int post_launch(rk_ctx* ctx, const char* what);
 
 // NTT (kernels_ntt.hip)
 int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fuse_zk_shift);
+int ntt_reverse_from(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t size, size_t count, bool fuse_zk_shift);
 int ntt_forward(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_size, size_t count,
                 unsigned expand_bits);
 int zk_shift(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count);

@@ -268,24 +268,29 @@ inline bool aligned16(const void* p, const void* q) { return ((((uintptr_t)p) | 
 
 namespace rk {
 
-int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fuse_zk_shift) {
+// d_dst <- interpolation of d_src (may be the same buffer): the FIRST pass reads d_src and writes d_dst, the others run in
+// place on d_dst -- a caller that must leave its input untouched (on_device = 1 traces) needs no copy in front of the
+// transform
+int ntt_reverse_from(rk_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t size, size_t count, bool fuse_zk_shift) {
     if (!is_pow2(size) || size > ((size_t)1 << ntt::LAMBDA) || count == 0) return RK_ERR_INVALID;
     unsigned k = log2u(size);
     uint32_t scale = bb::inv(bb::encode((uint32_t)size));
     if (k == 0) {
         // size-1 transform: identity (1/1 scale, 3^0 shift)
+        if (d_dst != d_src) RK_HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
         return RK_OK;
     }
-    if (nf::usable(k, 0, aligned16(d_io, d_io)) && count <= 0xffffffffu) {
+    if (nf::usable(k, 0, aligned16(d_dst, d_src)) && count <= 0xffffffffu) {
         // strided pass (top k - 14 stages), then 2^14-point sub-transforms with the four-step twiddle on
         // the way in and 1/n (and the zk shift) on the way out
         nf::Args a{};
-        a.dst = d_io;
-        a.src = d_io;
+        a.dst = d_dst;
+        a.src = d_src;
         a.n = a.n_src = size;
         a.k = k;
         a.count = (unsigned)count;
         RK_TRY(launch_nf_strided<false>(ctx, a));
+        a.src = d_dst;
         RK_TRY(nf_table(ctx, 1, k, &a.fs));
         if (fuse_zk_shift) RK_TRY(nf_table(ctx, 2, k, &a.zk));
         a.scale = scale;
@@ -294,8 +299,8 @@ int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fus
     ntt::Plan plan = ntt::make_plan(k);
     for (unsigned p = 0; p < plan.npass; p++) {
         ntt::PassArgs a{};
-        a.dst = d_io;
-        a.src = d_io;
+        a.dst = d_dst;
+        a.src = p == 0 ? d_src : d_dst;
         a.n = size;
         a.n_src = size;
         a.mu = plan.mu[p];
@@ -308,6 +313,9 @@ int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fus
         RK_TRY(launch_pass<false>(ctx, a, count));
     }
     return RK_OK;
+}
+int ntt_reverse(rk_ctx* ctx, uint32_t* d_io, size_t size, size_t count, bool fuse_zk_shift) {
+    return ntt_reverse_from(ctx, d_io, d_io, size, count, fuse_zk_shift);
 }
 
 int ntt_forward(rk_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t in_size, size_t count,

@@ -351,8 +351,15 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     // and host inputs are uploaded once into `raw` and copied from there.
     DevBuf raw[3];
     const uint32_t* d_raw[3] = {nullptr, nullptr, nullptr};
-    auto load_group = [&](int g, DevBuf& dst, const uint32_t* src, size_t words) -> int {
-        if (!hook_accum || g == 0) return load_trace(dst, src, words);
+    // `from`: where the interpolation's first pass reads the trace when that is not `dst` itself -- a device input that
+    // must stay untouched is never copied, the transform's first pass reads it and writes the prover's own buffer
+    auto load_group = [&](int g, DevBuf& dst, const uint32_t* src, size_t words, const uint32_t*& from) -> int {
+        from = nullptr;
+        if (!hook_accum || g == 0) {
+            if (seg->on_device != 1) return load_trace(dst, src, words);   // given up (in place) or a host buffer (upload)
+            from = src;
+            return dst.alloc(ctx, words * 4);
+        }
         if (seg->on_device) {
             d_raw[g] = src;
         } else {
@@ -360,15 +367,15 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
             RK_HIP_TRY(ctx, hipMemcpyAsync(raw[g].p, src, words * 4, hipMemcpyHostToDevice, ctx->stream));
             d_raw[g] = raw[g].u32();
         }
-        RK_TRY(dst.alloc(ctx, words * 4));
-        RK_HIP_TRY(ctx, hipMemcpyAsync(dst.p, d_raw[g], words * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        return RK_OK;
+        from = d_raw[g];
+        return dst.alloc(ctx, words * 4);
     };
     // Prover::commit_group; `preloaded`: pg.coeffs already holds the trace (written by a hook)
     auto commit_group = [&](int g, PolyGroup& pg, const uint32_t* trace, size_t count, bool preloaded = false) -> int {
-        if (!preloaded) RK_TRY(load_group(g, pg.coeffs, trace, count * N));
+        const uint32_t* from = nullptr;
+        if (!preloaded) RK_TRY(load_group(g, pg.coeffs, trace, count * N, from));
         sw.start("ntt");
-        RK_TRY(rk::ntt_reverse(ctx, pg.coeffs.u32(), N, count, /*fuse_zk_shift=*/true));
+        RK_TRY(rk::ntt_reverse_from(ctx, pg.coeffs.u32(), from ? from : pg.coeffs.u32(), N, count, /*fuse_zk_shift=*/true));
         RK_TRY(pg.build(ctx, count, N));
         sw.stop(&ctx->timing.ntt);
         sw.start("hash");
@@ -416,6 +423,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
 
     // Prover::finalize
     const Ext poly_mix = iop.random_ext();
+    const uint32_t* check_from = nullptr;
     if (hook_check) {
         // CircuitHal::eval_check over the LDE domain, into the buffer that becomes the check group
         RK_TRY(check.coeffs.alloc(ctx, 4 * D * 4));
@@ -431,6 +439,9 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
             RK_TRY(rk::program_eval_check(hooks->program, &view, poly_mix.c, check.coeffs.u32()));
         }
         sw.stop(&ctx->timing.circuit);
+    } else if (seg->on_device == 1) {
+        RK_TRY(check.coeffs.alloc(ctx, 4 * D * 4));   // pre-computed stand-in, left untouched: read by the transform's first pass
+        check_from = seg->check;
     } else {
         RK_TRY(load_trace(check.coeffs, seg->check, 4 * D));  // pre-computed stand-in
     }
@@ -441,7 +452,7 @@ int prove_segment(rk_ctx* ctx, const rk_segment* seg, std::vector<uint32_t>& sea
     // verifier's remap [0,2,1,3]).
     // No zk_shift here: the hook evaluates at x_i = 3*w^i, so these already are the coefficients
     // of y -> check(3y), the form every PolyGroup is kept in (recalled items).
-    RK_TRY(rk::ntt_reverse(ctx, check.coeffs.u32(), D, 4, false));
+    RK_TRY(rk::ntt_reverse_from(ctx, check.coeffs.u32(), check_from ? check_from : check.coeffs.u32(), D, 4, false));
     RK_TRY(check.build(ctx, CHECK_SIZE, N));
     sw.stop(&ctx->timing.ntt);
     sw.start("hash");
