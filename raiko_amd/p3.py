@@ -502,15 +502,14 @@ def verify_hashes(tables, proof, init=(), params=None):
     w = int(params.p2_width) if params is not None else 16
     n = C.c_size_t(0)
     par = C.byref(params) if params is not None else None
-    rc = lib.rk_p3_verify_hashes(par, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size, pf.ctypes.data_as(_lib.u32p), pf.size,
-                                 None, 0, C.byref(n))
-    if rc != _lib.RK_ERR_CAPACITY:
-        if rc < 0:
-            _lib.check(None, rc)
-        return rc, np.zeros((0, w), dtype=np.uint32)
-    states = np.zeros((n.value, w), dtype=np.uint32)
-    rc = lib.rk_p3_verify_hashes(par, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size, pf.ctypes.data_as(_lib.u32p), pf.size,
-                                 states.ctypes.data_as(_lib.u32p), n.value, C.byref(n))
+    cap = 1 << 16                  # enough for a 100-query proof of a few tables: one pass; otherwise the call says how many
+    while True:
+        states = np.zeros((cap, w), dtype=np.uint32)
+        rc = lib.rk_p3_verify_hashes(par, arr, len(tables), iw.ctypes.data_as(_lib.u32p), iw.size, pf.ctypes.data_as(_lib.u32p), pf.size,
+                                     states.ctypes.data_as(_lib.u32p), cap, C.byref(n))
+        if rc != _lib.RK_ERR_CAPACITY:
+            break
+        cap = n.value
     if rc < 0:
         _lib.check(None, rc)
     del keep
