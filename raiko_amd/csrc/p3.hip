@@ -1013,8 +1013,11 @@ struct ShardPool {
     std::mutex busy;                 // one batch at a time per device
     std::vector<rk_ctx*> ctxs;
     std::vector<std::vector<uint32_t>> key;   // the parameter set each context carries
+    rk_ctx* uploader = nullptr;      // stages host-resident traces ahead of the provers (its own stream)
+    std::mutex up_mu;                // the uploader's allocator: the feeder allocates, the provers free
     ~ShardPool() {
         for (rk_ctx* c : ctxs) (void)rk_ctx_destroy(c);
+        if (uploader) (void)rk_ctx_destroy(uploader);
     }
 };
 std::mutex g_shard_mu;
@@ -1079,6 +1082,7 @@ int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t 
             RK_TRY(rk_set_params(pool.ctxs[j], &par));
             pool.key[j] = key;
         }
+        if (!pool.uploader) RK_TRY(rk_ctx_create(devices[d], nullptr, &pool.uploader));
     }
     std::atomic<size_t> next{0};
     std::mutex mu;
@@ -1095,22 +1099,96 @@ int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t 
         }
         cv.notify_all();
     };
-    auto worker = [&](rk_ctx* ctx) {
+    // One feeder per device claims shards from the common queue and, for traces in host memory, uploads them into device
+    // buffers AHEAD of the provers (a single thread per device keeps the PCIe link busy with one stream of copies, and a
+    // proof never waits for its own upload); the provers then see on_device tables.  At most `per_dev + 1` staged shards
+    // per device.
+    struct Staged {
+        size_t idx = 0;
+        std::vector<rk_p3_table> tables;
+        std::vector<void*> bufs;
+    };
+    struct DevQueue {
+        std::deque<std::unique_ptr<Staged>> ready;
+        size_t outstanding = 0;     // staged or being proven
+        bool feeder_done = false;
+    };
+    std::vector<DevQueue> dq(devices.size());
+    auto release = [&](ShardPool& pool, Staged& st) {
+        std::lock_guard<std::mutex> l(pool.up_mu);
+        for (void* b : st.bufs) (void)rk_free(pool.uploader, b);
+        st.bufs.clear();
+    };
+    auto feeder = [&](size_t d) {
+        ShardPool& pool = *pools[d];
         for (;;) {
             {
-                std::lock_guard<std::mutex> l(mu);
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return status != RK_OK || dq[d].outstanding < per_dev + 1; });
                 if (status != RK_OK) break;
             }
             const size_t i = next.fetch_add(1);
             if (i >= n) break;
+            auto st = std::make_unique<Staged>();
+            st->idx = i;
+            const rk_p3_shard& sh = shards[i];
+            int rc = sh.tables && sh.n_tables ? RK_OK : RK_ERR_INVALID;
+            if (rc == RK_OK) st->tables.assign(sh.tables, sh.tables + sh.n_tables);
+            for (uint32_t t = 0; rc == RK_OK && t < sh.n_tables; t++) {
+                rk_p3_table& tb = st->tables[t];
+                if (tb.on_device || !tb.trace || tb.log_height < 1 || tb.log_height > ntt::LAMBDA || tb.width == 0) continue;   // the prover refuses what is malformed
+                const size_t bytes = ((size_t)tb.width << tb.log_height) * 4;
+                void* buf = nullptr;
+                {
+                    std::lock_guard<std::mutex> l(pool.up_mu);
+                    rc = rk_alloc(pool.uploader, bytes, &buf);
+                }
+                if (rc != RK_OK) break;
+                st->bufs.push_back(buf);
+                rc = rk_h2d(pool.uploader, buf, tb.trace, bytes);      // copy + wait on the uploader's own stream
+                tb.trace = (const uint32_t*)buf;
+                tb.on_device = 1;
+            }
+            if (rc != RK_OK) {
+                release(pool, *st);
+                fail(rc, i);
+                break;
+            }
+            std::lock_guard<std::mutex> l(mu);
+            dq[d].outstanding++;
+            dq[d].ready.push_back(std::move(st));
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> l(mu);
+        dq[d].feeder_done = true;
+        cv.notify_all();
+    };
+    auto worker = [&](rk_ctx* ctx, size_t d) {
+        ShardPool& pool = *pools[d];
+        for (;;) {
+            std::unique_ptr<Staged> st;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return status != RK_OK || !dq[d].ready.empty() || dq[d].feeder_done; });
+                if (status != RK_OK || dq[d].ready.empty()) break;
+                st = std::move(dq[d].ready.front());
+                dq[d].ready.pop_front();
+            }
+            const size_t i = st->idx;
             rk_p3_shard& sh = shards[i];
-            int st = RK_ERR_INTERNAL;
+            int rc = RK_ERR_INTERNAL;
             try {
-                st = rk_p3_prove(ctx, sh.tables, sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.capacity_words, &sh.proof_words);
+                rc = rk_p3_prove(ctx, st->tables.data(), sh.n_tables, sh.init_words, sh.n_init, sh.h_proof, sh.capacity_words, &sh.proof_words);
             } catch (...) {
             }
-            if (st != RK_OK) {
-                fail(st, i);
+            release(pool, *st);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                dq[d].outstanding--;
+                cv.notify_all();
+            }
+            if (rc != RK_OK) {
+                fail(rc, i);
                 break;
             }
             if (opts->verify) {   // host work (~40 ms for 100 queries): never on the thread that feeds the GPU
@@ -1147,8 +1225,10 @@ int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t 
     };
     std::vector<std::thread> threads;
     workers_left = devices.size() * per_dev;
-    for (size_t d = 0; d < devices.size(); d++)
-        for (size_t j = 0; j < per_dev; j++) threads.emplace_back(worker, pools[d]->ctxs[j]);
+    for (size_t d = 0; d < devices.size(); d++) {
+        threads.emplace_back(feeder, d);
+        for (size_t j = 0; j < per_dev; j++) threads.emplace_back(worker, pools[d]->ctxs[j], d);
+    }
     if (opts->verify) {
         const unsigned hw = std::thread::hardware_concurrency();
         size_t nv = std::min<size_t>(std::min<size_t>(16, 4 * devices.size()), std::max<unsigned>(1, hw / 4));
@@ -1156,6 +1236,8 @@ int p3_prove_shards(const rk_p3_session_opts* opts, rk_p3_shard* shards, size_t 
         for (size_t v = 0; v < nv; v++) threads.emplace_back(verifier);
     }
     for (auto& t : threads) t.join();
+    for (size_t d = 0; d < devices.size(); d++)     // a failed run leaves staged shards nobody proved
+        for (auto& st : dq[d].ready) release(*pools[d], *st);
     if (failed_index) *failed_index = failed;
     return status;
 }

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--shards", type=int, default=0, help="also prove this many copies of the shape as independent shards through "
                                                           "rk_p3_prove_shards with --batch of them in flight (SP1's SHARD_BATCH_SIZE)")
     ap.add_argument("--batch", type=int, default=3)
+    ap.add_argument("--host-traces", action="store_true", help="also time the shards with the traces in (pageable) host memory: "
+                                                                  "what a caller with CPU-generated traces pays over PCIe")
     ap.add_argument("--lookups", type=int, default=0, help="every table sends and receives this many tuples (2x interactions): "
                                                            "the permutation argument's cost on top of the plain proof")
     args = ap.parse_args()
@@ -96,6 +98,22 @@ def run(args):
         out["shards"] = {"n": args.shards, "batch": args.batch, "wall_ms": round(dt * 1e3, 2), "ms_per_shard": round(dt * 1e3 / args.shards, 3),
                          "cells_per_s": round(cells * args.shards / dt, 1), "verified_inside": not args.no_verify,
                          "distinct_proofs": len({pf.tobytes() for pf in proofs})}
+    if getattr(args, "host_traces", False):
+        host_tables = []
+        for t, b in zip(tables, bufs):
+            ht = p3.Table(t.air, b.cpu().numpy().view(np.uint32), [])
+            host_tables.append(ht)
+        n_sh = max(getattr(args, "shards", 0), 6)
+        shards = [(host_tables, [i + 1]) for i in range(n_sh)]
+        p3.prove_shards(shards[: args.batch], blob, batch=args.batch, verify=False)
+        t4 = time.perf_counter()
+        p3.prove_shards(shards, blob, batch=args.batch, verify=False)
+        dt = time.perf_counter() - t4
+        t5 = time.perf_counter()
+        p3.prove(hal, host_tables)
+        one = time.perf_counter() - t5
+        out["host_traces"] = {"n": n_sh, "batch": args.batch, "ms_per_shard": round(dt * 1e3 / n_sh, 3), "cells_per_s": round(cells * n_sh / dt, 1),
+                              "one_proof_ms": round(one * 1e3, 3), "trace_bytes": int(cells * 4)}
     hal.close()
     return out
 
