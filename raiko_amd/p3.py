@@ -11,6 +11,14 @@ symbolic_builder.rs, RECALLED): every step but ASSERT_ZERO pushes one value, ope
     b.when_first_row().assert_eq(l, b.public(0))
     b.when_transition().assert_eq(nl, r)
     air = b.build()
+
+Tables of one proof may look values up in each other (sp1-core's LogUp permutation argument): `b.send(bus, cols, mult)` /
+`b.receive(..)` list the interactions; `build()` writes the permutation constraints itself or -- `library_constraints=True`
+-- leaves them to rk_air_create_lookup.  `poseidon2_chip_air` / `poseidon2_chip_trace` are the Poseidon2 permutation as a
+table (rows written on the GPU), `merkle_path_air` a table that verifies Merkle paths by looking its compressions up in it,
+`verify_hashes` the list of permutations one verification performs: pieces of a recursion / compress layer.
+`prove` / `prove_shards` / `verify` are the calls; `lookup_demo_airs`, `fibonacci_air`, `cubic_air`, `wide_air`, `local_air`
+the example AIRs the tests and benches use.
 """
 import ctypes as C
 
