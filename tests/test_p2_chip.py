@@ -245,3 +245,27 @@ def test_gpu_proves_device_generated_chip_rows():
     finally:
         o.oracle_set_params()
         h.close()
+
+
+def test_new_entry_points_refuse_malformed_arguments():
+    """NULL / out-of-range arguments come back as RK_ERR_INVALID (or RK_ERR_CAPACITY with the size needed), nothing is touched"""
+    import ctypes as C
+    from raiko_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rk_p2_chip_air(None, P, C.byref(h)) == -1                       # bus not canonical
+    assert lib.rk_p2_chip_air(None, 4, None) == -1
+    assert lib.rk_p2_chip_width(None) == 314
+    bad = hal.make_params(1)
+    bad.p2_width = 20
+    assert lib.rk_p2_chip_width(C.byref(bad)) == 0 and lib.rk_p2_chip_air(C.byref(bad), 4, C.byref(h)) == -1
+    assert lib.rk_p2_chip_trace(None, None, None, 4, None) == -1
+    n = C.c_size_t(0)
+    assert lib.rk_air_get_steps(None, None, 0, C.byref(n)) == -1
+    air = p3.fibonacci_air()
+    assert lib.rk_air_get_steps(air.handle(), None, 0, C.byref(n)) == _lib.RK_ERR_CAPACITY and n.value == air.steps.shape[0]
+    out = np.zeros((n.value, 3), dtype=np.uint32)
+    assert lib.rk_air_get_steps(air.handle(), out.ctypes.data, n.value, C.byref(n)) == 0 and np.array_equal(out, air.steps)
+    assert lib.rk_p3_verify_hashes(None, None, 0, None, 0, None, 0, None, 0, None) == -1
+    assert lib.rk_p3_verify_hashes(None, None, 0, None, 0, None, 0, None, 0, C.byref(n)) == -1      # no tables
+    assert lib.rk_exec_lookup_tables(None, 0, None, None, None) == -1
