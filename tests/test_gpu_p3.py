@@ -254,4 +254,16 @@ def test_elf_to_shard_proofs(hal):
         assert all(np.array_equal(x.trace, y.trace) for x, y in zip(ta, tb))
     plain = X.execute_and_prove_p3_pipelined(image, shard_po2=13, params=blob, lookups=False, compile_airs=False)[1]
     assert all(np.array_equal(a, b) for a, b in zip(plain, proofs))
+    # a guest that traps in its third shard: the error surfaces, the prover thread and the contexts are wound down, and the
+    # pipeline object proves the next program
+    trap = A.li("a2", 5000) + ["loop:", ("addi", "a3", "a3", 3), ("xor", "a4", "a4", "a3"), ("addi", "a2", "a2", -1),
+                               ("bne", "a2", "zero", "loop"), ("word", 0xFFFFFFFF)]
+    pipe = X.P3Pipeline(blob, compile_airs=False)
+    try:
+        with pytest.raises(X.ExecutorError):
+            pipe.run(A.elf(A.assemble(trap)[0]), shard_po2=13)
+        again = pipe.run(image, shard_po2=13)[1]
+        assert all(np.array_equal(a, b) for a, b in zip(again, lproofs))
+    finally:
+        pipe.close()
     H.session_release()
